@@ -1,0 +1,52 @@
+/*
+ * rwkv_mi355x.h -- opt-in extensions of librwkv.so for MI355X. None of these change the behaviour of the rwkv.h entry
+ * points; they expose what the device-resident engine can do beyond the reference ABI:
+ *
+ *  - the recurrent state can stay in HBM between calls (the reference ABI hands the whole state in and out through host
+ *    memory on every call, rwkv_eval.inc:2-22 -- 34.6 MB each way for RWKV-6 7B, i.e. as long as the token itself);
+ *  - a greedy decode loop that never leaves the device (argmax on the GPU feeds the next embedding lookup);
+ *  - the numbers the benchmark needs (algorithmic bytes per token).
+ */
+#ifndef RWKV_MI355X_H
+#define RWKV_MI355X_H
+
+#include "rwkv.h"
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+/* Copies a host state (or a fresh state when NULL) into the context's device-resident state. */
+RWKV_API bool rwkv_mi_state_load(struct rwkv_context * ctx, const float * state_in);
+/* Copies the device-resident state to host memory (FP32[rwkv_get_state_len]). */
+RWKV_API bool rwkv_mi_state_store(struct rwkv_context * ctx, float * state_out);
+
+/* Like rwkv_eval_sequence, but continues from and updates the device-resident state; no state traffic over PCIe.
+ * logits_out (of the last token) may be NULL. */
+RWKV_API bool rwkv_mi_eval_resident(struct rwkv_context * ctx, const uint32_t * tokens, size_t n_tokens, float * logits_out);
+
+/* Greedy single-stream decode entirely on the device: feeds first_token, then n_tokens - 1 times the argmax of the
+ * previous logits. tokens_out[i] = argmax after step i (may be NULL). elapsed_ms (may be NULL) receives the HIP-event
+ * time of the whole loop measured on the context's stream. */
+RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, uint32_t * tokens_out, float * elapsed_ms);
+
+/* Algorithmic HBM bytes one decoded token must move on this context's layers: every parameter once (file dtype), one
+ * embedding row, state read + write, logits write. */
+RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx);
+RWKV_API uint64_t rwkv_mi_weight_bytes(const struct rwkv_context * ctx);
+
+/* Detected architecture (4, 5.1, 5.2, 6, 7) and head geometry. Any pointer may be NULL. */
+RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major, uint32_t * minor, uint32_t * head_count, uint32_t * head_size);
+
+/* Single-token steps are replayed from a captured hipGraph by default; disable for debugging / profiling per kernel. */
+RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled);
+
+/* Test hook (used by tests/ only): y[T][N] = W[N][K] . x[T][K] through the production projection kernels. `w` holds N rows
+ * in the FILE layout of `type` (rwkv.cpp type id: 0 FP32, 1 FP16, 2 Q4_0, 3 Q4_1, 7 Q5_0, 8 Q5_1, 9 Q8_0). */
+RWKV_API bool rwkv_mi_test_mul_mat(int type, const void * w, int64_t K, int64_t N, const float * x, int64_t T, float * y);
+
+#if defined(__cplusplus)
+}
+#endif
+
+#endif

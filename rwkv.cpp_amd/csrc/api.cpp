@@ -1,0 +1,315 @@
+// api.cpp -- the C ABI of librwkv.so: the reference's rwkv.h entry points (reference rwkv.cpp:71-258, rwkv_eval.inc:38-241)
+// re-implemented on the device-resident engine, plus the opt-in rwkv_mi_* extensions (include/rwkv_mi355x.h).
+#include "model.h"
+#include "rwkv_mi355x.h"
+
+#include <cinttypes>
+#include <cstring>
+#include <string>
+
+using namespace rwkvmi;
+
+#define HIP_CTX_OK(CTX, CALL) \
+    do { hipError_t e_ = (CALL); RW_CTX_CHECK((CTX), RWKV_ERROR_GRAPH, false, e_ == hipSuccess, "HIP error: %s", hipGetErrorString(e_)); } while (0)
+
+// Sequence calls are cut into pieces of at most this many tokens internally (bounds scratch memory; results do not
+// depend on the cut because every kernel is per-token order-preserving).
+static const size_t k_max_tokens_per_pass = 1024;
+
+static bool upload_tokens(rwkv_context * ctx, const uint32_t * tokens, size_t n) {
+    if ((int64_t) n > ctx->d_tokens_cap) {
+        HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_tokens) (void) hipFree(ctx->d_tokens);
+        if (ctx->h_tokens) (void) hipHostFree(ctx->h_tokens);
+        ctx->d_tokens = nullptr; ctx->h_tokens = nullptr; ctx->d_tokens_cap = 0;
+        size_t cap = n < 64 ? 64 : n;
+        HIP_CTX_OK(ctx, hipMalloc((void **) &ctx->d_tokens, cap * sizeof(uint32_t)));
+        HIP_CTX_OK(ctx, hipHostMalloc((void **) &ctx->h_tokens, cap * sizeof(uint32_t), hipHostMallocDefault));
+        ctx->d_tokens_cap = (int64_t) cap;
+        // captured graphs hold the old token pointer
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (ctx->graph_exec[a][b]) { (void) hipGraphExecDestroy(ctx->graph_exec[a][b]); ctx->graph_exec[a][b] = nullptr; }
+    }
+    // the previous pass may still be reading h_tokens through an in-flight copy
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(ctx->h_tokens, tokens, n * sizeof(uint32_t));
+    HIP_CTX_OK(ctx, hipMemcpyAsync(ctx->d_tokens, ctx->h_tokens, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    return true;
+}
+
+// Runs tokens[0..n) from the device-resident state; logits (of the last token) stay in ctx->d_logits.
+static bool run_tokens(rwkv_context * ctx, const uint32_t * tokens, size_t n, bool want_logits) {
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    size_t done = 0;
+    while (done < n) {
+        const size_t step = (n - done) < k_max_tokens_per_pass ? (n - done) : k_max_tokens_per_pass;
+        const bool last = done + step == n;
+        if (!upload_tokens(ctx, tokens + done, step)) return false;
+        const bool ok = (step == 1) ? forward_decode(ctx, want_logits && last) : forward(ctx, (int64_t) step, want_logits && last);
+        if (!ok) return false;
+        done += step;
+    }
+    return true;
+}
+
+static bool fetch_outputs(rwkv_context * ctx, float * state_out, float * logits_out) {
+    if (state_out && !state_to_host(ctx, state_out)) return false;
+    if (logits_out) HIP_CTX_OK(ctx, hipMemcpyAsync(logits_out, ctx->d_logits, (size_t) ctx->model->n_vocab() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return true;
+}
+
+extern "C" {
+
+RWKV_API struct rwkv_context * rwkv_init_from_file(const char * file_path, const uint32_t n_threads, const uint32_t n_gpu_layers) {
+    (void) n_gpu_layers;  // every layer runs on the GPU; the layer pipeline (rwkv_mi_init_stage) supersedes partial offload
+    g_last_error = RWKV_ERROR_NONE;
+    RW_CHECK(RWKV_ERROR_ARGS, nullptr, file_path != nullptr, "model_file_path is NULL");
+    Model * m = load_model(file_path, 0, UINT32_MAX);
+    if (!m) return nullptr;
+    rwkv_context * ctx = create_context(m, n_threads);
+    return ctx;  // on failure create_context has already released the model
+}
+
+RWKV_API struct rwkv_context * rwkv_clone_context(struct rwkv_context * ctx, const uint32_t n_threads) {
+    RW_CHECK(RWKV_ERROR_ARGS, nullptr, ctx != nullptr, "ctx is NULL");
+    (void) hipSetDevice(ctx->model->device);
+    rwkv_context * clone = create_context(ctx->model, n_threads);
+    if (clone) clone->print_errors = ctx->print_errors;
+    return clone;
+}
+
+RWKV_API bool rwkv_eval(struct rwkv_context * ctx, const uint32_t token, const float * state_in, float * state_out, float * logits_out) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    const size_t n_vocab = (size_t) ctx->model->n_vocab();
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, token < n_vocab, "Token (%" PRId32 ") is out of range (0 .. %zu)", (int32_t) token, n_vocab - 1);
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    if (!state_from_host(ctx, state_in)) return false;
+    if (!run_tokens(ctx, &token, 1, logits_out != nullptr)) return false;
+    return fetch_outputs(ctx, state_out, logits_out);
+}
+
+RWKV_API bool rwkv_eval_sequence(struct rwkv_context * ctx, const uint32_t * sequence, const size_t sequence_len,
+                                 const float * state_in, float * state_out, float * logits_out) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, sequence_len > 0, "Sequence length is 0");
+    if (sequence) {
+        const size_t n_vocab = (size_t) ctx->model->n_vocab();
+        for (size_t i = 0; i < sequence_len; i++) {
+            RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, sequence[i] < n_vocab, "Token at index %zu (%" PRId32 ") is out of range (0 .. %zu)",
+                         i, (int32_t) sequence[i], n_vocab - 1);
+        }
+    } else {
+        // "prepare only": the reference builds and caches the graph for this length; nothing to build here.
+        return true;
+    }
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    if (!state_from_host(ctx, state_in)) return false;
+    if (!run_tokens(ctx, sequence, sequence_len, logits_out != nullptr)) return false;
+    return fetch_outputs(ctx, state_out, logits_out);
+}
+
+RWKV_API bool rwkv_eval_sequence_in_chunks(struct rwkv_context * ctx, const uint32_t * tokens, const size_t sequence_len, const size_t chunk_size,
+                                           const float * state_in, float * state_out, float * logits_out) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, sequence_len > 0, "Sequence length is 0");
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, chunk_size > 0, "Chunk size is 0");
+    if (!tokens) return true;
+    const size_t n_vocab = (size_t) ctx->model->n_vocab();
+    for (size_t i = 0; i < sequence_len; i++) {
+        RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, tokens[i] < n_vocab, "Token at index %zu (%" PRId32 ") is out of range (0 .. %zu)",
+                     i, (int32_t) tokens[i], n_vocab - 1);
+    }
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    if (!state_from_host(ctx, state_in)) return false;
+    // The state stays in HBM between chunks; only the final chunk produces logits (reference rwkv_eval.inc:183-218).
+    size_t done = 0;
+    while (done < sequence_len) {
+        const size_t step = (sequence_len - done) < chunk_size ? (sequence_len - done) : chunk_size;
+        const bool last = done + step == sequence_len;
+        if (!run_tokens(ctx, tokens + done, step, last && logits_out != nullptr)) return false;
+        done += step;
+    }
+    return fetch_outputs(ctx, state_out, logits_out);
+}
+
+RWKV_API size_t rwkv_get_n_vocab(const struct rwkv_context * ctx) { return (size_t) ctx->model->n_vocab(); }
+RWKV_API size_t rwkv_get_n_embed(const struct rwkv_context * ctx) { return (size_t) ctx->model->n_embed(); }
+RWKV_API size_t rwkv_get_n_layer(const struct rwkv_context * ctx) { return (size_t) ctx->model->n_layer(); }
+RWKV_API size_t rwkv_get_state_len(const struct rwkv_context * ctx) { return (size_t) ctx->model->state_len(); }
+RWKV_API size_t rwkv_get_logits_len(const struct rwkv_context * ctx) { return (size_t) ctx->model->n_vocab(); }
+RWKV_API uint32_t rwkv_get_state_buffer_element_count(const struct rwkv_context * ctx) { return (uint32_t) rwkv_get_state_len(ctx); }
+RWKV_API uint32_t rwkv_get_logits_buffer_element_count(const struct rwkv_context * ctx) { return (uint32_t) rwkv_get_logits_len(ctx); }
+
+RWKV_API void rwkv_init_state(const struct rwkv_context * ctx, float * state) {
+    const Model & m = *ctx->model;
+    const size_t n = (size_t) m.state_len();
+    memset(state, 0, n * sizeof(float));
+    if (m.arch_major >= 5) return;
+    const size_t D = (size_t) m.n_embed();
+    for (size_t l = 0; l < (size_t) m.n_layer(); l++) {
+        float * pp = state + l * 5 * D + 4 * D;
+        for (size_t i = 0; i < D; i++) pp[i] = -1e30F;
+    }
+}
+
+RWKV_API void rwkv_free(struct rwkv_context * ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->model->device);
+    destroy_context(ctx);
+}
+
+RWKV_API void rwkv_set_print_errors(struct rwkv_context * ctx, const bool print_errors) {
+    if (ctx) ctx->print_errors = print_errors; else g_print_errors = print_errors;
+}
+
+RWKV_API bool rwkv_get_print_errors(const struct rwkv_context * ctx) { return ctx ? ctx->print_errors : g_print_errors; }
+
+RWKV_API enum rwkv_error_flags rwkv_get_last_error(struct rwkv_context * ctx) {
+    int * p = ctx ? &ctx->last_error : &g_last_error;
+    const int v = *p;
+    *p = RWKV_ERROR_NONE;
+    return (enum rwkv_error_flags) v;
+}
+
+RWKV_API const char * rwkv_get_system_info_string(void) {
+    static std::string s;
+    if (s.empty()) {
+        // Same key order as the reference (rwkv.cpp:239-258); the host SIMD flags are informational only here.
+#define RW_HAS(F) std::to_string((int) (__builtin_cpu_supports(F) != 0))
+        s += "AVX=" + RW_HAS("avx") + " ";
+        s += "AVX2=" + RW_HAS("avx2") + " ";
+        s += "AVX512=" + RW_HAS("avx512f") + " ";
+        s += "FMA=" + RW_HAS("fma") + " ";
+        s += "NEON=0 ARM_FMA=0 ";
+        s += "F16C=" + RW_HAS("f16c") + " ";
+        s += "FP16_VA=0 WASM_SIMD=0 ";
+        s += "SSE3=" + RW_HAS("sse3") + " ";
+        s += "VSX=0";
+#undef RW_HAS
+        int n = 0;
+        if (hipGetDeviceCount(&n) == hipSuccess && n > 0) {
+            hipDeviceProp_t p;
+            int dev = 0;
+            (void) hipGetDevice(&dev);
+            if (hipGetDeviceProperties(&p, dev) == hipSuccess) {
+                s += " | HIP=1 DEVICES=" + std::to_string(n) + " ARCH=" + std::string(p.gcnArchName) + " CU=" + std::to_string(p.multiProcessorCount);
+            }
+        } else {
+            s += " | HIP=0";
+        }
+    }
+    return s.c_str();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rwkv_mi_* extensions (include/rwkv_mi355x.h)
+// ---------------------------------------------------------------------------------------------------------------
+
+RWKV_API bool rwkv_mi_state_load(struct rwkv_context * ctx, const float * state_in) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    if (!state_from_host(ctx, state_in)) return false;
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return true;
+}
+
+RWKV_API bool rwkv_mi_state_store(struct rwkv_context * ctx, float * state_out) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, state_out != nullptr, "state_out is NULL");
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    return fetch_outputs(ctx, state_out, nullptr);
+}
+
+RWKV_API bool rwkv_mi_eval_resident(struct rwkv_context * ctx, const uint32_t * tokens, size_t n_tokens, float * logits_out) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, tokens != nullptr && n_tokens > 0, "tokens is NULL or empty");
+    const size_t n_vocab = (size_t) ctx->model->n_vocab();
+    for (size_t i = 0; i < n_tokens; i++) RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, tokens[i] < n_vocab, "Token at index %zu is out of range", i);
+    if (!run_tokens(ctx, tokens, n_tokens, logits_out != nullptr)) return false;
+    return fetch_outputs(ctx, nullptr, logits_out);
+}
+
+RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, uint32_t * tokens_out, float * elapsed_ms) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    const size_t n_vocab = (size_t) ctx->model->n_vocab();
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, first_token < n_vocab, "Token is out of range");
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, n_tokens > 0, "n_tokens is 0");
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    if (!upload_tokens(ctx, &first_token, 1)) return false;
+    uint32_t * d_hist = nullptr;
+    HIP_CTX_OK(ctx, hipMalloc((void **) &d_hist, n_tokens * sizeof(uint32_t)));
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_CTX_OK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    bool ok = true;
+    for (size_t i = 0; i < n_tokens && ok; i++) {
+        ok = forward_decode(ctx, true);
+        if (!ok) break;
+        // next token = argmax(logits), written where the embedding kernel reads it; no host round trip
+        launch_argmax(ctx->d_logits, (int64_t) n_vocab, ctx->d_tokens, ctx->stream);
+        if (hipMemcpyAsync(d_hist + i, ctx->d_tokens, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) ok = false;
+    }
+    if (ok) {
+        ok = hipEventRecord(ctx->ev1, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (ok && elapsed_ms) ok = hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1) == hipSuccess;
+        if (ok && tokens_out) ok = hipMemcpy(tokens_out, d_hist, n_tokens * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void) hipFree(d_hist);
+    RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, ok, "greedy decode failed: %s", hipGetErrorString(hipGetLastError()));
+    return true;
+}
+
+RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx) { return ctx->model->bytes_per_token; }
+RWKV_API uint64_t rwkv_mi_weight_bytes(const struct rwkv_context * ctx) { return ctx->model->weight_bytes; }
+
+RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major, uint32_t * minor, uint32_t * head_count, uint32_t * head_size) {
+    if (major) *major = (uint32_t) ctx->model->arch_major;
+    if (minor) *minor = (uint32_t) ctx->model->arch_minor;
+    if (head_count) *head_count = (uint32_t) ctx->model->head_count;
+    if (head_size) *head_size = (uint32_t) ctx->model->head_size;
+}
+
+RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled) { ctx->use_graph = enabled; }
+
+// Test hook: y[T][N] = W[N][K] . x[T][K] through the production projection kernels (load-time re-pack, activation
+// quantiser, single-token or token-tiled kernel) on standalone buffers. W is in the FILE layout of `type`.
+RWKV_API bool rwkv_mi_test_mul_mat(int type, const void * w, int64_t K, int64_t N, const float * x, int64_t T, float * y) {
+    g_last_error = RWKV_ERROR_NONE;
+    RW_CHECK(RWKV_ERROR_ARGS, false, dtype_supported(type) && w && x && y && K > 0 && N > 0 && T > 0, "bad arguments");
+    RW_CHECK(RWKV_ERROR_ARGS, false, K % (dtype_quantized(type) ? 32 : 8) == 0, "K must be a multiple of 32 (quantised) or 8");
+    const uint64_t wbytes = tensor_nbytes(type, K, N, 1);
+    const int64_t nblk = K * N / 32;
+    void *d_raw = nullptr, *d_x = nullptr, *d_y = nullptr, *d_q = nullptr, *d_planes = nullptr;
+    bool ok = true;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess) { global_fail(RWKV_ERROR_GRAPH, __FILE__, __LINE__, "hip call", "HIP error: %s", hipGetErrorString(e)); ok = false; } return ok; };
+    DevTensor W;
+    W.type = type; W.ndim = 2; W.ne[0] = K; W.ne[1] = N; W.nbytes = wbytes;
+    QAct qa;
+    const size_t nbk = (size_t) T * (size_t)(K / 32);
+    if (chk(hipMalloc(&d_raw, wbytes)) && chk(hipMalloc(&d_x, (size_t) T * K * 4)) && chk(hipMalloc(&d_y, (size_t) T * N * 4)) &&
+        chk(hipMalloc(&d_q, (size_t) T * K + 3 * nbk * 4 + 1024)) && chk(hipMalloc(&d_planes, (size_t) nblk * 40 + 1024)) &&
+        chk(hipMemcpy(d_raw, w, wbytes, hipMemcpyHostToDevice)) && chk(hipMemcpy(d_x, x, (size_t) T * K * 4, hipMemcpyHostToDevice))) {
+        hipStream_t st = nullptr;
+        if (dtype_quantized(type)) {
+            W.qs = (uint8_t *) d_planes;
+            W.qh = (uint32_t *) ((uint8_t *) d_planes + (size_t) nblk * 32);
+            W.sc = (uint8_t *) d_planes + (size_t) nblk * 36;
+            launch_repack(type, (const uint8_t *) d_raw, nblk, W.qs, W.qh, W.sc, st);
+            qa.q = (int8_t *) d_q;
+            qa.d = (float *) ((uint8_t *) d_q + (((size_t) T * K + 255) / 256) * 256);
+            qa.s = qa.d + nbk;
+            qa.isum = (int *) (qa.s + nbk);
+            launch_quantize_act((const float *) d_x, T, K, qa, st);
+            launch_matvec_q(W, qa, T, (float *) d_y, N, Epi(), st);
+        } else {
+            W.data = d_raw;
+            launch_matvec_f(W, (const float *) d_x, K, T, (float *) d_y, N, Epi(), st);
+        }
+        chk(hipDeviceSynchronize());
+        chk(hipGetLastError());
+        if (ok) chk(hipMemcpy(y, d_y, (size_t) T * N * 4, hipMemcpyDeviceToHost));
+    }
+    for (void * p : {d_raw, d_x, d_y, d_q, d_planes}) if (p) (void) hipFree(p);
+    return ok;
+}
+
+}  // extern "C"

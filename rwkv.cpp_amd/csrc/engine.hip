@@ -1,0 +1,320 @@
+// engine.hip -- the hand-scheduled per-layer pipeline that replaces the reference's ggml graphs
+// (rwkv_build_serial_graph / rwkv_build_sequential_graph, rwkv_graph.inc:611-866). One code path serves T = 1 (decode)
+// and T > 1 (sequence mode); state and weights never leave HBM between calls.
+#include "model.h"
+
+#include <cstdarg>
+#include <cstring>
+
+namespace rwkvmi {
+
+#define HIP_CTX_OK(CTX, CALL) \
+    do { hipError_t e_ = (CALL); RW_CTX_CHECK((CTX), RWKV_ERROR_GRAPH, false, e_ == hipSuccess, "HIP error: %s", hipGetErrorString(e_)); } while (0)
+
+void ctx_fail(struct ::rwkv_context * ctx, int flags, const char * file, int line, const char * expr, const char * fmt, ...) {
+    ctx->last_error |= flags;
+    if (!ctx->print_errors) return;
+    if (fmt && fmt[0]) {
+        va_list ap;
+        va_start(ap, fmt);
+        vfprintf(stderr, fmt, ap);
+        va_end(ap);
+    }
+    fprintf(stderr, "\n%s:%d: %s\n", file, line, expr);
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+rwkv_context * create_context(Model * m, uint32_t n_threads) {
+    std::unique_ptr<rwkv_context> ctx(new (std::nothrow) rwkv_context());
+    RW_CHECK(RWKV_ERROR_CTX | RWKV_ERROR_ALLOC, nullptr, ctx != nullptr, "Failed to allocate rwkv_context");
+    ctx->model = m;
+    ctx->n_threads = n_threads;
+    m->refcount++;
+    auto fail = [&](hipError_t e) {
+        global_fail(RWKV_ERROR_CTX | RWKV_ERROR_ALLOC, __FILE__, __LINE__, "hip allocation", "HIP error: %s", hipGetErrorString(e));
+        destroy_context(ctx.release());
+        return (rwkv_context *) nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(m->device)) != hipSuccess) return fail(e);
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+    const size_t sbytes = (size_t) m->state_len() * sizeof(float);
+    for (int i = 0; i < 2; i++) if ((e = hipMalloc((void **) &ctx->state[i], sbytes)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **) &ctx->d_logits, (size_t) m->n_vocab() * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **) &ctx->d_next_token, 64)) != hipSuccess) return fail(e);
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return fail(e);
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail(e);
+    const char * g = getenv("RWKV_MI_NO_GRAPH");
+    ctx->use_graph = !(g && g[0] == '1');
+    return ctx.release();
+}
+
+static void drop_graphs(rwkv_context * ctx) {
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (ctx->graph_exec[a][b]) { (void) hipGraphExecDestroy(ctx->graph_exec[a][b]); ctx->graph_exec[a][b] = nullptr; }
+}
+
+void destroy_context(rwkv_context * ctx) {
+    if (!ctx) return;
+    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    drop_graphs(ctx);
+    for (int i = 0; i < 2; i++) if (ctx->state[i]) (void) hipFree(ctx->state[i]);
+    if (ctx->scratch) (void) hipFree(ctx->scratch);
+    if (ctx->d_tokens) (void) hipFree(ctx->d_tokens);
+    if (ctx->d_logits) (void) hipFree(ctx->d_logits);
+    if (ctx->d_next_token) (void) hipFree(ctx->d_next_token);
+    if (ctx->h_tokens) (void) hipHostFree(ctx->h_tokens);
+    if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    release_model(ctx->model);
+    delete ctx;
+}
+
+// Scratch for T tokens: one allocation carved into named activations.
+static bool ensure_scratch(rwkv_context * ctx, int64_t T) {
+    if (T <= ctx->scratch_T) return true;
+    Model & m = *ctx->model;
+    const size_t D = (size_t) m.n_embed(), F = (size_t) m.ffn_size;
+    const size_t LR = (size_t)(m.max_lowrank > 0 ? m.max_lowrank : 32);
+    const size_t KQ = D > F ? D : F;  // widest quantised activation row
+    auto fsz = [&](size_t n) { return align_up((size_t) T * n * sizeof(float), 256); };
+    const size_t n_D = 3 + 6 + 6 + 3 + 1 + 1;  // x xn sx | m[6] | r k v g w a | t0 t1 t2 | out | v_first
+    size_t total = n_D * fsz(D) + fsz(F) + 2 * fsz(LR) + align_up(D * sizeof(float), 256);
+    total += align_up((size_t) T * KQ, 256) + 3 * align_up((size_t) T * (KQ / 32) * 4, 256);
+    if (ctx->scratch) { HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream)); (void) hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_T = 0; }
+    drop_graphs(ctx);
+    HIP_CTX_OK(ctx, hipMalloc(&ctx->scratch, total));
+    ctx->scratch_bytes = total;
+    uint8_t * p = (uint8_t *) ctx->scratch;
+    auto takef = [&](size_t n) { float * r = (float *) p; p += fsz(n); return r; };
+    auto & b = ctx->b;
+    b.x = takef(D); b.xn = takef(D); b.sx = takef(D);
+    for (int i = 0; i < 6; i++) b.m[i] = takef(D);
+    b.r = takef(D); b.k = takef(D); b.v = takef(D); b.g = takef(D); b.w = takef(D); b.a = takef(D);
+    b.t0 = takef(D); b.t1 = takef(D); b.t2 = takef(D); b.out = takef(D); b.v_first = takef(D);
+    b.ffk = takef(F); b.lr1 = takef(LR); b.lr2 = takef(LR);
+    b.xlast = (float *) p; p += align_up(D * sizeof(float), 256);
+    b.qa.q = (int8_t *) p; p += align_up((size_t) T * KQ, 256);
+    b.qa.d = (float *) p; p += align_up((size_t) T * (KQ / 32) * 4, 256);
+    b.qa.s = (float *) p; p += align_up((size_t) T * (KQ / 32) * 4, 256);
+    b.qa.isum = (int *) p; p += align_up((size_t) T * (KQ / 32) * 4, 256);
+    ctx->scratch_T = T;
+    return true;
+}
+
+bool state_from_host(rwkv_context * ctx, const float * state_in) {
+    Model & m = *ctx->model;
+    float * dst = ctx->state[ctx->cur];
+    if (state_in) {
+        HIP_CTX_OK(ctx, hipMemcpyAsync(dst, state_in, (size_t) m.state_len() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    } else if (m.arch_major >= 5) {
+        HIP_CTX_OK(ctx, hipMemsetAsync(dst, 0, (size_t) m.state_len() * sizeof(float), ctx->stream));
+    } else {
+        launch_fill_state_v4(dst, m.n_layer(), m.n_embed(), ctx->stream);
+    }
+    return true;
+}
+
+bool state_to_host(rwkv_context * ctx, float * state_out) {
+    Model & m = *ctx->model;
+    HIP_CTX_OK(ctx, hipMemcpyAsync(state_out, ctx->state[ctx->cur], (size_t) m.state_len() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layer pipeline
+// ---------------------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct Runner {
+    rwkv_context * ctx;
+    Model & m;
+    hipStream_t st;
+    int64_t T, D, H, S;
+    rwkv_context::Buf & b;
+
+    // y[T][N] = epi(W . x[T][K])    (ggml_mul_mat)
+    void mm(const DevTensor * W, const float * x, float * y, const Epi & epi = Epi()) {
+        const int64_t N = W->rows(), K = W->cols();
+        if (dtype_quantized(W->type)) {
+            launch_quantize_act(x, T, K, b.qa, st);
+            launch_matvec_q(*W, b.qa, T, y, N, epi, st);
+        } else {
+            launch_matvec_f(*W, x, K, T, y, N, epi, st);
+        }
+    }
+    static const float * f(const DevTensor * t) { return (const float *) t->data; }
+    static Epi epi(int op, const float * bias = nullptr, const float * res = nullptr, const float * aux = nullptr) {
+        Epi e; e.op = op; e.bias = bias; e.res = res; e.aux = aux; return e;
+    }
+
+    // channel mixing (rwkv_ffn_v4_v5 :484-511, rwkv_ffn_v6 :513-531, rwkv_ffn_v7 :533-543)
+    void ffn(const LayerW & L, const float * sin, float * sout) {
+        launch_layernorm(b.x, T, D, f(L.ln2_w), f(L.ln2_b), b.xn, st);
+        MixArgs a; a.xn = b.xn; a.carry_in = sin; a.carry_out = sout;
+        if (m.arch_major <= 5) { a.mode = 0; a.n_out = 2; a.coef[0] = f(L.ffn_time_mix_k); a.coef[1] = f(L.ffn_time_mix_r); }
+        else if (m.arch_major == 6) { a.mode = 1; a.n_out = 2; a.coef[0] = f(L.ffn_time_maa_k); a.coef[1] = f(L.ffn_time_maa_r); }
+        else { a.mode = 1; a.n_out = 1; a.coef[0] = f(L.ffn_x_k); }
+        a.out[0] = b.m[0]; a.out[1] = b.m[1];
+        launch_mix(a, T, D, st);
+        mm(L.ffn_key, b.m[0], b.ffk, epi(EPI_RELU_SQ));
+        if (m.arch_major == 7) {
+            mm(L.ffn_value, b.ffk, b.x, epi(EPI_ADD_RES, nullptr, b.x));
+        } else {
+            mm(L.ffn_receptance, b.m[1], b.r);
+            mm(L.ffn_value, b.ffk, b.x, epi(EPI_SIGMUL_ADD_RES, nullptr, b.x, b.r));
+        }
+    }
+
+    // rwkv_att_v4 (:163-197)
+    void att_v4(const LayerW & L, const float * sin, float * sout) {
+        launch_layernorm(b.x, T, D, f(L.ln1_w), f(L.ln1_b), b.xn, st);
+        MixArgs a; a.xn = b.xn; a.carry_in = sin + D; a.carry_out = sout + D; a.mode = 0; a.n_out = 3;
+        a.coef[0] = f(L.att_time_mix_k); a.coef[1] = f(L.att_time_mix_v); a.coef[2] = f(L.att_time_mix_r);
+        a.out[0] = b.m[0]; a.out[1] = b.m[1]; a.out[2] = b.m[2];
+        launch_mix(a, T, D, st);
+        mm(L.att_receptance, b.m[2], b.r, epi(EPI_SIGMOID));
+        mm(L.att_key, b.m[0], b.k);
+        mm(L.att_value, b.m[1], b.v);
+        launch_wkv4(b.k, b.v, b.r, f(L.att_time_first), f(L.att_time_decay), sin + 2 * D, sin + 3 * D, sin + 4 * D,
+                    sout + 2 * D, sout + 3 * D, sout + 4 * D, b.out, T, D, st);
+        mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
+    }
+
+    // rwkv_att_v5 (:199-292)
+    void att_v5(const LayerW & L, const float * sin, float * sout) {
+        const bool v52 = m.arch_minor >= 2;
+        launch_layernorm(b.x, T, D, f(L.ln1_w), f(L.ln1_b), b.xn, st);
+        MixArgs a; a.xn = b.xn; a.carry_in = sin + D; a.carry_out = sout + D; a.mode = 0; a.n_out = v52 ? 4 : 3;
+        a.coef[0] = f(L.att_time_mix_k); a.coef[1] = f(L.att_time_mix_v); a.coef[2] = f(L.att_time_mix_r);
+        if (v52) a.coef[3] = f(L.att_time_mix_g);
+        for (int i = 0; i < 4; i++) a.out[i] = b.m[i];
+        launch_mix(a, T, D, st);
+        mm(L.att_receptance, b.m[2], b.r);
+        mm(L.att_key, b.m[0], b.k);
+        mm(L.att_value, b.m[1], b.v);
+        if (v52) mm(L.att_gate, b.m[3], b.g, epi(EPI_SILU));
+        launch_wkv6(b.r, b.k, b.v, v52 ? f(L.att_time_faaaa) : f(L.att_time_first), v52 ? 1 : 0, f(L.att_time_decay), v52 ? 1 : 0,
+                    sin + 2 * D, sout + 2 * D, b.out, T, H, S, st);
+        launch_groupnorm(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), 1e-5f, v52 ? b.g : nullptr, nullptr, nullptr, nullptr, nullptr, T, H, S, st);
+        mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
+    }
+
+    // rwkv_att_v6 (:294-385)
+    void att_v6(const LayerW & L, const float * sin, float * sout) {
+        launch_layernorm(b.x, T, D, f(L.ln1_w), f(L.ln1_b), b.xn, st);
+        MixArgs a; a.xn = b.xn; a.carry_in = sin + D; a.carry_out = sout + D; a.mode = 1; a.n_out = 1;
+        a.coef[0] = f(L.att_time_maa_x); a.out[0] = b.m[5]; a.sx = b.sx;
+        launch_mix(a, T, D, st);
+        const int64_t R5 = L.att_time_maa_w1->ne[1], R = R5 / 5;
+        mm(L.att_time_maa_w1, b.m[5], b.lr1, epi(EPI_TANH));
+        V6Mix2Args v; v.w2 = f(L.att_time_maa_w2); v.tl = b.lr1; v.sx = b.sx; v.xn = b.xn;
+        v.maa[0] = f(L.att_time_maa_w); v.maa[1] = f(L.att_time_maa_k); v.maa[2] = f(L.att_time_maa_v);
+        v.maa[3] = f(L.att_time_maa_r); v.maa[4] = f(L.att_time_maa_g);
+        for (int i = 0; i < 5; i++) v.out[i] = b.m[i];  // xw, xk, xv, xr, xg
+        launch_v6_mix2(v, T, D, R, st);
+        mm(L.att_receptance, b.m[3], b.r);
+        mm(L.att_key, b.m[1], b.k);
+        mm(L.att_value, b.m[2], b.v);
+        mm(L.att_gate, b.m[4], b.g, epi(EPI_SILU));
+        mm(L.att_time_decay_w1, b.m[0], b.lr2, epi(EPI_TANH));
+        // decay_w2 consumes [T][DR] rows of lr2
+        mm(L.att_time_decay_w2, b.lr2, b.w, epi(EPI_V6_DECAY, f(L.att_time_decay)));
+        launch_wkv6(b.r, b.k, b.v, f(L.att_time_faaaa), 1, b.w, 2, sin + 2 * D, sout + 2 * D, b.out, T, H, S, st);
+        launch_groupnorm(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), 64e-5f, b.g, nullptr, nullptr, nullptr, nullptr, T, H, S, st);
+        mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
+    }
+
+    // rwkv_att_v7 (:387-482)
+    void att_v7(const LayerW & L, int layer, const float * sin, float * sout) {
+        launch_layernorm(b.x, T, D, f(L.ln1_w), f(L.ln1_b), b.xn, st);
+        MixArgs a; a.xn = b.xn; a.carry_in = sin + D; a.carry_out = sout + D; a.mode = 1; a.n_out = 6;
+        for (int i = 0; i < 6; i++) { a.coef[i] = f(L.att_x_rwkvag) + (int64_t) i * D; a.out[i] = b.m[i]; }  // r, w, k, v, a, g
+        launch_mix(a, T, D, st);
+        mm(L.att_receptance, b.m[0], b.r);
+        mm(L.att_g1, b.m[5], b.lr1, epi(EPI_SIGMOID));
+        mm(L.att_g2, b.lr1, b.g);
+        mm(L.att_a1, b.m[4], b.lr1);
+        mm(L.att_a2, b.lr1, b.a, epi(EPI_BIAS_SIGMOID, f(L.att_a0)));
+        mm(L.att_w1, b.m[1], b.lr1, epi(EPI_TANH));
+        mm(L.att_w2, b.lr1, b.w, epi(EPI_V7_DECAY, f(L.att_w0)));
+        mm(L.att_key, b.m[2], b.k);
+        launch_v7_kprep(b.k, b.a, f(L.att_k_k), f(L.att_k_a), b.t0 /* k' */, b.t1 /* -kk */, b.t2 /* kk*a */, T, H, S, st);
+        mm(L.att_value, b.m[3], b.v);
+        if (layer == 0) {
+            launch_copy_f32(b.v_first, b.v, T * D, st);
+        } else {
+            mm(L.att_v1, b.m[3], b.lr1);
+            mm(L.att_v2, b.lr1, b.sx, epi(EPI_BIAS_SIGMOID, f(L.att_v0)));
+            launch_v7_vmix(b.v, b.v_first, b.sx, T * D, st);
+        }
+        launch_wkv7(b.r, b.w, b.t0, b.v, b.t1, b.t2, sin + 2 * D, sout + 2 * D, b.out, T, H, S, st);
+        launch_groupnorm(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), 64e-5f, b.g, b.t0, b.r, b.v, f(L.att_r_k), T, H, S, st);
+        mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
+    }
+
+    void run(bool want_logits) {
+        const float * sin = ctx->state[ctx->cur];
+        float * sout = ctx->state[ctx->cur ^ 1];
+        const int64_t per_layer = m.state_per_layer();
+        if (m.has_embed) launch_embed_ln0(*m.emb, ctx->d_tokens, T, D, f(m.ln0_w), f(m.ln0_b), b.x, st);
+        for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
+            const LayerW & L = m.layers[i];
+            const float * li = sin + (int64_t) i * per_layer;
+            float * lo = sout + (int64_t) i * per_layer;
+            switch (m.arch_major) {
+                case 4: att_v4(L, li, lo); break;
+                case 5: att_v5(L, li, lo); break;
+                case 6: att_v6(L, li, lo); break;
+                case 7: att_v7(L, (int) i, li, lo); break;
+                default: break;
+            }
+            ffn(L, li, lo);
+        }
+        if (want_logits && m.has_head) {
+            // ln_out on the last token only, then the head projection (rwkv_graph.inc:704-708, 851-854)
+            launch_layernorm(b.x + (T - 1) * D, 1, D, f(m.ln_out_w), f(m.ln_out_b), b.xlast, st);
+            const int64_t Tsave = T; T = 1;
+            mm(m.head, b.xlast, ctx->d_logits);
+            T = Tsave;
+        }
+    }
+};
+
+}  // namespace
+
+bool forward(rwkv_context * ctx, int64_t T, bool want_logits) {
+    if (!ensure_scratch(ctx, T)) return false;
+    Model & m = *ctx->model;
+    Runner r{ctx, m, ctx->stream, T, m.n_embed(), m.head_count, m.head_size, ctx->b};
+    r.run(want_logits);
+    ctx->cur ^= 1;
+    HIP_CTX_OK(ctx, hipGetLastError());
+    return true;
+}
+
+// Single-token step through a captured hipGraph: one graph per (state parity, logits on/off), replayed per token so
+// that the ~100 short launches of a decode step cost one graph launch on the host.
+bool forward_decode(rwkv_context * ctx, bool want_logits) {
+    if (!ctx->use_graph) return forward(ctx, 1, want_logits);
+    if (!ensure_scratch(ctx, 1)) return false;
+    hipGraphExec_t & ge = ctx->graph_exec[ctx->cur][want_logits ? 1 : 0];
+    if (!ge) {
+        Model & m = *ctx->model;
+        hipGraph_t graph = nullptr;
+        HIP_CTX_OK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        Runner r{ctx, m, ctx->stream, 1, m.n_embed(), m.head_count, m.head_size, ctx->b};
+        r.run(want_logits);
+        HIP_CTX_OK(ctx, hipStreamEndCapture(ctx->stream, &graph));
+        hipError_t e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+        (void) hipGraphDestroy(graph);
+        RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, e == hipSuccess, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    HIP_CTX_OK(ctx, hipGraphLaunch(ge, ctx->stream));
+    ctx->cur ^= 1;
+    return true;
+}
+
+}  // namespace rwkvmi

@@ -1,0 +1,951 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the RWKV hot path.
+//
+// Numerics contract (DESIGN.md "Numerics"):
+//  * Projections with quantised weights follow ggml's CPU mul_mat: activations are quantised per
+//    32-element block to int8 (d = amax/127 stored fp16-rounded), the dot is an exact integer dot (v_dot4_i32_i8),
+//    and blocks are accumulated in f32:  acc = fma(d_w*d_x, isum, acc) [+ fma(m_w, s_x, acc)].
+//  * Lane l of the wave that owns an output row accumulates blocks l, l+64, l+128, ... in that order; the 64 partials
+//    are folded by an xor-butterfly (32,16,8,4,2,1). The single-token kernel and the token-tiled (sequence) kernel use
+//    the SAME order, so rwkv_eval_sequence is bit-identical to repeated rwkv_eval (reference test
+//    tests/test_eval_sequence_in_chunks.c:54 checks this with memcmp).
+//  * F16 weights: activations are rounded to fp16 first (what ggml does), products/accumulation in f32.
+//  * Norm statistics are accumulated in double (ggml_norm).
+#include "kernels.h"
+
+#include <hip/hip_fp16.h>
+
+namespace rwkvmi {
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float h2f_bits(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+
+// block-wide sum of doubles for blocks of up to 1024 threads (multiple of 64); result broadcast to all threads
+__device__ __forceinline__ double block_sum_d(double v, double * red /* [17] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum_d(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nw; i++) s += red[i];
+        red[16] = s;
+    }
+    __syncthreads();
+    return red[16];
+}
+
+__device__ __forceinline__ float apply_epi(const Epi & e, float acc, int64_t t, int64_t n, int64_t ldy) {
+    switch (e.op) {
+        case EPI_NONE: return acc;
+        case EPI_SIGMOID: return sigmoid_f(acc);
+        case EPI_RELU_SQ: { const float r = acc > 0.0f ? acc : 0.0f; return r * r; }
+        case EPI_SILU: return acc / (1.0f + expf(-acc));
+        case EPI_TANH: return tanhf(acc);
+        case EPI_ADD_RES: return e.res[t * ldy + n] + acc;
+        case EPI_SIGMUL_ADD_RES: return e.res[t * ldy + n] + sigmoid_f(e.aux[t * ldy + n]) * acc;
+        case EPI_BIAS_SIGMOID: return sigmoid_f(acc + e.bias[n]);
+        case EPI_V6_DECAY: return expf(-expf(acc + e.bias[n]));
+        case EPI_V7_DECAY: return expf(sigmoid_f(acc + e.bias[n]) * -0.606531f);
+        default: return acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Quantised weight blocks (planes, see DevTensor). One block = 32 weights.
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int FMT> struct QF;
+template <> struct QF<T_Q4_0> { static constexpr int QS = 16; static constexpr bool QH = false, HM = false; static constexpr int OFF = 8; };
+template <> struct QF<T_Q4_1> { static constexpr int QS = 16; static constexpr bool QH = false, HM = true;  static constexpr int OFF = 0; };
+template <> struct QF<T_Q5_0> { static constexpr int QS = 16; static constexpr bool QH = true,  HM = false; static constexpr int OFF = 16; };
+template <> struct QF<T_Q5_1> { static constexpr int QS = 16; static constexpr bool QH = true,  HM = true;  static constexpr int OFF = 0; };
+template <> struct QF<T_Q8_0> { static constexpr int QS = 32; static constexpr bool QH = false, HM = false; static constexpr int OFF = 0; };
+
+// Codes of one block as 8 dwords of 4 x int8: c[0..3] = elements 0..15, c[4..7] = elements 16..31.
+// 4/5-bit codes are left unsigned (0..15 / 0..31); the -8 / -16 offset is applied through the activation sum.
+template <int FMT>
+struct WBlk {
+    int c[8];
+    float d, m;
+};
+
+template <int FMT>
+__device__ __forceinline__ void load_wblk(WBlk<FMT> & w, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
+                                          const void * __restrict__ sc, int64_t blk) {
+    if constexpr (QF<FMT>::QS == 32) {
+        const int4 a = *reinterpret_cast<const int4 *>(qs + blk * 32);
+        const int4 b = *reinterpret_cast<const int4 *>(qs + blk * 32 + 16);
+        w.c[0] = a.x; w.c[1] = a.y; w.c[2] = a.z; w.c[3] = a.w;
+        w.c[4] = b.x; w.c[5] = b.y; w.c[6] = b.z; w.c[7] = b.w;
+    } else {
+        const int4 a = *reinterpret_cast<const int4 *>(qs + blk * 16);
+        const int raw[4] = {a.x, a.y, a.z, a.w};
+        unsigned hbits = 0;
+        if constexpr (QF<FMT>::QH) hbits = qh[blk];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int lo = raw[i] & 0x0F0F0F0F;
+            int hi = (raw[i] >> 4) & 0x0F0F0F0F;
+            if constexpr (QF<FMT>::QH) {
+                // bit j of qh -> bit 4 of byte j (elements 0..15), bit 16+j -> elements 16..31.
+                const unsigned nl = (hbits >> (4 * i)) & 0xFu, nh = (hbits >> (16 + 4 * i)) & 0xFu;
+                lo |= (int)(((nl * 0x00204081u) & 0x01010101u) << 4);
+                hi |= (int)(((nh * 0x00204081u) & 0x01010101u) << 4);
+            }
+            w.c[i] = lo;
+            w.c[4 + i] = hi;
+        }
+    }
+    if constexpr (QF<FMT>::HM) {
+        const uint32_t dm = reinterpret_cast<const uint32_t *>(sc)[blk];
+        w.d = h2f_bits((uint16_t)(dm & 0xFFFFu));
+        w.m = h2f_bits((uint16_t)(dm >> 16));
+    } else {
+        w.d = h2f_bits(reinterpret_cast<const uint16_t *>(sc)[blk]);
+        w.m = 0.0f;
+    }
+}
+
+// acc <- acc + contribution of one weight block against one activation block.
+template <int FMT>
+__device__ __forceinline__ float blk_fma(const WBlk<FMT> & w, const int4 alo, const int4 ahi, float dx, float sx, int asum, float acc) {
+    int s = 0;
+    s = __builtin_amdgcn_sdot4(w.c[0], alo.x, s, false);
+    s = __builtin_amdgcn_sdot4(w.c[1], alo.y, s, false);
+    s = __builtin_amdgcn_sdot4(w.c[2], alo.z, s, false);
+    s = __builtin_amdgcn_sdot4(w.c[3], alo.w, s, false);
+    s = __builtin_amdgcn_sdot4(w.c[4], ahi.x, s, false);
+    s = __builtin_amdgcn_sdot4(w.c[5], ahi.y, s, false);
+    s = __builtin_amdgcn_sdot4(w.c[6], ahi.z, s, false);
+    s = __builtin_amdgcn_sdot4(w.c[7], ahi.w, s, false);
+    if constexpr (QF<FMT>::OFF != 0) s -= QF<FMT>::OFF * asum;
+    const float dd = w.d * dx;
+    acc = fmaf(dd, (float) s, acc);
+    if constexpr (QF<FMT>::HM) acc = fmaf(w.m, sx, acc);
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Projection, quantised weights, single token (decode): the HBM-roofline kernel.
+// One wave owns R consecutive rows; lane l streams blocks l, l+64, ... of each row straight into VGPRs (16 B/lane,
+// 1 KiB per wave-instruction, no LDS round trip -- every weight byte is used exactly once).
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int FMT, int R>
+__global__ __launch_bounds__(256) void k_mvq_t1(const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh, const void * __restrict__ sc,
+                                                int64_t N, int nb, const int8_t * __restrict__ xq, const float * __restrict__ xd,
+                                                const float * __restrict__ xs, const int * __restrict__ xi, float * __restrict__ y, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t) blockIdx.x * 4 + wave) * R;
+    if (row0 >= N) return;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0f;
+    for (int b = lane; b < nb; b += WAVE) {
+        const int4 alo = reinterpret_cast<const int4 *>(xq)[2 * b];
+        const int4 ahi = reinterpret_cast<const int4 *>(xq)[2 * b + 1];
+        const float dx = xd[b], sx = xs[b];
+        const int asum = xi[b];
+        WBlk<FMT> w[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
+            load_wblk<FMT>(w[r], qs, qh, sc, row * nb + b);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = blk_fma<FMT>(w[r], alo, ahi, dx, sx, asum, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const float v = wave_sum_f(acc[r]);
+        if (lane == 0 && row0 + r < N) y[row0 + r] = apply_epi(epi, v, 0, row0 + r, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Projection, quantised weights, token tile (sequence mode). Each weight block is unpacked once and used for TT tokens;
+// the activation tile of the current K-step (64 blocks x TT tokens) is staged in LDS in a lane-linear, conflict-free
+// image [tt][half][lane][16 B]. Per (row, token) the accumulation order equals k_mvq_t1's.
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int FMT, int R, int TT>
+__global__ __launch_bounds__(256) void k_mvq_tn(const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh, const void * __restrict__ sc,
+                                                int64_t N, int nb, const int8_t * __restrict__ xq, const float * __restrict__ xd,
+                                                const float * __restrict__ xs, const int * __restrict__ xi, int64_t T,
+                                                float * __restrict__ y, int64_t ldy, Epi epi) {
+    __shared__ __attribute__((aligned(16))) int8_t l_q[TT * 2048];
+    __shared__ float l_d[TT * 64];
+    __shared__ float l_s[TT * 64];
+    __shared__ int l_i[TT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t) blockIdx.x * 4 + wave) * R;
+    const int64_t t0 = (int64_t) blockIdx.y * TT;
+    const int64_t K = (int64_t) nb * 32;
+    float acc[R][TT];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) acc[r][tt] = 0.0f;
+
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+        __syncthreads();
+        // stage q: TT * 128 chunks of 16 B
+        for (int c = threadIdx.x; c < TT * 128; c += 256) {
+            const int tt = c >> 7, cc = c & 127, blk = cc >> 1, half = cc & 1;
+            int4 v = make_int4(0, 0, 0, 0);
+            if (t0 + tt < T && b0 + blk < nb) v = *reinterpret_cast<const int4 *>(xq + (t0 + tt) * K + (int64_t)(b0 + blk) * 32 + half * 16);
+            *reinterpret_cast<int4 *>(l_q + tt * 2048 + half * 1024 + blk * 16) = v;
+        }
+        for (int c = threadIdx.x; c < TT * 64; c += 256) {
+            const int tt = c >> 6, blk = c & 63;
+            const bool ok = (t0 + tt < T) && (b0 + blk < nb);
+            const int64_t idx = (t0 + tt) * nb + b0 + blk;
+            l_d[c] = ok ? xd[idx] : 0.0f;
+            l_s[c] = ok ? xs[idx] : 0.0f;
+            l_i[c] = ok ? xi[idx] : 0;
+        }
+        __syncthreads();
+        const int b = b0 + lane;
+        if (b < nb && row0 < N) {
+            WBlk<FMT> w[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
+                load_wblk<FMT>(w[r], qs, qh, sc, row * nb + b);
+            }
+#pragma unroll
+            for (int tt = 0; tt < TT; tt++) {
+                const int4 alo = *reinterpret_cast<const int4 *>(l_q + tt * 2048 + lane * 16);
+                const int4 ahi = *reinterpret_cast<const int4 *>(l_q + tt * 2048 + 1024 + lane * 16);
+                const float dx = l_d[tt * 64 + lane], sx = l_s[tt * 64 + lane];
+                const int asum = l_i[tt * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r][tt] = blk_fma<FMT>(w[r], alo, ahi, dx, sx, asum, acc[r][tt]);
+            }
+        }
+    }
+    if (row0 >= N) return;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) {
+            const float v = wave_sum_f(acc[r][tt]);
+            if (lane == 0 && row0 + r < N && t0 + tt < T) y[(t0 + tt) * ldy + row0 + r] = apply_epi(epi, v, t0 + tt, row0 + r, ldy);
+        }
+    }
+}
+
+template <int FMT>
+static void launch_mvq_fmt(const DevTensor & W, const QAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
+    const int64_t N = W.rows();
+    const int nb = (int)(W.cols() / 32);
+    if (T == 1) {
+        constexpr int R = 4;
+        const dim3 grid((unsigned)((N + 4 * R - 1) / (4 * R)));
+        hipLaunchKernelGGL((k_mvq_t1<FMT, R>), grid, dim3(256), 0, st, W.qs, W.qh, W.sc, N, nb, x.q, x.d, x.s, x.isum, y, epi);
+    } else {
+        constexpr int R = 4, TT = 8;
+        const dim3 grid((unsigned)((N + 4 * R - 1) / (4 * R)), (unsigned)((T + TT - 1) / TT));
+        hipLaunchKernelGGL((k_mvq_tn<FMT, R, TT>), grid, dim3(256), 0, st, W.qs, W.qh, W.sc, N, nb, x.q, x.d, x.s, x.isum, T, y, ldy, epi);
+    }
+}
+
+void launch_matvec_q(const DevTensor & W, const QAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
+    switch (W.type) {
+        case T_Q4_0: launch_mvq_fmt<T_Q4_0>(W, x, T, y, ldy, epi, st); break;
+        case T_Q4_1: launch_mvq_fmt<T_Q4_1>(W, x, T, y, ldy, epi, st); break;
+        case T_Q5_0: launch_mvq_fmt<T_Q5_0>(W, x, T, y, ldy, epi, st); break;
+        case T_Q5_1: launch_mvq_fmt<T_Q5_1>(W, x, T, y, ldy, epi, st); break;
+        case T_Q8_0: launch_mvq_fmt<T_Q8_0>(W, x, T, y, ldy, epi, st); break;
+        default: break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Projection, F32 / F16 weights. Lane l owns 16-byte chunks l, l+64, ... of a row (4 f32 or 8 f16 weights each) and
+// accumulates them with fma in element order; same butterfly; same order in the token-tiled variant.
+// ---------------------------------------------------------------------------------------------------------------
+
+template <bool F16> struct FChunk { static constexpr int E = F16 ? 8 : 4; };
+
+template <bool F16>
+__device__ __forceinline__ void load_fchunk(float (&w)[FChunk<F16>::E], const void * __restrict__ base, int64_t chunk) {
+    const int4 raw = reinterpret_cast<const int4 *>(base)[chunk];
+    if constexpr (F16) {
+        const unsigned u[4] = {(unsigned) raw.x, (unsigned) raw.y, (unsigned) raw.z, (unsigned) raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            w[2 * i] = h2f_bits((uint16_t)(u[i] & 0xFFFFu));
+            w[2 * i + 1] = h2f_bits((uint16_t)(u[i] >> 16));
+        }
+    } else {
+        w[0] = __int_as_float(raw.x); w[1] = __int_as_float(raw.y); w[2] = __int_as_float(raw.z); w[3] = __int_as_float(raw.w);
+    }
+}
+
+template <bool F16, int R>
+__global__ __launch_bounds__(256) void k_mvf_t1(const void * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x,
+                                                float * __restrict__ y, Epi epi) {
+    constexpr int E = FChunk<F16>::E;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t) blockIdx.x * 4 + wave) * R;
+    if (row0 >= N) return;
+    const int64_t nch = K / E;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0f;
+    for (int64_t c = lane; c < nch; c += WAVE) {
+        float xv[E];
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + c * E + i);
+            xv[i] = v.x; xv[i + 1] = v.y; xv[i + 2] = v.z; xv[i + 3] = v.w;
+        }
+        if constexpr (F16) {
+#pragma unroll
+            for (int i = 0; i < E; i++) xv[i] = round_f16(xv[i]);
+        }
+        float w[R][E];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
+            load_fchunk<F16>(w[r], W, row * nch + c);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int i = 0; i < E; i++) acc[r] = fmaf(w[r][i], xv[i], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const float v = wave_sum_f(acc[r]);
+        if (lane == 0 && row0 + r < N) y[row0 + r] = apply_epi(epi, v, 0, row0 + r, 0);
+    }
+}
+
+template <bool F16, int R, int TT>
+__global__ __launch_bounds__(256) void k_mvf_tn(const void * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x, int64_t ldx,
+                                                int64_t T, float * __restrict__ y, int64_t ldy, Epi epi) {
+    constexpr int E = FChunk<F16>::E;
+    constexpr int Q = E / 4;  // float4's per chunk
+    __shared__ __attribute__((aligned(16))) float l_x[TT * 64 * E];  // [tt][q][lane][4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t) blockIdx.x * 4 + wave) * R;
+    const int64_t t0 = (int64_t) blockIdx.y * TT;
+    const int64_t nch = K / E;
+    float acc[R][TT];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) acc[r][tt] = 0.0f;
+
+    for (int64_t c0 = 0; c0 < nch; c0 += 64) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < TT * 64 * Q; c += 256) {
+            const int tt = c / (64 * Q), rem = c % (64 * Q), ch = rem / Q, q = rem % Q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + tt < T && c0 + ch < nch) v = *reinterpret_cast<const float4 *>(x + (t0 + tt) * ldx + (c0 + ch) * E + q * 4);
+            if constexpr (F16) { v.x = round_f16(v.x); v.y = round_f16(v.y); v.z = round_f16(v.z); v.w = round_f16(v.w); }
+            *reinterpret_cast<float4 *>(l_x + ((tt * Q + q) * 64 + ch) * 4) = v;
+        }
+        __syncthreads();
+        const int64_t c = c0 + lane;
+        if (c < nch && row0 < N) {
+            float w[R][E];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
+                load_fchunk<F16>(w[r], W, row * nch + c);
+            }
+#pragma unroll
+            for (int tt = 0; tt < TT; tt++) {
+                float xv[E];
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const float4 v = *reinterpret_cast<const float4 *>(l_x + ((tt * Q + q) * 64 + lane) * 4);
+                    xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int i = 0; i < E; i++) acc[r][tt] = fmaf(w[r][i], xv[i], acc[r][tt]);
+            }
+        }
+    }
+    if (row0 >= N) return;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) {
+            const float v = wave_sum_f(acc[r][tt]);
+            if (lane == 0 && row0 + r < N && t0 + tt < T) y[(t0 + tt) * ldy + row0 + r] = apply_epi(epi, v, t0 + tt, row0 + r, ldy);
+        }
+    }
+}
+
+template <bool F16>
+static void launch_mvf_t(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
+    const int64_t N = W.rows(), K = W.cols();
+    if (T == 1) {
+        constexpr int R = 4;
+        const dim3 grid((unsigned)((N + 4 * R - 1) / (4 * R)));
+        hipLaunchKernelGGL((k_mvf_t1<F16, R>), grid, dim3(256), 0, st, W.data, N, K, x, y, epi);
+    } else {
+        constexpr int R = 4, TT = 4;
+        const dim3 grid((unsigned)((N + 4 * R - 1) / (4 * R)), (unsigned)((T + TT - 1) / TT));
+        hipLaunchKernelGGL((k_mvf_tn<F16, R, TT>), grid, dim3(256), 0, st, W.data, N, K, x, ldx, T, y, ldy, epi);
+    }
+}
+
+void launch_matvec_f(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
+    if (W.type == T_F16) launch_mvf_t<true>(W, x, ldx, T, y, ldy, epi, st);
+    else launch_mvf_t<false>(W, x, ldx, T, y, ldy, epi, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Activation quantiser f32 -> Q8_0/Q8_1 blocks (ggml quantize_row_q8_0 / q8_1 reference semantics)
+// one half-wave (32 lanes) per block
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_quant_act(const float * __restrict__ x, int64_t n_blocks, int8_t * __restrict__ q,
+                                                   float * __restrict__ d, float * __restrict__ s, int * __restrict__ isum) {
+    const int64_t blk = ((int64_t) blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int e = threadIdx.x & 31;
+    if (blk >= n_blocks) return;
+    const float v = x[blk * 32 + e];
+    float amax = fabsf(v);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, WAVE));
+    const float dd = amax / 127.0f;
+    const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+    const int qi = (int) roundf(v * id);
+    int sum = qi;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);
+    q[blk * 32 + e] = (int8_t) qi;
+    if (e == 0) {
+        d[blk] = round_f16(dd);
+        s[blk] = round_f16((float) sum * dd);
+        isum[blk] = sum;
+    }
+}
+
+void launch_quantize_act(const float * x, int64_t T, int64_t K, const QAct & out, hipStream_t st) {
+    const int64_t n_blocks = T * K / 32;
+    const unsigned grid = (unsigned)((n_blocks * 32 + 255) / 256);
+    hipLaunchKernelGGL(k_quant_act, dim3(grid), dim3(256), 0, st, x, n_blocks, out.q, out.d, out.s, out.isum);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Embedding gather + LayerNorm, LayerNorm. One 256-thread block per token; the row lives in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+
+struct EmbView {
+    int type;
+    const void * data;
+    const uint8_t * qs;
+    const uint32_t * qh;
+    const void * sc;
+};
+
+__device__ __forceinline__ float emb_elem(const EmbView & e, int64_t row, int64_t D, int64_t k) {
+    switch (e.type) {
+        case T_F32: return reinterpret_cast<const float *>(e.data)[row * D + k];
+        case T_F16: return h2f_bits(reinterpret_cast<const uint16_t *>(e.data)[row * D + k]);
+        default: break;
+    }
+    // quantised embedding (never produced by the reference quantiser, supported for completeness)
+    const int64_t blk = row * (D / 32) + k / 32;
+    const int j = (int)(k & 31);
+    float d, m = 0.0f;
+    int code;
+    if (e.type == T_Q8_0) {
+        code = reinterpret_cast<const int8_t *>(e.qs)[blk * 32 + j];
+        d = h2f_bits(reinterpret_cast<const uint16_t *>(e.sc)[blk]);
+        return code * d;
+    }
+    const uint8_t byte = e.qs[blk * 16 + (j & 15)];
+    code = (j < 16) ? (byte & 0x0F) : (byte >> 4);
+    if (e.type == T_Q5_0 || e.type == T_Q5_1) code |= (int)((e.qh[blk] >> j) & 1u) << 4;
+    if (e.type == T_Q4_1 || e.type == T_Q5_1) {
+        const uint32_t dm = reinterpret_cast<const uint32_t *>(e.sc)[blk];
+        d = h2f_bits((uint16_t)(dm & 0xFFFF)); m = h2f_bits((uint16_t)(dm >> 16));
+        return code * d + m;
+    }
+    d = h2f_bits(reinterpret_cast<const uint16_t *>(e.sc)[blk]);
+    return (code - (e.type == T_Q4_0 ? 8 : 16)) * d;
+}
+
+// normalises the row held in l_row (D floats) in place: (x - mean) / sqrt(var + eps) * w + b, written to out
+__device__ __forceinline__ void block_layernorm(float * l_row, int64_t D, const float * __restrict__ w, const float * __restrict__ b,
+                                                float eps, float * __restrict__ out, double * red) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) s += (double) l_row[i];
+    const float mean = (float)(block_sum_d(s, red) / (double) D);
+    double s2 = 0.0;
+    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
+    const float var = (float)(block_sum_d(s2, red) / (double) D);
+    const float scale = 1.0f / sqrtf(var + eps);
+    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) out[i] = fmaf(l_row[i] * scale, w[i], b[i]);
+}
+
+__global__ __launch_bounds__(256) void k_embed_ln0(EmbView emb, const uint32_t * __restrict__ tokens, int64_t D,
+                                                   const float * __restrict__ w, const float * __restrict__ b, float * __restrict__ x) {
+    extern __shared__ __attribute__((aligned(16))) float l_row[];
+    __shared__ double red[17];
+    const int64_t t = blockIdx.x;
+    const int64_t row = tokens[t];
+    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) l_row[i] = emb_elem(emb, row, D, i);
+    __syncthreads();
+    block_layernorm(l_row, D, w, b, 1e-5f, x + t * D, red);
+}
+
+__global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x, int64_t D, const float * __restrict__ w,
+                                                   const float * __restrict__ b, float * __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float l_row[];
+    __shared__ double red[17];
+    const int64_t t = blockIdx.x;
+    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) l_row[i] = x[t * D + i];
+    __syncthreads();
+    block_layernorm(l_row, D, w, b, 1e-5f, y + t * D, red);
+}
+
+void launch_embed_ln0(const DevTensor & emb, const uint32_t * tokens, int64_t T, int64_t D, const float * w, const float * b, float * x, hipStream_t st) {
+    EmbView e{emb.type, emb.data, emb.qs, emb.qh, emb.sc};
+    hipLaunchKernelGGL(k_embed_ln0, dim3((unsigned) T), dim3(256), (size_t) D * sizeof(float), st, e, tokens, D, w, b, x);
+}
+
+void launch_layernorm(const float * x, int64_t T, int64_t D, const float * w, const float * b, float * y, hipStream_t st) {
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned) T), dim3(256), (size_t) D * sizeof(float), st, x, D, w, b, y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Token-shift mixes
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_mix(MixArgs a, int64_t T, int64_t D) {
+    const int64_t n = T * D;
+    for (int64_t idx = (int64_t) blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t) gridDim.x * 256) {
+        const int64_t t = idx / D, d = idx - t * D;
+        const float x = a.xn[idx];
+        const float xp = (t == 0) ? a.carry_in[d] : a.xn[idx - D];
+        if (a.mode == 0) {
+            for (int f = 0; f < a.n_out; f++) { const float c = a.coef[f][d]; a.out[f][idx] = x * c + (xp - xp * c); }
+        } else {
+            const float sx = xp - x;
+            if (a.sx) a.sx[idx] = sx;
+            for (int f = 0; f < a.n_out; f++) a.out[f][idx] = sx * a.coef[f][d] + x;
+        }
+        if (t == T - 1) a.carry_out[d] = x;
+    }
+}
+
+void launch_mix(const MixArgs & a, int64_t T, int64_t D, hipStream_t st) {
+    const int64_t n = T * D;
+    const unsigned grid = (unsigned) ((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_mix, dim3(grid), dim3(256), 0, st, a, T, D);
+}
+
+__global__ __launch_bounds__(256) void k_v6_mix2(V6Mix2Args a, int64_t T, int64_t D, int64_t R) {
+    const int64_t n = T * 5 * D;
+    for (int64_t idx = (int64_t) blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t) gridDim.x * 256) {
+        const int64_t d = idx % D;
+        const int64_t f = (idx / D) % 5;
+        const int64_t t = idx / (5 * D);
+        const float * row = a.w2 + (f * D + d) * R;
+        const float * tl = a.tl + t * 5 * R + f * R;
+        float acc = 0.0f;
+        for (int64_t m = 0; m < R; m += 4) {
+            const float4 wv = *reinterpret_cast<const float4 *>(row + m);
+            acc = fmaf(wv.x, tl[m], acc); acc = fmaf(wv.y, tl[m + 1], acc);
+            acc = fmaf(wv.z, tl[m + 2], acc); acc = fmaf(wv.w, tl[m + 3], acc);
+        }
+        const int64_t o = t * D + d;
+        a.out[f][o] = fmaf(acc + a.maa[f][d], a.sx[o], a.xn[o]);
+    }
+}
+
+void launch_v6_mix2(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, hipStream_t st) {
+    const int64_t n = T * 5 * D;
+    const unsigned grid = (unsigned) ((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_v6_mix2, dim3(grid), dim3(256), 0, st, a, T, D, R);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// WKV recurrences. Sequential in t inside the kernel; the state stays in registers across the tokens of a call.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_wkv4(const float * __restrict__ k, const float * __restrict__ v, const float * __restrict__ r,
+                                              const float * __restrict__ tf, const float * __restrict__ td,
+                                              const float * __restrict__ aa_in, const float * __restrict__ bb_in, const float * __restrict__ pp_in,
+                                              float * __restrict__ aa_out, float * __restrict__ bb_out, float * __restrict__ pp_out,
+                                              float * __restrict__ out, int64_t T, int64_t D) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    float aa = aa_in[i], bb = bb_in[i], pp = pp_in[i];
+    const float u = tf[i], w = td[i];
+    for (int64_t t = 0; t < T; t++) {
+        const float kk = k[t * D + i], vv = v[t * D + i];
+        float ww = u + kk;
+        float qq = fmaxf(pp, ww);
+        float e1 = expf(pp - qq), e2 = expf(ww - qq);
+        const float a = e1 * aa + e2 * vv;
+        const float b = e1 * bb + e2;
+        ww = pp + w;
+        qq = fmaxf(ww, kk);
+        e1 = expf(ww - qq); e2 = expf(kk - qq);
+        aa = e1 * aa + e2 * vv;
+        bb = e1 * bb + e2;
+        pp = qq;
+        out[t * D + i] = r[t * D + i] * (a / b);
+    }
+    aa_out[i] = aa; bb_out[i] = bb; pp_out[i] = pp;
+}
+
+void launch_wkv4(const float * k, const float * v, const float * r, const float * time_first, const float * time_decay,
+                 const float * aa_in, const float * bb_in, const float * pp_in, float * aa_out, float * bb_out, float * pp_out,
+                 float * out, int64_t T, int64_t D, hipStream_t st) {
+    hipLaunchKernelGGL(k_wkv4, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, k, v, r, time_first, time_decay,
+                       aa_in, bb_in, pp_in, aa_out, bb_out, pp_out, out, T, D);
+}
+
+// wkv6: one wave per head, lane j owns value column j of state[h][:, j] (SREG = S when S is a supported compile-time
+// size, else the state column is kept in global memory -- generic path for unusual head sizes).
+template <int S>
+__global__ __launch_bounds__(64) void k_wkv6(const float * __restrict__ r, const float * __restrict__ k, const float * __restrict__ v,
+                                             const float * __restrict__ u, int u_per_chan, const float * __restrict__ w, int w_mode,
+                                             const float * __restrict__ state_in, float * __restrict__ state_out, float * __restrict__ out,
+                                             int64_t T, int64_t H) {
+    __shared__ float l_r[S], l_k[S], l_u[S], l_w[S];
+    const int64_t h = blockIdx.x;
+    const int j = threadIdx.x;
+    const int64_t D = H * S;
+    float s[S];
+    if (j < S) {
+#pragma unroll
+        for (int i = 0; i < S; i++) s[i] = state_in[h * S * S + i * S + j];
+    }
+    if (j < S) {
+        l_u[j] = u_per_chan ? u[h * S + j] : u[h];
+        if (w_mode < 2) l_w[j] = (w_mode == 1) ? w[h * S + j] : w[h];
+    }
+    for (int64_t t = 0; t < T; t++) {
+        __syncthreads();
+        if (j < S) {
+            l_r[j] = r[t * D + h * S + j];
+            l_k[j] = k[t * D + h * S + j];
+            if (w_mode == 2) l_w[j] = w[t * D + h * S + j];
+        }
+        __syncthreads();
+        if (j < S) {
+            const float vj = v[t * D + h * S + j];
+            float o = 0.0f;
+#pragma unroll
+            for (int i = 0; i < S; i++) {
+                const float kv = vj * l_k[i];
+                const float prev = s[i];
+                o = fmaf(fmaf(kv, l_u[i], prev), l_r[i], o);
+                s[i] = fmaf(prev, l_w[i], kv);
+            }
+            out[t * D + h * S + j] = o;
+        }
+    }
+    if (j < S) {
+#pragma unroll
+        for (int i = 0; i < S; i++) state_out[h * S * S + i * S + j] = s[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wkv6_generic(const float * __restrict__ r, const float * __restrict__ k, const float * __restrict__ v,
+                                                      const float * __restrict__ u, int u_per_chan, const float * __restrict__ w, int w_mode,
+                                                      const float * __restrict__ state_in, float * __restrict__ state_out, float * __restrict__ out,
+                                                      int64_t T, int64_t H, int64_t S) {
+    const int64_t h = blockIdx.x;
+    const int64_t D = H * S;
+    for (int64_t j = threadIdx.x; j < S; j += blockDim.x) {
+        for (int64_t t = 0; t < T; t++) {
+            const float * sin = (t == 0) ? state_in : state_out;
+            const float vj = v[t * D + h * S + j];
+            float o = 0.0f;
+            for (int64_t i = 0; i < S; i++) {
+                const float ki = k[t * D + h * S + i], ri = r[t * D + h * S + i];
+                const float ui = u_per_chan ? u[h * S + i] : u[h];
+                const float wi = (w_mode == 2) ? w[t * D + h * S + i] : (w_mode == 1 ? w[h * S + i] : w[h]);
+                const float kv = vj * ki;
+                const float prev = sin[h * S * S + i * S + j];
+                o = fmaf(fmaf(kv, ui, prev), ri, o);
+                state_out[h * S * S + i * S + j] = fmaf(prev, wi, kv);
+            }
+            out[t * D + h * S + j] = o;
+        }
+    }
+}
+
+void launch_wkv6(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
+                 const float * state_in, float * state_out, float * out, int64_t T, int64_t H, int64_t S, hipStream_t st) {
+    switch (S) {
+        case 64: hipLaunchKernelGGL((k_wkv6<64>), dim3((unsigned) H), dim3(64), 0, st, r, k, v, u, u_per_chan, w, w_mode, state_in, state_out, out, T, H); break;
+        case 32: hipLaunchKernelGGL((k_wkv6<32>), dim3((unsigned) H), dim3(64), 0, st, r, k, v, u, u_per_chan, w, w_mode, state_in, state_out, out, T, H); break;
+        case 16: hipLaunchKernelGGL((k_wkv6<16>), dim3((unsigned) H), dim3(64), 0, st, r, k, v, u, u_per_chan, w, w_mode, state_in, state_out, out, T, H); break;
+        case 8:  hipLaunchKernelGGL((k_wkv6<8>),  dim3((unsigned) H), dim3(64), 0, st, r, k, v, u, u_per_chan, w, w_mode, state_in, state_out, out, T, H); break;
+        default: hipLaunchKernelGGL(k_wkv6_generic, dim3((unsigned) H), dim3(256), 0, st, r, k, v, u, u_per_chan, w, w_mode, state_in, state_out, out, T, H, S); break;
+    }
+}
+
+// wkv7: one wave per head, lane i owns value row i of state[h][i, :].
+template <int S>
+__global__ __launch_bounds__(64) void k_wkv7(const float * __restrict__ r, const float * __restrict__ w, const float * __restrict__ k,
+                                             const float * __restrict__ v, const float * __restrict__ a, const float * __restrict__ b,
+                                             const float * __restrict__ state_in, float * __restrict__ state_out, float * __restrict__ out,
+                                             int64_t T, int64_t H) {
+    __shared__ float l_r[S], l_w[S], l_k[S], l_a[S], l_b[S];
+    const int64_t h = blockIdx.x;
+    const int i = threadIdx.x;
+    const int64_t D = H * S;
+    float s[S];
+    if (i < S) {
+#pragma unroll
+        for (int j = 0; j < S; j += 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(state_in + h * S * S + (int64_t) i * S + j);
+            s[j] = q.x; s[j + 1] = q.y; s[j + 2] = q.z; s[j + 3] = q.w;
+        }
+    }
+    for (int64_t t = 0; t < T; t++) {
+        __syncthreads();
+        if (i < S) {
+            const int64_t o = t * D + h * S + i;
+            l_r[i] = r[o]; l_w[i] = w[o]; l_k[i] = k[o]; l_a[i] = a[o]; l_b[i] = b[o];
+        }
+        __syncthreads();
+        if (i < S) {
+            const float vi = v[t * D + h * S + i];
+            float sa = 0.0f;
+#pragma unroll
+            for (int j = 0; j < S; j++) sa = fmaf(l_a[j], s[j], sa);
+            float res = 0.0f;
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+                const float kv = vi * l_k[j];
+                const float ns = fmaf(sa, l_b[j], fmaf(s[j], l_w[j], kv));
+                s[j] = ns;
+                res = fmaf(ns, l_r[j], res);
+            }
+            out[t * D + h * S + i] = res;
+        }
+    }
+    if (i < S) {
+#pragma unroll
+        for (int j = 0; j < S; j += 4)
+            *reinterpret_cast<float4 *>(state_out + h * S * S + (int64_t) i * S + j) = make_float4(s[j], s[j + 1], s[j + 2], s[j + 3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wkv7_generic(const float * __restrict__ r, const float * __restrict__ w, const float * __restrict__ k,
+                                                      const float * __restrict__ v, const float * __restrict__ a, const float * __restrict__ b,
+                                                      const float * __restrict__ state_in, float * __restrict__ state_out, float * __restrict__ out,
+                                                      int64_t T, int64_t H, int64_t S) {
+    const int64_t h = blockIdx.x;
+    const int64_t D = H * S;
+    for (int64_t i = threadIdx.x; i < S; i += blockDim.x) {
+        for (int64_t t = 0; t < T; t++) {
+            const float * sin = (t == 0) ? state_in : state_out;
+            const int64_t base = t * D + h * S;
+            const float vi = v[base + i];
+            float sa = 0.0f;
+            for (int64_t j = 0; j < S; j++) sa = fmaf(a[base + j], sin[h * S * S + i * S + j], sa);
+            float res = 0.0f;
+            for (int64_t j = 0; j < S; j++) {
+                const float kv = vi * k[base + j];
+                const float ns = fmaf(sa, b[base + j], fmaf(sin[h * S * S + i * S + j], w[base + j], kv));
+                state_out[h * S * S + i * S + j] = ns;
+                res = fmaf(ns, r[base + j], res);
+            }
+            out[base + i] = res;
+        }
+    }
+}
+
+void launch_wkv7(const float * r, const float * w, const float * k, const float * v, const float * a, const float * b,
+                 const float * state_in, float * state_out, float * out, int64_t T, int64_t H, int64_t S, hipStream_t st) {
+    switch (S) {
+        case 64: hipLaunchKernelGGL((k_wkv7<64>), dim3((unsigned) H), dim3(64), 0, st, r, w, k, v, a, b, state_in, state_out, out, T, H); break;
+        case 32: hipLaunchKernelGGL((k_wkv7<32>), dim3((unsigned) H), dim3(64), 0, st, r, w, k, v, a, b, state_in, state_out, out, T, H); break;
+        default: hipLaunchKernelGGL(k_wkv7_generic, dim3((unsigned) H), dim3(256), 0, st, r, w, k, v, a, b, state_in, state_out, out, T, H, S); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Group norm (+ v7 bonus, + gate), v7 key prep, small elementwise kernels. One wave per (token, head).
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_groupnorm(float * __restrict__ x, const float * __restrict__ lw, const float * __restrict__ lb, float eps,
+                                                   const float * __restrict__ gate, const float * __restrict__ v7_k, const float * __restrict__ v7_r,
+                                                   const float * __restrict__ v7_v, const float * __restrict__ v7_rk, int64_t TH, int64_t H, int64_t S) {
+    const int lane = threadIdx.x & 63;
+    const int64_t th = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (th >= TH) return;
+    const int64_t h = th % H;
+    const int64_t base = th * S;  // == t*D + h*S
+    double s = 0.0;
+    for (int64_t j = lane; j < S; j += WAVE) s += (double) x[base + j];
+    const float mean = (float)(wave_sum_d(s) / (double) S);
+    double s2 = 0.0;
+    for (int64_t j = lane; j < S; j += WAVE) { const float v = x[base + j] - mean; s2 += (double)(v * v); }
+    const float var = (float)(wave_sum_d(s2) / (double) S);
+    const float scale = 1.0f / sqrtf(var + eps);
+    float bonus = 0.0f;
+    if (v7_k) {
+        float p = 0.0f;
+        for (int64_t j = lane; j < S; j += WAVE) p = fmaf(v7_k[base + j] * v7_r[base + j], v7_rk[h * S + j], p);
+        bonus = wave_sum_f(p);
+    }
+    for (int64_t j = lane; j < S; j += WAVE) {
+        float y = fmaf((x[base + j] - mean) * scale, lw[h * S + j], lb[h * S + j]);
+        if (v7_k) y = fmaf(v7_v[base + j], bonus, y);
+        if (gate) y *= gate[base + j];
+        x[base + j] = y;
+    }
+}
+
+void launch_groupnorm(float * x, const float * lw, const float * lb, float eps, const float * gate,
+                      const float * v7_k, const float * v7_r, const float * v7_v, const float * v7_rk,
+                      int64_t T, int64_t H, int64_t S, hipStream_t st) {
+    const int64_t TH = T * H;
+    hipLaunchKernelGGL(k_groupnorm, dim3((unsigned)((TH + 3) / 4)), dim3(256), 0, st, x, lw, lb, eps, gate, v7_k, v7_r, v7_v, v7_rk, TH, H, S);
+}
+
+__global__ __launch_bounds__(256) void k_v7_kprep(const float * __restrict__ k, const float * __restrict__ a, const float * __restrict__ k_k,
+                                                  const float * __restrict__ k_a, float * __restrict__ k_out, float * __restrict__ neg_kk,
+                                                  float * __restrict__ kk_a, int64_t TH, int64_t H, int64_t S) {
+    const int lane = threadIdx.x & 63;
+    const int64_t th = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (th >= TH) return;
+    const int64_t h = th % H;
+    const int64_t base = th * S;
+    float p = 0.0f;
+    for (int64_t j = lane; j < S; j += WAVE) { const float t = k[base + j] * k_k[h * S + j]; p = fmaf(t, t, p); }
+    const float sum = wave_sum_f(p);
+    const float scale = 1.0f / fmaxf(sqrtf(sum), 1e-12f);
+    for (int64_t j = lane; j < S; j += WAVE) {
+        const float kv = k[base + j], av = a[base + j];
+        const float kk = kv * k_k[h * S + j] * scale;
+        const float ka = kv * k_a[h * S + j];
+        k_out[base + j] = kv + (av * ka - ka);
+        neg_kk[base + j] = -kk;
+        kk_a[base + j] = kk * av;
+    }
+}
+
+void launch_v7_kprep(const float * k, const float * a, const float * k_k, const float * k_a, float * k_out, float * neg_kk, float * kk_a,
+                     int64_t T, int64_t H, int64_t S, hipStream_t st) {
+    const int64_t TH = T * H;
+    hipLaunchKernelGGL(k_v7_kprep, dim3((unsigned)((TH + 3) / 4)), dim3(256), 0, st, k, a, k_k, k_a, k_out, neg_kk, kk_a, TH, H, S);
+}
+
+__global__ __launch_bounds__(256) void k_v7_vmix(float * __restrict__ v, const float * __restrict__ v_first, const float * __restrict__ gate, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) v[i] = v[i] + (v_first[i] - v[i]) * gate[i];
+}
+void launch_v7_vmix(float * v, const float * v_first, const float * gate, int64_t n, hipStream_t st) {
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_v7_vmix, dim3(grid), dim3(256), 0, st, v, v_first, gate, n);
+}
+
+__global__ __launch_bounds__(256) void k_mul(float * __restrict__ y, const float * __restrict__ a, const float * __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) y[i] = a[i] * b[i];
+}
+void launch_mul(float * y, const float * a, const float * b, int64_t n, hipStream_t st) {
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_mul, dim3(grid), dim3(256), 0, st, y, a, b, n);
+}
+
+__global__ __launch_bounds__(256) void k_copy(float * __restrict__ dst, const float * __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) dst[i] = src[i];
+}
+void launch_copy_f32(float * dst, const float * src, int64_t n, hipStream_t st) {
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, st, dst, src, n);
+}
+
+__global__ __launch_bounds__(256) void k_fill_state_v4(float * __restrict__ state, int64_t n_layer, int64_t D) {
+    const int64_t n = n_layer * 5 * D;
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) state[i] = ((i / D) % 5 == 4) ? -1e30f : 0.0f;
+}
+void launch_fill_state_v4(float * state, int64_t n_layer, int64_t D, hipStream_t st) {
+    const int64_t n = n_layer * 5 * D;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_fill_state_v4, dim3(grid), dim3(256), 0, st, state, n_layer, D);
+}
+
+__global__ __launch_bounds__(1024) void k_argmax(const float * __restrict__ logits, int64_t n, uint32_t * __restrict__ out) {
+    __shared__ float l_v[16];
+    __shared__ int l_i[16];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = logits[i];
+        if (v > best) { best = v; bi = (int) i; }  // strided scan keeps the smallest index per thread for ties
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, WAVE);
+        const int oi = __shfl_xor(bi, o, WAVE);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { l_v[wave] = best; l_i[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+            if (l_v[w] > best || (l_v[w] == best && l_i[w] < bi)) { best = l_v[w]; bi = l_i[w]; }
+        *out = (uint32_t) bi;
+    }
+}
+void launch_argmax(const float * logits, int64_t n, uint32_t * out, hipStream_t st) {
+    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, n, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Load-time re-pack: file blocks (d [m] [qh] qs) -> planes. One thread per block.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_repack(int type, const uint8_t * __restrict__ raw, int64_t n_blocks, uint8_t * __restrict__ qs,
+                                                uint32_t * __restrict__ qh, uint8_t * __restrict__ sc) {
+    const int64_t b = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blocks) return;
+    int bsz, qoff, qbytes, scb, hoff = -1;
+    switch (type) {
+        case T_Q4_0: bsz = 18; scb = 2; qoff = 2; qbytes = 16; break;
+        case T_Q4_1: bsz = 20; scb = 4; qoff = 4; qbytes = 16; break;
+        case T_Q5_0: bsz = 22; scb = 2; hoff = 2; qoff = 6; qbytes = 16; break;
+        case T_Q5_1: bsz = 24; scb = 4; hoff = 4; qoff = 8; qbytes = 16; break;
+        default:     bsz = 34; scb = 2; qoff = 2; qbytes = 32; break;  // Q8_0
+    }
+    const uint8_t * src = raw + b * bsz;
+    for (int i = 0; i < scb; i++) sc[b * scb + i] = src[i];
+    if (hoff >= 0) qh[b] = (uint32_t) src[hoff] | ((uint32_t) src[hoff + 1] << 8) | ((uint32_t) src[hoff + 2] << 16) | ((uint32_t) src[hoff + 3] << 24);
+    for (int i = 0; i < qbytes; i++) qs[b * qbytes + i] = src[qoff + i];
+}
+
+void launch_repack(int type, const uint8_t * raw, int64_t n_blocks, uint8_t * qs, uint32_t * qh, void * sc, hipStream_t st) {
+    hipLaunchKernelGGL(k_repack, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, type, raw, n_blocks, qs, qh, (uint8_t *) sc);
+}
+
+}  // namespace rwkvmi

@@ -1,0 +1,127 @@
+// model.h -- weights resident in HBM + the per-context execution state of librwkv.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <atomic>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace rwkvmi {
+
+// Parameter slots of one layer; names follow the reference's key table (rwkv_model_loading.inc:132-282).
+struct LayerW {
+    const DevTensor *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
+    // v4 / v5
+    const DevTensor *att_time_mix_k = nullptr, *att_time_mix_v = nullptr, *att_time_mix_r = nullptr, *att_time_mix_g = nullptr;
+    const DevTensor *att_time_first = nullptr, *att_time_decay = nullptr, *att_time_faaaa = nullptr;
+    const DevTensor *att_key = nullptr, *att_value = nullptr, *att_receptance = nullptr, *att_output = nullptr, *att_gate = nullptr;
+    const DevTensor *att_ln_x_w = nullptr, *att_ln_x_b = nullptr;
+    // v6
+    const DevTensor *att_time_maa_x = nullptr, *att_time_maa_w = nullptr, *att_time_maa_k = nullptr, *att_time_maa_v = nullptr,
+                    *att_time_maa_r = nullptr, *att_time_maa_g = nullptr, *att_time_maa_w1 = nullptr, *att_time_maa_w2 = nullptr,
+                    *att_time_decay_w1 = nullptr, *att_time_decay_w2 = nullptr;
+    // v7
+    const DevTensor *att_x_rwkvag = nullptr, *att_w0 = nullptr, *att_w1 = nullptr, *att_w2 = nullptr, *att_a0 = nullptr, *att_a1 = nullptr,
+                    *att_a2 = nullptr, *att_g1 = nullptr, *att_g2 = nullptr, *att_v0 = nullptr, *att_v1 = nullptr, *att_v2 = nullptr,
+                    *att_r_k = nullptr, *att_k_k = nullptr, *att_k_a = nullptr;
+    // channel mixing
+    const DevTensor *ffn_time_mix_k = nullptr, *ffn_time_mix_r = nullptr, *ffn_time_maa_k = nullptr, *ffn_time_maa_r = nullptr, *ffn_x_k = nullptr;
+    const DevTensor *ffn_key = nullptr, *ffn_value = nullptr, *ffn_receptance = nullptr;
+};
+
+struct Model {
+    FileHeader header{};
+    int arch_major = 4, arch_minor = 0;
+    int64_t head_count = 0, head_size = 0, ffn_size = 0;
+    int64_t max_lowrank = 0;  // widest intermediate of a low-rank pair (v6 5*r, decay rank; v7 ranks)
+
+    std::vector<std::unique_ptr<DevTensor>> tensors;
+    std::unordered_map<std::string, DevTensor *> by_name;
+
+    const DevTensor *emb = nullptr, *ln0_w = nullptr, *ln0_b = nullptr, *ln_out_w = nullptr, *ln_out_b = nullptr, *head = nullptr;
+    std::vector<LayerW> layers;  // indexed by absolute layer id; only [layer_begin, layer_end) are populated
+
+    // pipeline stage owned by this process (whole model by default)
+    uint32_t layer_begin = 0, layer_end = 0;
+    bool has_embed = true, has_head = true;
+
+    void * arena = nullptr;       // one HBM allocation holding every parameter plane
+    size_t arena_bytes = 0;
+    int device = 0;
+    uint64_t bytes_per_token = 0; // algorithmic bytes of one decoded token on this stage
+    uint64_t weight_bytes = 0;
+
+    std::atomic<int> refcount{0};
+
+    int64_t n_embed() const { return header.n_embed; }
+    int64_t n_vocab() const { return header.n_vocab; }
+    int64_t n_layer() const { return header.n_layer; }
+    int64_t state_per_layer() const { return arch_major >= 5 ? n_embed() * (2 + head_size) : n_embed() * 5; }
+    int64_t state_len() const { return state_per_layer() * n_layer(); }
+};
+
+// Loads [layer_begin, layer_end) of the file (layer_end == UINT32_MAX: all layers) onto the current HIP device.
+// Returns nullptr with the thread-local error set, like the reference loader (rwkv_model_loading.inc:288-419).
+Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end);
+void    release_model(Model * m);
+
+}  // namespace rwkvmi
+
+// ---------------------------------------------------------------------------------------------------------------
+// The context (opaque to callers).
+// ---------------------------------------------------------------------------------------------------------------
+
+struct rwkv_context {
+    rwkvmi::Model * model = nullptr;
+    uint32_t n_threads = 0;
+    int  last_error = 0;
+    bool print_errors = false;  // a fresh reference context starts silent (rwkv.cpp:74 value-initialises it)
+
+    hipStream_t stream = nullptr;
+
+    // Device-resident recurrent state, ping-pong (kernels read [cur], write [cur ^ 1]).
+    float * state[2] = {nullptr, nullptr};
+    int cur = 0;
+
+    // Scratch for T tokens (grown on demand).
+    int64_t scratch_T = 0;
+    void *  scratch = nullptr;
+    size_t  scratch_bytes = 0;
+    struct Buf {
+        float *x, *xn, *sx, *m[6], *r, *k, *v, *g, *w, *a, *t0, *t1, *t2, *out, *ffk, *lr1, *lr2, *v_first, *xlast;
+        rwkvmi::QAct qa;
+    } b{};
+
+    uint32_t * d_tokens = nullptr;
+    int64_t    d_tokens_cap = 0;
+    float *    d_logits = nullptr;
+    uint32_t * d_next_token = nullptr;
+
+    // pinned host staging for tokens / logits
+    uint32_t * h_tokens = nullptr;
+    int64_t    h_tokens_cap = 0;
+
+    // captured single-token graphs: [cur][with_logits]
+    hipGraphExec_t graph_exec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    bool use_graph = true;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace rwkvmi {
+
+rwkv_context * create_context(Model * m, uint32_t n_threads);
+void destroy_context(rwkv_context * ctx);
+
+// state upload / download / init on the device-resident state
+bool state_from_host(rwkv_context * ctx, const float * state_in /* NULL = fresh */);
+bool state_to_host(rwkv_context * ctx, float * state_out);
+
+// Runs T tokens (already in ctx->d_tokens) through the layers of this stage. Reads state[cur], writes state[cur^1], flips cur.
+// x_in / x_out: residual stream hand-off for pipeline stages (nullptr on a full model). Logits land in ctx->d_logits.
+bool forward(rwkv_context * ctx, int64_t T, bool want_logits);
+// single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
+bool forward_decode(rwkv_context * ctx, bool want_logits);
+
+}  // namespace rwkvmi

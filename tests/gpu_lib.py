@@ -1,0 +1,49 @@
+"""Shared helpers of the GPU parity tests: the product library through its C ABI + the CPU oracle as checker."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+pkg = graft.load_package()
+from rwkv_cpp_amd import synth  # noqa: E402,F401
+
+_lib = None
+
+
+def library():
+    global _lib
+    if _lib is None:
+        pkg.build_library()
+        _lib = pkg.load_rwkv_shared_library()
+        L = _lib.library
+        L.rwkv_mi_test_mul_mat.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        L.rwkv_mi_test_mul_mat.restype = ctypes.c_bool
+    return _lib
+
+
+def model(path, **kw):
+    return pkg.RWKVModel(library(), path, thread_count=2, gpu_layer_count=0, **kw)
+
+
+def gpu_mul_mat(type_id, w_bytes, K, N, x):
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, K)
+    T = x.shape[0]
+    w = np.ascontiguousarray(w_bytes).view(np.uint8)
+    y = np.empty((T, N), dtype=np.float32)
+    ok = library().library.rwkv_mi_test_mul_mat(type_id, w.ctypes.data, K, N, x.ctypes.data, T, y.ctypes.data)
+    assert ok, "rwkv_mi_test_mul_mat failed"
+    return y
+
+
+def run_prompt(m, tokens, sequence=False):
+    if sequence:
+        return m.eval_sequence(tokens, None)
+    state, logits = None, None
+    for t in tokens:
+        logits, state = m.eval(t, state)
+    return logits, state
