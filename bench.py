@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py -- single-stream decode of RWKV-6-World-7B Q4_0 (BASELINE.json's metric) through librwkv.so on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one decoded token: one pass of the hot path (embedding row, 32 x (time mixing + channel mixing), ln_out, head,
+on-device argmax) with weights and recurrent state already resident in HBM.  Weights are synthetic (seeded random blocks
+with the tensor names / shapes / dtypes of the real checkpoint; no checkpoint is available offline), the decode is greedy.
+
+Prints ONE JSON line (rank 0) with the contract's keys plus
+  "roofline":     the dominant kernel (quantised single-token projection) timed per launch with HIP events on its stream,
+  "cpu_baseline": the CPU oracle (a port of the reference's ggml CPU algorithm) timed on the host cores, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--config", default="rwkv6-7b", help="key of rwkv_cpp_amd.synth.CONFIGS")
+    ap.add_argument("--dtype", default="Q4_0")
+    ap.add_argument("--model-dir", default=os.environ.get("RWKV_BENCH_DIR", "/tmp"))
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline leg (0 disables it)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event pass")
+    return ap.parse_args()
+
+
+def ensure_model_file(args, synth, rank, barrier):
+    spec = synth.CONFIGS[args.config]
+    path = os.path.join(args.model_dir, f"synthetic-{args.config}-{args.dtype}-seed42.bin")
+    if rank == 0:
+        marker = path + ".ok"
+        if not (os.path.exists(path) and os.path.exists(marker)):
+            t = time.time()
+            info = synth.write_model(path, spec, args.dtype, seed=42)
+            with open(marker, "w") as f:
+                f.write(json.dumps(info))
+            print(f"[bench] wrote {path}: {info['bytes'] / 1e9:.2f} GB, {info['params'] / 1e9:.2f} B params in {time.time() - t:.1f}s", file=sys.stderr)
+    barrier()
+    return path, spec
+
+
+def cpu_baseline(path, first_token, budget_s):
+    """Times the CPU oracle (oracle/rwkv_oracle.c: ggml's CPU algorithm restated, OpenMP) on the same file and the same
+    greedy decode. Bounded sample; reported, never the target."""
+    import numpy as np
+    import oracle_lib
+    cores = os.cpu_count() or 1
+    oracle_lib.lib().orc_set_threads(cores)
+    t0 = time.time()
+    om = oracle_lib.OracleModel(path)
+    load_s = time.time() - t0
+    state = om.init_state()
+    tok, n, t_start = first_token, 0, time.time()
+    while True:
+        logits, state = om.eval(tok, state)
+        tok = int(np.argmax(logits))
+        n += 1
+        el = time.time() - t_start
+        if n >= 2 and (el + el / n > budget_s or n >= 64):
+            break
+    om.free()
+    return {"value": n / el, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{n} greedy decode tokens of the same model file on the host CPU ({el:.1f}s, load {load_s:.1f}s)"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1", file=sys.stderr)
+    import torch
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from rwkv_cpp_amd import synth
+    if rank == 0 and not os.path.exists(pkg.LIB_PATH):
+        pkg.build_library()
+    barrier()
+    lib = pkg.load_rwkv_shared_library()
+
+    path, spec = ensure_model_file(args, synth, rank, barrier)
+
+    if world > 1:
+        from rwkv_cpp_amd import pipeline  # layer pipeline over RCCL send/recv
+        result = pipeline.bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world)
+    else:
+        t0 = time.time()
+        model = pkg.RWKVModel(lib, path, thread_count=1, gpu_layer_count=spec.n_layer + 1)
+        load_s = time.time() - t0
+        bpt = model.bytes_per_token()
+        first = 1103515245 % spec.n_vocab
+        model.state_load(None)
+        if args.warmup > 0:
+            model.decode_greedy(first, args.warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks, ev_ms = model.decode_greedy(first, args.steps)
+        torch.cuda.synchronize()
+        wall_s = time.perf_counter() - t0
+        tok_s = args.steps / wall_s
+        result = {
+            "metric": "tokens/sec single-stream decode", "value": tok_s, "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall_s * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int8 x int4 dot, f32 accumulate (Q4_0 weights, Q8_0 activations); f16 head", "data": "synthetic",
+            "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode, state resident in HBM", "layers": spec.n_layer,
+                       "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": "1 GPU"},
+            "hbm": {"algorithmic_bytes_per_token": bpt, "achieved_GBps": bpt * tok_s / 1e9, "frac_of_8TBps": bpt * tok_s / 1e9 / HBM_PEAK_GBS,
+                    "hip_event_ms_per_token": ev_ms / args.steps},
+            "load_seconds": load_s,
+        }
+        if not args.no_profile:
+            p = model.profile_decode(first, min(args.steps, 32))
+            ach = p["bytes"] / (p["kernel_ms"] * 1e-3) / 1e9
+            result["roofline"] = {"bound": "hbm", "kernel": f"k_mvq_t1<{args.dtype}> (quantised single-token projection)", "achieved": ach,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                  "launches": p["launches"], "avg_launch_us": p["kernel_ms"] * 1e3 / p["launches"],
+                                  "avg_bytes_per_launch": p["bytes"] / p["launches"]}
+        model.free()
+        if args.cpu_seconds > 0:
+            result["cpu_baseline"] = cpu_baseline(path, first, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,11 @@ RWKV_API bool rwkv_mi_eval_resident(struct rwkv_context * ctx, const uint32_t * 
  * time of the whole loop measured on the context's stream. */
 RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, uint32_t * tokens_out, float * elapsed_ms);
 
+/* Measurement aid: eager greedy decode with a HIP-event pair (on the context's stream) around every launch of the dominant
+ * kernel -- the single-token projection of the model's quantised format. out[0] = summed kernel ms, out[1] = launches,
+ * out[2] = summed algorithmic bytes (weight rows + quantised activation + outputs), out[3] = wall ms of the loop. */
+RWKV_API bool rwkv_mi_profile_decode(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, double * out);
+
 /* Algorithmic HBM bytes one decoded token must move on this context's layers: every parameter once (file dtype), one
  * embedding row, state read + write, logits write. */
 RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx);

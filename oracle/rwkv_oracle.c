@@ -13,7 +13,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -433,9 +435,11 @@ orc_model * orc_load(const char * path) {
     if (fstat(fileno(f), &st) != 0) { fclose(f); return NULL; }
     orc_model * m = (orc_model *) calloc(1, sizeof *m);
     m->blob_size = (size_t) st.st_size;
-    m->blob = (uint8_t *) malloc(m->blob_size);
-    if (!m->blob || fread(m->blob, 1, m->blob_size, f) != m->blob_size) { fclose(f); orc_free(m); return NULL; }
+    /* map the file: multi-GB benchmark models are read straight from the page cache */
+    void * map = mmap(NULL, m->blob_size, PROT_READ, MAP_PRIVATE, fileno(f), 0);
     fclose(f);
+    if (map == MAP_FAILED) { free(m); return NULL; }
+    m->blob = (uint8_t *) map;
     const uint8_t * p = m->blob, * end = m->blob + m->blob_size;
     if (m->blob_size < 24 || rd32(p) != 0x67676d66u) { fprintf(stderr, "oracle: bad magic\n"); orc_free(m); return NULL; }
     m->version = rd32(p + 4); m->n_vocab = rd32(p + 8); m->n_embed = rd32(p + 12); m->n_layer = rd32(p + 16); m->data_type = rd32(p + 20);
@@ -529,7 +533,8 @@ orc_model * orc_load(const char * path) {
 
 void orc_free(orc_model * m) {
     if (!m) return;
-    free(m->blob); free(m->tensors); free(m->layers); free(m->scratch); free(m);
+    if (m->blob) munmap(m->blob, m->blob_size);
+    free(m->tensors); free(m->layers); free(m->scratch); free(m);
 }
 
 void orc_info(const orc_model * m, int64_t * info) {

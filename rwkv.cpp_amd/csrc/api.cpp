@@ -258,6 +258,39 @@ RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_to
     return true;
 }
 
+// Eager (graph-free) greedy decode with a HIP-event pair around every launch of the dominant kernel.
+// out[0] = summed kernel time (ms), out[1] = launches, out[2] = summed algorithmic bytes, out[3] = wall ms of the loop.
+RWKV_API bool rwkv_mi_profile_decode(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, double * out) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    const size_t n_vocab = (size_t) ctx->model->n_vocab();
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, first_token < n_vocab && n_tokens > 0 && out, "bad arguments");
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    if (!upload_tokens(ctx, &first_token, 1)) return false;
+    auto & pf = ctx->prof;
+    pf.total_ms = 0.0; pf.launches = 0; pf.total_bytes = 0;
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_CTX_OK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (size_t i = 0; i < n_tokens; i++) {
+        pf.on = true; pf.used = 0;
+        const bool ok = forward(ctx, 1, true);
+        pf.on = false;
+        if (!ok) return false;
+        launch_argmax(ctx->d_logits, (int64_t) n_vocab, ctx->d_tokens, ctx->stream);
+        HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t k = 0; k < pf.used; k++) {
+            float ms = 0.0f;
+            HIP_CTX_OK(ctx, hipEventElapsedTime(&ms, pf.events[2 * k], pf.events[2 * k + 1]));
+            pf.total_ms += ms; pf.launches++; pf.total_bytes += pf.bytes[k];
+        }
+    }
+    HIP_CTX_OK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    float wall = 0.0f;
+    HIP_CTX_OK(ctx, hipEventElapsedTime(&wall, ctx->ev0, ctx->ev1));
+    out[0] = pf.total_ms; out[1] = (double) pf.launches; out[2] = (double) pf.total_bytes; out[3] = wall;
+    return true;
+}
+
 RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx) { return ctx->model->bytes_per_token; }
 RWKV_API uint64_t rwkv_mi_weight_bytes(const struct rwkv_context * ctx) { return ctx->model->weight_bytes; }
 
@@ -275,7 +308,7 @@ RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled)
 RWKV_API bool rwkv_mi_test_mul_mat(int type, const void * w, int64_t K, int64_t N, const float * x, int64_t T, float * y) {
     g_last_error = RWKV_ERROR_NONE;
     RW_CHECK(RWKV_ERROR_ARGS, false, dtype_supported(type) && w && x && y && K > 0 && N > 0 && T > 0, "bad arguments");
-    RW_CHECK(RWKV_ERROR_ARGS, false, K % (dtype_quantized(type) ? 32 : 8) == 0, "K must be a multiple of 32 (quantised) or 8");
+    RW_CHECK(RWKV_ERROR_ARGS, false, K % 32 == 0, "K must be a multiple of 32");
     const uint64_t wbytes = tensor_nbytes(type, K, N, 1);
     const int64_t nblk = K * N / 32;
     void *d_raw = nullptr, *d_x = nullptr, *d_y = nullptr, *d_q = nullptr, *d_planes = nullptr;

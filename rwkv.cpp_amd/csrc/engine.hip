@@ -66,6 +66,7 @@ void destroy_context(rwkv_context * ctx) {
     if (ctx->h_tokens) (void) hipHostFree(ctx->h_tokens);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->prof.events) (void) hipEventDestroy(e);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     release_model(ctx->model);
     delete ctx;
@@ -140,7 +141,20 @@ struct Runner {
         const int64_t N = W->rows(), K = W->cols();
         if (dtype_quantized(W->type)) {
             launch_quantize_act(x, T, K, b.qa, st);
+            auto & pf = ctx->prof;
+            const bool timed = pf.on && T == 1 && W->type == (int) m.header.data_type;
+            if (timed) {
+                if (pf.used * 2 + 2 > pf.events.size()) {
+                    hipEvent_t a = nullptr, c = nullptr;
+                    (void) hipEventCreate(&a); (void) hipEventCreate(&c);
+                    pf.events.push_back(a); pf.events.push_back(c); pf.bytes.push_back(0);
+                }
+                // algorithmic bytes of this launch: the weight rows once + the quantised activation + the outputs
+                pf.bytes[pf.used] = W->nbytes + (uint64_t) K + (uint64_t)(K / 32) * 12 + (uint64_t) N * 4;
+                (void) hipEventRecord(pf.events[pf.used * 2], st);
+            }
             launch_matvec_q(*W, b.qa, T, y, N, epi, st);
+            if (timed) { (void) hipEventRecord(pf.events[pf.used * 2 + 1], st); pf.used++; }
         } else {
             launch_matvec_f(*W, x, K, T, y, N, epi, st);
         }

@@ -280,138 +280,94 @@ void launch_matvec_q(const DevTensor & W, const QAct & x, int64_t T, float * y, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Projection, F32 / F16 weights. Lane l owns 16-byte chunks l, l+64, ... of a row (4 f32 or 8 f16 weights each) and
-// accumulates them with fma in element order; same butterfly; same order in the token-tiled variant.
+// Projection, F32 / F16 weights.
+// The f32 accumulation order is the one of ggml's AVX2 ggml_vec_dot_f32 / ggml_vec_dot_f16 (and of the CPU oracle):
+// 32 partial sums, partial p accumulating k = p, p+32, p+64, ... with fma; then ps[i] += ps[i+16], ps[i] += ps[i+8],
+// ps[i] += ps[i+4], result (ps0+ps1)+(ps2+ps3). With fp16-rounded activations (what ggml feeds an F16 matrix) the
+// logits are sensitive to this order at the level the reference's FP16 thresholds test, so it is pinned, not chosen
+// for speed: 4 lanes own one row (lane q keeps partials 8q..8q+7 = one 16/32-byte chunk per 32-element step), 16 rows
+// per wave. Activations for the current K tile are staged (and fp16-rounded) once per workgroup in LDS.
+// The same kernel serves T = 1 and token tiles, so sequence mode is bit-identical to serial mode.
 // ---------------------------------------------------------------------------------------------------------------
 
-template <bool F16> struct FChunk { static constexpr int E = F16 ? 8 : 4; };
-
-template <bool F16>
-__device__ __forceinline__ void load_fchunk(float (&w)[FChunk<F16>::E], const void * __restrict__ base, int64_t chunk) {
-    const int4 raw = reinterpret_cast<const int4 *>(base)[chunk];
-    if constexpr (F16) {
-        const unsigned u[4] = {(unsigned) raw.x, (unsigned) raw.y, (unsigned) raw.z, (unsigned) raw.w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            w[2 * i] = h2f_bits((uint16_t)(u[i] & 0xFFFFu));
-            w[2 * i + 1] = h2f_bits((uint16_t)(u[i] >> 16));
-        }
-    } else {
-        w[0] = __int_as_float(raw.x); w[1] = __int_as_float(raw.y); w[2] = __int_as_float(raw.z); w[3] = __int_as_float(raw.w);
-    }
-}
-
-template <bool F16, int R>
-__global__ __launch_bounds__(256) void k_mvf_t1(const void * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x,
-                                                float * __restrict__ y, Epi epi) {
-    constexpr int E = FChunk<F16>::E;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = ((int64_t) blockIdx.x * 4 + wave) * R;
-    if (row0 >= N) return;
-    const int64_t nch = K / E;
-    float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = 0.0f;
-    for (int64_t c = lane; c < nch; c += WAVE) {
-        float xv[E];
-#pragma unroll
-        for (int i = 0; i < E; i += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + c * E + i);
-            xv[i] = v.x; xv[i + 1] = v.y; xv[i + 2] = v.z; xv[i + 3] = v.w;
-        }
-        if constexpr (F16) {
-#pragma unroll
-            for (int i = 0; i < E; i++) xv[i] = round_f16(xv[i]);
-        }
-        float w[R][E];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
-            load_fchunk<F16>(w[r], W, row * nch + c);
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int i = 0; i < E; i++) acc[r] = fmaf(w[r][i], xv[i], acc[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const float v = wave_sum_f(acc[r]);
-        if (lane == 0 && row0 + r < N) y[row0 + r] = apply_epi(epi, v, 0, row0 + r, 0);
-    }
-}
-
-template <bool F16, int R, int TT>
-__global__ __launch_bounds__(256) void k_mvf_tn(const void * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x, int64_t ldx,
-                                                int64_t T, float * __restrict__ y, int64_t ldy, Epi epi) {
-    constexpr int E = FChunk<F16>::E;
-    constexpr int Q = E / 4;  // float4's per chunk
-    __shared__ __attribute__((aligned(16))) float l_x[TT * 64 * E];  // [tt][q][lane][4]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = ((int64_t) blockIdx.x * 4 + wave) * R;
+template <bool F16, int TT>
+__global__ __launch_bounds__(256) void k_mvf(const void * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x, int64_t ldx,
+                                             int64_t T, float * __restrict__ y, int64_t ldy, Epi epi) {
+    constexpr int KT = 2048;
+    __shared__ __attribute__((aligned(16))) float l_x[TT * KT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 3, rloc = lane >> 2;
+    const int64_t row = ((int64_t) blockIdx.x * 4 + wave) * 16 + rloc;
+    const int64_t rowc = row < N ? row : N - 1;
     const int64_t t0 = (int64_t) blockIdx.y * TT;
-    const int64_t nch = K / E;
-    float acc[R][TT];
+    float acc[TT][8];
 #pragma unroll
-    for (int r = 0; r < R; r++)
+    for (int tt = 0; tt < TT; tt++)
 #pragma unroll
-        for (int tt = 0; tt < TT; tt++) acc[r][tt] = 0.0f;
+        for (int e = 0; e < 8; e++) acc[tt][e] = 0.0f;
 
-    for (int64_t c0 = 0; c0 < nch; c0 += 64) {
+    for (int64_t k0 = 0; k0 < K; k0 += KT) {
+        const int kt = (int) ((K - k0) < KT ? (K - k0) : KT);
         __syncthreads();
-        for (int c = threadIdx.x; c < TT * 64 * Q; c += 256) {
-            const int tt = c / (64 * Q), rem = c % (64 * Q), ch = rem / Q, q = rem % Q;
+        for (int i = threadIdx.x; i < TT * (kt / 4); i += 256) {
+            const int tt = i / (kt / 4), c = i % (kt / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t0 + tt < T && c0 + ch < nch) v = *reinterpret_cast<const float4 *>(x + (t0 + tt) * ldx + (c0 + ch) * E + q * 4);
+            if (t0 + tt < T) v = *reinterpret_cast<const float4 *>(x + (t0 + tt) * ldx + k0 + 4 * c);
             if constexpr (F16) { v.x = round_f16(v.x); v.y = round_f16(v.y); v.z = round_f16(v.z); v.w = round_f16(v.w); }
-            *reinterpret_cast<float4 *>(l_x + ((tt * Q + q) * 64 + ch) * 4) = v;
+            *reinterpret_cast<float4 *>(l_x + tt * KT + 4 * c) = v;
         }
         __syncthreads();
-        const int64_t c = c0 + lane;
-        if (c < nch && row0 < N) {
-            float w[R][E];
+        const int steps = kt / 32;
+#pragma unroll 4
+        for (int s = 0; s < steps; s++) {
+            float w[8];
+            const int64_t e0 = rowc * K + k0 + 32 * s + 8 * q;
+            if constexpr (F16) {
+                const int4 raw = *reinterpret_cast<const int4 *>(reinterpret_cast<const uint16_t *>(W) + e0);
+                const unsigned u[4] = {(unsigned) raw.x, (unsigned) raw.y, (unsigned) raw.z, (unsigned) raw.w};
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
-                load_fchunk<F16>(w[r], W, row * nch + c);
+                for (int i = 0; i < 4; i++) { w[2 * i] = h2f_bits((uint16_t)(u[i] & 0xFFFFu)); w[2 * i + 1] = h2f_bits((uint16_t)(u[i] >> 16)); }
+            } else {
+                const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(W) + e0);
+                const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(W) + e0 + 4);
+                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
             }
 #pragma unroll
             for (int tt = 0; tt < TT; tt++) {
-                float xv[E];
-#pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    const float4 v = *reinterpret_cast<const float4 *>(l_x + ((tt * Q + q) * 64 + lane) * 4);
-                    xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
-                }
-#pragma unroll
-                for (int r = 0; r < R; r++)
-#pragma unroll
-                    for (int i = 0; i < E; i++) acc[r][tt] = fmaf(w[r][i], xv[i], acc[r][tt]);
+                const float4 xa = *reinterpret_cast<const float4 *>(l_x + tt * KT + 32 * s + 8 * q);
+                const float4 xb = *reinterpret_cast<const float4 *>(l_x + tt * KT + 32 * s + 8 * q + 4);
+                acc[tt][0] = fmaf(w[0], xa.x, acc[tt][0]); acc[tt][1] = fmaf(w[1], xa.y, acc[tt][1]);
+                acc[tt][2] = fmaf(w[2], xa.z, acc[tt][2]); acc[tt][3] = fmaf(w[3], xa.w, acc[tt][3]);
+                acc[tt][4] = fmaf(w[4], xb.x, acc[tt][4]); acc[tt][5] = fmaf(w[5], xb.y, acc[tt][5]);
+                acc[tt][6] = fmaf(w[6], xb.z, acc[tt][6]); acc[tt][7] = fmaf(w[7], xb.w, acc[tt][7]);
             }
         }
     }
-    if (row0 >= N) return;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
+    for (int tt = 0; tt < TT; tt++) {
+        float ps[8];
 #pragma unroll
-        for (int tt = 0; tt < TT; tt++) {
-            const float v = wave_sum_f(acc[r][tt]);
-            if (lane == 0 && row0 + r < N && t0 + tt < T) y[(t0 + tt) * ldy + row0 + r] = apply_epi(epi, v, t0 + tt, row0 + r, ldy);
+        for (int e = 0; e < 8; e++) {
+            float v = acc[tt][e];
+            v += __shfl_xor(v, 2, WAVE);  // ps[i] += ps[i + 16]
+            v += __shfl_xor(v, 1, WAVE);  // ps[i] += ps[i + 8]
+            ps[e] = v;
         }
+#pragma unroll
+        for (int e = 0; e < 4; e++) ps[e] += ps[e + 4];
+        const float r = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        if (q == 0 && row < N && t0 + tt < T) y[(t0 + tt) * ldy + row] = apply_epi(epi, r, t0 + tt, row, ldy);
     }
 }
 
 template <bool F16>
 static void launch_mvf_t(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
     const int64_t N = W.rows(), K = W.cols();
+    const unsigned gx = (unsigned)((N + 63) / 64);
     if (T == 1) {
-        constexpr int R = 4;
-        const dim3 grid((unsigned)((N + 4 * R - 1) / (4 * R)));
-        hipLaunchKernelGGL((k_mvf_t1<F16, R>), grid, dim3(256), 0, st, W.data, N, K, x, y, epi);
+        hipLaunchKernelGGL((k_mvf<F16, 1>), dim3(gx), dim3(256), 0, st, W.data, N, K, x, ldx, T, y, ldy, epi);
     } else {
-        constexpr int R = 4, TT = 4;
-        const dim3 grid((unsigned)((N + 4 * R - 1) / (4 * R)), (unsigned)((T + TT - 1) / TT));
-        hipLaunchKernelGGL((k_mvf_tn<F16, R, TT>), grid, dim3(256), 0, st, W.data, N, K, x, ldx, T, y, ldy, epi);
+        constexpr int TT = 4;
+        hipLaunchKernelGGL((k_mvf<F16, TT>), dim3(gx, (unsigned)((T + TT - 1) / TT)), dim3(256), 0, st, W.data, N, K, x, ldx, T, y, ldy, epi);
     }
 }
 

@@ -107,6 +107,17 @@ struct rwkv_context {
     bool use_graph = true;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // Live per-launch timing of the dominant kernel (the quantised single-token projection) with HIP events on this
+    // context's stream; filled by rwkv_mi_profile_decode, used by bench.py's roofline figure.
+    struct Prof {
+        bool on = false;
+        std::vector<hipEvent_t> events;  // pairs
+        std::vector<uint64_t> bytes;     // per pair
+        size_t used = 0;
+        double total_ms = 0.0;
+        uint64_t launches = 0, total_bytes = 0;
+    } prof;
 };
 
 namespace rwkvmi {

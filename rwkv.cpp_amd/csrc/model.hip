@@ -140,7 +140,7 @@ static bool validate_shapes(Model & m) {
     };
     auto mat = [&](const DevTensor * t, int64_t K, int64_t N, const char * what) {
         if (!t) return;
-        const bool kdiv = dtype_quantized(t->type) ? (t->ne[0] % 32 == 0) : (t->type == T_F16 ? t->ne[0] % 8 == 0 : t->ne[0] % 4 == 0);
+        const bool kdiv = t->ne[0] % 32 == 0;  // 32-element steps in every projection kernel
         if ((K > 0 && t->ne[0] != K) || (N > 0 && t->ne[1] * t->ne[2] != N) || !kdiv) {
             global_fail(RWKV_ERROR_MODEL_PARAMS | RWKV_ERROR_DIMENSION, __FILE__, __LINE__, "matrix parameter has the expected shape",
                         "Parameter %s (%s) has unexpected shape [%" PRId64 ", %" PRId64 ", %" PRId64 "]", t->name.c_str(), what, t->ne[0], t->ne[1], t->ne[2]);

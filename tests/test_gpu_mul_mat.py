@@ -31,7 +31,10 @@ def test_single_token_matches_oracle(fmt, K, N):
     y = gpu_mul_mat(t, wb, K, N, x)[0]
     ref = O.mul_mat(t, wb, K, N, x)[0]
     scale = float(np.abs(ref).max()) + 1e-6
-    # identical integer block dots and f32 products; only the f32 summation order over blocks differs
+    if fmt in ("FP32", "FP16"):
+        # same 32-partial-sum order as the oracle (ggml's AVX2 dot): bit-identical
+        assert np.array_equal(y, ref), (fmt, K, N, float(np.abs(y - ref).max()))
+    # quantised: identical integer block dots and f32 products; only the f32 summation order over blocks differs
     assert float(np.abs(y - ref).max()) <= 2e-5 * scale * np.sqrt(K / 64), (fmt, K, N)
 
 
