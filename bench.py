@@ -53,12 +53,24 @@ def ensure_model_file(args, synth, rank, barrier):
     return path, spec
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask and cgroup CPU quota, capped (the port is memory-bound)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(path, first_token, budget_s):
     """Times the CPU oracle (oracle/rwkv_oracle.c: ggml's CPU algorithm restated, OpenMP) on the same file and the same
     greedy decode. Bounded sample; reported, never the target."""
     import numpy as np
     import oracle_lib
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     oracle_lib.lib().orc_set_threads(cores)
     t0 = time.time()
     om = oracle_lib.OracleModel(path)

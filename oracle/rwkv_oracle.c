@@ -14,7 +14,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <unistd.h>
 
 #ifdef _OPENMP
@@ -100,6 +102,62 @@ static inline float f16_to_f32_sw(uint16_t h) {
     float f; memcpy(&f, &x, 4);
     return f;
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Deterministic arithmetic (DESIGN.md "Numerics"). The reference calls the platform's expf / tanhf and leaves */
+/* fma contraction and reduction order to the compiler, so its float results are only reproducible on one      */
+/* platform; several of its recorded thresholds sit on single rounding ties (a 1-ulp change upstream flips one  */
+/* int8 activation code and moves the 5v1 Q8_0 sum from +0.585 to +1.351). Oracle and GPU kernels therefore     */
+/* implement ONE spelled-out arithmetic: every fused multiply-add is an explicit fmaf (both sides are compiled  */
+/* with -ffp-contract=off), reductions use fixed trees, and exp/tanh are the double-precision routines below          */
+/* (correctly rounded to float but for ~1e-8 of arguments). GPU == oracle bit for bit follows.                  */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* exp in double (argument reduction by ln2 hi/lo, degree-13 Taylor polynomial, fma Horner), rounded once to float: the
+ * float result is the correctly rounded expf(x) except for a ~1e-8 fraction of arguments, i.e. it agrees with a good
+ * libm while being reproducible bit for bit on CPU and GPU (only IEEE double fma / mul / add / rint / ldexp). */
+static inline double det_exp_d(double x) {
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;          /* 1/13! */
+    p = fma(p, r, 2.08767569878681e-09);        /* 1/12! */
+    p = fma(p, r, 2.505210838544172e-08);       /* 1/11! */
+    p = fma(p, r, 2.755731922398589e-07);       /* 1/10! */
+    p = fma(p, r, 2.7557319223985893e-06);      /* 1/9!  */
+    p = fma(p, r, 2.48015873015873e-05);        /* 1/8!  */
+    p = fma(p, r, 1.984126984126984e-04);       /* 1/7!  */
+    p = fma(p, r, 1.388888888888889e-03);       /* 1/6!  */
+    p = fma(p, r, 8.333333333333333e-03);       /* 1/5!  */
+    p = fma(p, r, 4.1666666666666664e-02);      /* 1/4!  */
+    p = fma(p, r, 1.6666666666666666e-01);      /* 1/3!  */
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int) n);
+}
+
+static inline float det_expf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return INFINITY;
+    if (x < -103.97208404541016f) return 0.0f;
+    return (float) det_exp_d((double) x);
+}
+
+static inline float det_tanhf(float x) {
+    if (x != x) return x;
+    const double xd = (double) x;
+    const double ax = fabs(xd);
+    if (ax < 1e-4) return (float) (xd * fma(xd * xd, -1.0 / 3.0, 1.0));
+    if (ax > 20.0) return x > 0.0f ? 1.0f : -1.0f;
+    const double s = det_exp_d(ax + ax);
+    const double t = 1.0 - 2.0 / (s + 1.0);
+    return (float) (x > 0.0f ? t : -t);
+}
+
+/* halving-tree folds: for o = n/2 .. 1: p[i] += p[i + o] */
+static inline double fold_d(double * p, int n) { for (int o = n / 2; o > 0; o >>= 1) for (int i = 0; i < o; i++) p[i] += p[i + o]; return p[0]; }
+static inline float  fold_f(float * p, int n)  { for (int o = n / 2; o > 0; o >>= 1) for (int i = 0; i < o; i++) p[i] += p[i + o]; return p[0]; }
 
 /* ------------------------------------------------------------------------------------------------ */
 /* Block formats (ggml block_q4_0 / q4_1 / q5_0 / q5_1 / q8_0), 32 elements per block  */
@@ -308,7 +366,8 @@ static inline float dot32_finish(float * ps) {
  *   F16 W: activations are rounded to fp16 first (ggml converts src1 to the weight's vec_dot_type), products and
  *          accumulation in f32.  This is what reproduces the reference's recorded 7v0 FP16->Qx sums to 6 digits
  *          (tests/test_tiny_rwkv.c:128-133); see DESIGN.md "F16 weights".
- *   Q4_0/Q5_0/Q8_0: x -> Q8_0; y = sum_b (d_w*d_x) * isum.   Q4_1/Q5_1: x -> Q8_1; + m_w * s_x. */
+ *   Q4_0/Q5_0/Q8_0: x -> Q8_0; y = sum_b (d_w*d_x) * isum.   Q4_1/Q5_1: x -> Q8_1; + m_w * s_x.
+ *   f32 accumulation over blocks: 64 interleaved partial sums + halving tree (DESIGN.md "Numerics"). */
 void orc_mul_mat(int wtype, const void * Wv, int64_t K, int64_t N, const float * x, int64_t T, float * y) {
     const uint8_t * W = (const uint8_t *) Wv;
     if (wtype == ORC_F32 || wtype == ORC_F16) {
@@ -345,7 +404,8 @@ void orc_mul_mat(int wtype, const void * Wv, int64_t K, int64_t N, const float *
         #pragma omp parallel for schedule(static) if (N * K > 65536)
         for (int64_t n = 0; n < N; n++) {
             const uint8_t * row = W + (size_t) n * nb * ts;
-            float acc = 0.0f;
+            float lanes[64];
+            for (int i = 0; i < 64; i++) lanes[i] = 0.0f;
             for (int64_t b = 0; b < nb; b++) {
                 const uint8_t * blk = row + b * ts;
                 const int8_t * qx = q + b * QK;
@@ -368,10 +428,13 @@ void orc_mul_mat(int wtype, const void * Wv, int64_t K, int64_t N, const float *
                     for (int j = 0; j < 32; j++) isum += qw[j] * qx[j];
                     break; }
                 }
-                acc += (d * dq[b]) * (float) isum;
-                if (has_m) acc += m * sq[b];
+                /* 64 partial sums (block b -> partial b mod 64, increasing b), fma per block, halving-tree fold */
+                float a = lanes[b & 63];
+                a = fmaf(d * dq[b], (float) isum, a);
+                if (has_m) a = fmaf(m, sq[b], a);
+                lanes[b & 63] = a;
             }
-            y[t * N + n] = acc;
+            y[t * N + n] = fold_f(lanes, 64);
         }
     }
     free(q); free(dq);
@@ -572,27 +635,30 @@ void orc_init_state(const orc_model * m, float * state) {
 
 static const float * f32data(const orc_tensor * t) { return (const float *) t->data; }
 
-/* ggml_norm: mean and sum of squared deviations accumulated in double, scale = 1/sqrtf(var + eps). */
-static void norm_row(const float * x, float * y, int64_t n, float eps) {
-    double sum = 0.0;
-    for (int64_t i = 0; i < n; i++) sum += (double) x[i];
-    const float mean = (float)(sum / (double) n);
-    double sum2 = 0.0;
-    for (int64_t i = 0; i < n; i++) { const float v = x[i] - mean; y[i] = v; sum2 += (double)(v * v); }
-    const float variance = (float)(sum2 / (double) n);
+/* ggml_norm: mean and sum of squared deviations accumulated in double, scale = 1/sqrtf(var + eps).
+ * Reduction order: NP partial sums (element i goes to partial i mod NP), folded by a halving tree. NP = 256 for a
+ * LayerNorm row (one partial per thread of the GPU workgroup), 64 for a per-head GroupNorm row (one per lane). */
+static void norm_row(const float * x, float * y, int64_t n, int np, float eps) {
+    double ps[256];
+    for (int i = 0; i < np; i++) ps[i] = 0.0;
+    for (int64_t i = 0; i < n; i++) ps[i % np] += (double) x[i];
+    const float mean = (float)(fold_d(ps, np) / (double) n);
+    for (int i = 0; i < np; i++) ps[i] = 0.0;
+    for (int64_t i = 0; i < n; i++) { const float v = x[i] - mean; y[i] = v; ps[i % np] += (double)(v * v); }
+    const float variance = (float)(fold_d(ps, np) / (double) n);
     const float scale = 1.0f / sqrtf(variance + eps);
     for (int64_t i = 0; i < n; i++) y[i] *= scale;
 }
 
-/* rwkv_operators.inc:93-97: norm(1e-5) * w + b */
+/* rwkv_operators.inc:93-97: norm(1e-5) * w + b -- three graph ops, three roundings (norm, mul, add) */
 static void layer_norm(const float * x, const orc_tensor * w, const orc_tensor * b, float * y, int64_t n) {
-    norm_row(x, y, n, 1e-5f);
+    norm_row(x, y, n, 256, 1e-5f);
     const float * wd = f32data(w), * bd = f32data(b);
     for (int64_t i = 0; i < n; i++) y[i] = y[i] * wd[i] + bd[i];
 }
 
-static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-static inline float siluf_(float x) { return x / (1.0f + expf(-x)); }
+static inline float sigmoidf_(float x) { return 1.0f / (1.0f + det_expf(-x)); }
+static inline float siluf_(float x) { return x / (1.0f + det_expf(-x)); }
 
 static void mm(const orc_tensor * W, const float * x, float * y) {
     orc_mul_mat(W->type, W->data, W->ne[0], W->ne[1], x, 1, y);
@@ -631,7 +697,7 @@ static void wkv6_token(float * state, const float * r, const float * k, const fl
 static void group_norm(float * x, const orc_tensor * w, const orc_tensor * b, int64_t H, int64_t S, float eps) {
     const float * wd = f32data(w), * bd = f32data(b);
     for (int64_t h = 0; h < H; h++) {
-        norm_row(x + h * S, x + h * S, S, eps);
+        norm_row(x + h * S, x + h * S, S, 64, eps);
         for (int64_t j = 0; j < S; j++) x[h * S + j] = x[h * S + j] * wd[h * S + j] + bd[h * S + j];
     }
 }
@@ -681,12 +747,12 @@ static void att_v4(orc_model * m, const orc_layer * L, orc_work * wk, float * st
         const float k = wk->k[i], v = wk->v[i];
         float ww = tf[i] + k;
         float qq = fmaxf(pp[i], ww);
-        float e1 = expf(pp[i] - qq), e2 = expf(ww - qq);
+        float e1 = det_expf(pp[i] - qq), e2 = det_expf(ww - qq);
         const float a = e1 * aa[i] + e2 * v;
         const float b = e1 * bb[i] + e2;
         ww = pp[i] + td[i];
         qq = fmaxf(ww, k);
-        e1 = expf(ww - qq); e2 = expf(k - qq);
+        e1 = det_expf(ww - qq); e2 = det_expf(k - qq);
         aa[i] = e1 * aa[i] + e2 * v;
         bb[i] = e1 * bb[i] + e2;
         pp[i] = qq;
@@ -729,7 +795,7 @@ static void att_v6(orc_model * m, const orc_layer * L, orc_work * wk, float * st
     memcpy(att_xx, wk->xn, (size_t) D * 4);
     const int64_t R5 = L->maa_w1->ne[1], R = R5 / 5;
     mm(L->maa_w1, wk->xa, wk->tmp);
-    for (int64_t i = 0; i < R5; i++) wk->tmp[i] = tanhf(wk->tmp[i]);
+    for (int64_t i = 0; i < R5; i++) wk->tmp[i] = det_tanhf(wk->tmp[i]);
     /* batched W2: time_maa_w2 ne = (R, D, 5), F32 x F32 (:326-334); slice order w,k,v,r,g (:336-340) */
     const float * w2 = f32data(L->maa_w2);
     const float * maa[5] = { f32data(L->maa_w), f32data(L->maa_k), f32data(L->maa_v), f32data(L->maa_r), f32data(L->maa_g) };
@@ -749,10 +815,10 @@ static void att_v6(orc_model * m, const orc_layer * L, orc_work * wk, float * st
     for (int64_t i = 0; i < D; i++) wk->g[i] = siluf_(wk->g[i]);
     const int64_t DR = L->decay_w1->ne[1];
     mm(L->decay_w1, wk->xw, wk->tmp);
-    for (int64_t i = 0; i < DR; i++) wk->tmp[i] = tanhf(wk->tmp[i]);
+    for (int64_t i = 0; i < DR; i++) wk->tmp[i] = det_tanhf(wk->tmp[i]);
     mm(L->decay_w2, wk->tmp, wk->w);
     const float * td = f32data(L->att_time_decay);
-    for (int64_t i = 0; i < D; i++) wk->w[i] = expf(-expf(wk->w[i] + td[i]));
+    for (int64_t i = 0; i < D; i++) wk->w[i] = det_expf(-det_expf(wk->w[i] + td[i]));
     wkv6_token(heads, wk->r, wk->k, wk->v, f32data(L->att_time_faaaa), 1, wk->w, 1, wk->tmp2, H, S);
     group_norm(wk->tmp2, L->att_ln_x_w, L->att_ln_x_b, H, S, 64e-5f);
     for (int64_t i = 0; i < D; i++) wk->tmp2[i] *= wk->g[i];
@@ -805,16 +871,17 @@ static void att_v7(orc_model * m, const orc_layer * L, orc_work * wk, float * st
     { const float * a0 = f32data(L->a0); for (int64_t i = 0; i < D; i++) wk->a[i] = sigmoidf_(wk->a[i] + a0[i]); }
     /* w = exp(-0.606531 * sigmoid(W2 * tanh(W1 * xw) + w0)) (:425-430) */
     mm(L->w1, wk->xw, wk->tmp);
-    for (int64_t i = 0; i < L->w1->ne[1]; i++) wk->tmp[i] = tanhf(wk->tmp[i]);
+    for (int64_t i = 0; i < L->w1->ne[1]; i++) wk->tmp[i] = det_tanhf(wk->tmp[i]);
     mm(L->w2, wk->tmp, wk->w);
-    { const float * w0 = f32data(L->w0); for (int64_t i = 0; i < D; i++) wk->w[i] = expf(sigmoidf_(wk->w[i] + w0[i]) * -0.606531f); }
+    { const float * w0 = f32data(L->w0); for (int64_t i = 0; i < D; i++) wk->w[i] = det_expf(sigmoidf_(wk->w[i] + w0[i]) * -0.606531f); }
     /* k, kk = l2norm_head(k * k_k), k += a*ka - ka (:432-437); l2norm: rwkv_operators.inc:40-82 */
     mm(L->att_key, wk->xk, wk->k);
     const float * k_k = f32data(L->k_k), * k_a = f32data(L->k_a);
     for (int64_t h = 0; h < H; h++) {
-        float sum = 0.0f;
-        for (int64_t j = 0; j < S; j++) { const float t = wk->k[h * S + j] * k_k[h * S + j]; wk->kk[h * S + j] = t; sum += t * t; }
-        const float scale = 1.0f / fmaxf(sqrtf(sum), 1e-12f);
+        float ps[64];
+        for (int i = 0; i < 64; i++) ps[i] = 0.0f;
+        for (int64_t j = 0; j < S; j++) { const float t = wk->k[h * S + j] * k_k[h * S + j]; wk->kk[h * S + j] = t; ps[j & 63] += t * t; }
+        const float scale = 1.0f / fmaxf(sqrtf(fold_f(ps, 64)), 1e-12f);
         for (int64_t j = 0; j < S; j++) wk->kk[h * S + j] *= scale;
     }
     for (int64_t i = 0; i < D; i++) { const float ka = wk->k[i] * k_a[i]; wk->k[i] = wk->k[i] + (wk->a[i] * ka - ka); }
@@ -835,8 +902,10 @@ static void att_v7(orc_model * m, const orc_layer * L, orc_work * wk, float * st
     /* + v * sum_head(k * r * r_k) (:472-477) */
     const float * r_k = f32data(L->r_k);
     for (int64_t h = 0; h < H; h++) {
-        float sum = 0.0f;
-        for (int64_t j = 0; j < S; j++) sum += (wk->k[h * S + j] * wk->r[h * S + j]) * r_k[h * S + j];
+        float ps[64];
+        for (int i = 0; i < 64; i++) ps[i] = 0.0f;
+        for (int64_t j = 0; j < S; j++) ps[j & 63] += (wk->k[h * S + j] * wk->r[h * S + j]) * r_k[h * S + j];
+        const float sum = fold_f(ps, 64);
         for (int64_t j = 0; j < S; j++) wk->out[h * S + j] += wk->v[h * S + j] * sum;
     }
     for (int64_t i = 0; i < D; i++) wk->out[i] *= wk->g[i];

@@ -9,7 +9,12 @@
 //    the SAME order, so rwkv_eval_sequence is bit-identical to repeated rwkv_eval (reference test
 //    tests/test_eval_sequence_in_chunks.c:54 checks this with memcmp).
 //  * F16 weights: activations are rounded to fp16 first (what ggml does), products/accumulation in f32.
-//  * Norm statistics are accumulated in double (ggml_norm).
+//  * Norm statistics are accumulated in double (ggml_norm), with a fixed reduction tree.
+//  * Everything outside the dot products is ONE ROUNDING PER ggml GRAPH OP (the reference evaluates mul, add, sub ...
+//    as separate graph nodes), so this file is compiled with -ffp-contract=off and fused multiply-adds appear only as
+//    explicit fmaf() inside dot products. exp / tanh are the deterministic double-precision routines below. Together
+//    with the fixed reduction orders this makes the GPU results bit-identical to the CPU oracle (oracle/rwkv_oracle.c),
+//    which the tests assert with array_equal.
 #include "kernels.h"
 
 #include <hip/hip_fp16.h>
@@ -32,24 +37,61 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp in double (ln2 hi/lo reduction, degree-13 Taylor, fma Horner), rounded once to float; same routine as the oracle's.
+__device__ __forceinline__ double det_exp_d(double x) {
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.388888888888889e-03);
+    p = fma(p, r, 8.333333333333333e-03);
+    p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int) n);
+}
+__device__ __forceinline__ float det_expf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return INFINITY;
+    if (x < -103.97208404541016f) return 0.0f;
+    return (float) det_exp_d((double) x);
+}
+__device__ __forceinline__ float det_tanhf(float x) {
+    if (x != x) return x;
+    const double xd = (double) x;
+    const double ax = fabs(xd);
+    if (ax < 1e-4) return (float) (xd * fma(xd * xd, -1.0 / 3.0, 1.0));
+    if (ax > 20.0) return x > 0.0f ? 1.0f : -1.0f;
+    const double sv = det_exp_d(ax + ax);
+    const double t = 1.0 - 2.0 / (sv + 1.0);
+    return (float) (x > 0.0f ? t : -t);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + det_expf(-x)); }
 __device__ __forceinline__ float h2f_bits(uint16_t h) { return __half2float(__ushort_as_half(h)); }
 __device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
 
-// block-wide sum of doubles for blocks of up to 1024 threads (multiple of 64); result broadcast to all threads
-__device__ __forceinline__ double block_sum_d(double v, double * red /* [17] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    v = wave_sum_d(v);
+// Sum of one double per thread over a 256-thread workgroup, as a halving tree over the 256 partials
+// (p[i] += p[i+128]; p[i] += p[i+64]; then the 64-entry butterfly): the order the oracle's fold_d(.., 256) uses.
+__device__ __forceinline__ double block_sum_d(double v, double * red /* [257] */) {
     __syncthreads();
-    if (lane == 0) red[wave] = v;
+    red[threadIdx.x] = v;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nw; i++) s += red[i];
-        red[16] = s;
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        double t = (red[i] + red[i + 128]) + (red[i + 64] + red[i + 192]);
+        t = wave_sum_d(t);
+        if (i == 0) red[256] = t;
     }
     __syncthreads();
-    return red[16];
+    return red[256];
 }
 
 __device__ __forceinline__ float apply_epi(const Epi & e, float acc, int64_t t, int64_t n, int64_t ldy) {
@@ -57,13 +99,13 @@ __device__ __forceinline__ float apply_epi(const Epi & e, float acc, int64_t t, 
         case EPI_NONE: return acc;
         case EPI_SIGMOID: return sigmoid_f(acc);
         case EPI_RELU_SQ: { const float r = acc > 0.0f ? acc : 0.0f; return r * r; }
-        case EPI_SILU: return acc / (1.0f + expf(-acc));
-        case EPI_TANH: return tanhf(acc);
+        case EPI_SILU: return acc / (1.0f + det_expf(-acc));
+        case EPI_TANH: return det_tanhf(acc);
         case EPI_ADD_RES: return e.res[t * ldy + n] + acc;
-        case EPI_SIGMUL_ADD_RES: return e.res[t * ldy + n] + sigmoid_f(e.aux[t * ldy + n]) * acc;
+        case EPI_SIGMUL_ADD_RES: { const float g = sigmoid_f(e.aux[t * ldy + n]) * acc; return e.res[t * ldy + n] + g; }
         case EPI_BIAS_SIGMOID: return sigmoid_f(acc + e.bias[n]);
-        case EPI_V6_DECAY: return expf(-expf(acc + e.bias[n]));
-        case EPI_V7_DECAY: return expf(sigmoid_f(acc + e.bias[n]) * -0.606531f);
+        case EPI_V6_DECAY: return det_expf(-det_expf(acc + e.bias[n]));
+        case EPI_V7_DECAY: return det_expf(sigmoid_f(acc + e.bias[n]) * -0.606531f);
         default: return acc;
     }
 }
@@ -450,23 +492,23 @@ __device__ __forceinline__ float emb_elem(const EmbView & e, int64_t row, int64_
     return (code - (e.type == T_Q4_0 ? 8 : 16)) * d;
 }
 
-// normalises the row held in l_row (D floats) in place: (x - mean) / sqrt(var + eps) * w + b, written to out
+// normalises the row held in l_row (D floats): ((x - mean) * scale) * w + b, one rounding per step, written to out
 __device__ __forceinline__ void block_layernorm(float * l_row, int64_t D, const float * __restrict__ w, const float * __restrict__ b,
                                                 float eps, float * __restrict__ out, double * red) {
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) s += (double) l_row[i];
+    for (int64_t i = threadIdx.x; i < D; i += 256) s += (double) l_row[i];
     const float mean = (float)(block_sum_d(s, red) / (double) D);
     double s2 = 0.0;
-    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
+    for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
     const float var = (float)(block_sum_d(s2, red) / (double) D);
     const float scale = 1.0f / sqrtf(var + eps);
-    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) out[i] = fmaf(l_row[i] * scale, w[i], b[i]);
+    for (int64_t i = threadIdx.x; i < D; i += 256) { const float y = l_row[i] * scale; const float yw = y * w[i]; out[i] = yw + b[i]; }
 }
 
 __global__ __launch_bounds__(256) void k_embed_ln0(EmbView emb, const uint32_t * __restrict__ tokens, int64_t D,
                                                    const float * __restrict__ w, const float * __restrict__ b, float * __restrict__ x) {
     extern __shared__ __attribute__((aligned(16))) float l_row[];
-    __shared__ double red[17];
+    __shared__ double red[257];
     const int64_t t = blockIdx.x;
     const int64_t row = tokens[t];
     for (int64_t i = threadIdx.x; i < D; i += blockDim.x) l_row[i] = emb_elem(emb, row, D, i);
@@ -477,7 +519,7 @@ __global__ __launch_bounds__(256) void k_embed_ln0(EmbView emb, const uint32_t *
 __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x, int64_t D, const float * __restrict__ w,
                                                    const float * __restrict__ b, float * __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float l_row[];
-    __shared__ double red[17];
+    __shared__ double red[257];
     const int64_t t = blockIdx.x;
     for (int64_t i = threadIdx.x; i < D; i += blockDim.x) l_row[i] = x[t * D + i];
     __syncthreads();
@@ -504,11 +546,11 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a, int64_t T, int64_t D) {
         const float x = a.xn[idx];
         const float xp = (t == 0) ? a.carry_in[d] : a.xn[idx - D];
         if (a.mode == 0) {
-            for (int f = 0; f < a.n_out; f++) { const float c = a.coef[f][d]; a.out[f][idx] = x * c + (xp - xp * c); }
+            for (int f = 0; f < a.n_out; f++) { const float c = a.coef[f][d]; const float xc = x * c, pc = xp * c; a.out[f][idx] = xc + (xp - pc); }
         } else {
             const float sx = xp - x;
             if (a.sx) a.sx[idx] = sx;
-            for (int f = 0; f < a.n_out; f++) a.out[f][idx] = sx * a.coef[f][d] + x;
+            for (int f = 0; f < a.n_out; f++) { const float sc = sx * a.coef[f][d]; a.out[f][idx] = sc + x; }
         }
         if (t == T - 1) a.carry_out[d] = x;
     }
@@ -531,11 +573,12 @@ __global__ __launch_bounds__(256) void k_v6_mix2(V6Mix2Args a, int64_t T, int64_
         float acc = 0.0f;
         for (int64_t m = 0; m < R; m += 4) {
             const float4 wv = *reinterpret_cast<const float4 *>(row + m);
-            acc = fmaf(wv.x, tl[m], acc); acc = fmaf(wv.y, tl[m + 1], acc);
-            acc = fmaf(wv.z, tl[m + 2], acc); acc = fmaf(wv.w, tl[m + 3], acc);
+            acc += wv.x * tl[m]; acc += wv.y * tl[m + 1];
+            acc += wv.z * tl[m + 2]; acc += wv.w * tl[m + 3];
         }
         const int64_t o = t * D + d;
-        a.out[f][o] = fmaf(acc + a.maa[f][d], a.sx[o], a.xn[o]);
+        const float mm = (acc + a.maa[f][d]) * a.sx[o];
+        a.out[f][o] = mm + a.xn[o];
     }
 }
 
@@ -562,12 +605,12 @@ __global__ __launch_bounds__(256) void k_wkv4(const float * __restrict__ k, cons
         const float kk = k[t * D + i], vv = v[t * D + i];
         float ww = u + kk;
         float qq = fmaxf(pp, ww);
-        float e1 = expf(pp - qq), e2 = expf(ww - qq);
+        float e1 = det_expf(pp - qq), e2 = det_expf(ww - qq);
         const float a = e1 * aa + e2 * vv;
         const float b = e1 * bb + e2;
         ww = pp + w;
         qq = fmaxf(ww, kk);
-        e1 = expf(ww - qq); e2 = expf(kk - qq);
+        e1 = det_expf(ww - qq); e2 = det_expf(kk - qq);
         aa = e1 * aa + e2 * vv;
         bb = e1 * bb + e2;
         pp = qq;
@@ -618,8 +661,9 @@ __global__ __launch_bounds__(64) void k_wkv6(const float * __restrict__ r, const
             for (int i = 0; i < S; i++) {
                 const float kv = vj * l_k[i];
                 const float prev = s[i];
-                o = fmaf(fmaf(kv, l_u[i], prev), l_r[i], o);
-                s[i] = fmaf(prev, l_w[i], kv);
+                const float temp = kv * l_u[i] + prev;
+                o += temp * l_r[i];
+                s[i] = prev * l_w[i] + kv;
             }
             out[t * D + h * S + j] = o;
         }
@@ -647,8 +691,9 @@ __global__ __launch_bounds__(256) void k_wkv6_generic(const float * __restrict__
                 const float wi = (w_mode == 2) ? w[t * D + h * S + i] : (w_mode == 1 ? w[h * S + i] : w[h]);
                 const float kv = vj * ki;
                 const float prev = sin[h * S * S + i * S + j];
-                o = fmaf(fmaf(kv, ui, prev), ri, o);
-                state_out[h * S * S + i * S + j] = fmaf(prev, wi, kv);
+                const float temp = kv * ui + prev;
+                o += temp * ri;
+                state_out[h * S * S + i * S + j] = prev * wi + kv;
             }
             out[t * D + h * S + j] = o;
         }
@@ -695,14 +740,14 @@ __global__ __launch_bounds__(64) void k_wkv7(const float * __restrict__ r, const
             const float vi = v[t * D + h * S + i];
             float sa = 0.0f;
 #pragma unroll
-            for (int j = 0; j < S; j++) sa = fmaf(l_a[j], s[j], sa);
+            for (int j = 0; j < S; j++) sa += l_a[j] * s[j];
             float res = 0.0f;
 #pragma unroll
             for (int j = 0; j < S; j++) {
                 const float kv = vi * l_k[j];
-                const float ns = fmaf(sa, l_b[j], fmaf(s[j], l_w[j], kv));
+                const float ns = (s[j] * l_w[j] + kv) + sa * l_b[j];
                 s[j] = ns;
-                res = fmaf(ns, l_r[j], res);
+                res += ns * l_r[j];
             }
             out[t * D + h * S + i] = res;
         }
@@ -726,13 +771,13 @@ __global__ __launch_bounds__(256) void k_wkv7_generic(const float * __restrict__
             const int64_t base = t * D + h * S;
             const float vi = v[base + i];
             float sa = 0.0f;
-            for (int64_t j = 0; j < S; j++) sa = fmaf(a[base + j], sin[h * S * S + i * S + j], sa);
+            for (int64_t j = 0; j < S; j++) sa += a[base + j] * sin[h * S * S + i * S + j];
             float res = 0.0f;
             for (int64_t j = 0; j < S; j++) {
                 const float kv = vi * k[base + j];
-                const float ns = fmaf(sa, b[base + j], fmaf(sin[h * S * S + i * S + j], w[base + j], kv));
+                const float ns = (sin[h * S * S + i * S + j] * w[base + j] + kv) + sa * b[base + j];
                 state_out[h * S * S + i * S + j] = ns;
-                res = fmaf(ns, r[base + j], res);
+                res += ns * r[base + j];
             }
             out[base + i] = res;
         }
@@ -770,12 +815,14 @@ __global__ __launch_bounds__(256) void k_groupnorm(float * __restrict__ x, const
     float bonus = 0.0f;
     if (v7_k) {
         float p = 0.0f;
-        for (int64_t j = lane; j < S; j += WAVE) p = fmaf(v7_k[base + j] * v7_r[base + j], v7_rk[h * S + j], p);
+        for (int64_t j = lane; j < S; j += WAVE) p += (v7_k[base + j] * v7_r[base + j]) * v7_rk[h * S + j];
         bonus = wave_sum_f(p);
     }
     for (int64_t j = lane; j < S; j += WAVE) {
-        float y = fmaf((x[base + j] - mean) * scale, lw[h * S + j], lb[h * S + j]);
-        if (v7_k) y = fmaf(v7_v[base + j], bonus, y);
+        float y = (x[base + j] - mean) * scale;
+        y = y * lw[h * S + j];
+        y = y + lb[h * S + j];
+        if (v7_k) y += v7_v[base + j] * bonus;
         if (gate) y *= gate[base + j];
         x[base + j] = y;
     }
@@ -797,14 +844,15 @@ __global__ __launch_bounds__(256) void k_v7_kprep(const float * __restrict__ k, 
     const int64_t h = th % H;
     const int64_t base = th * S;
     float p = 0.0f;
-    for (int64_t j = lane; j < S; j += WAVE) { const float t = k[base + j] * k_k[h * S + j]; p = fmaf(t, t, p); }
+    for (int64_t j = lane; j < S; j += WAVE) { const float t = k[base + j] * k_k[h * S + j]; p += t * t; }
     const float sum = wave_sum_f(p);
     const float scale = 1.0f / fmaxf(sqrtf(sum), 1e-12f);
     for (int64_t j = lane; j < S; j += WAVE) {
         const float kv = k[base + j], av = a[base + j];
-        const float kk = kv * k_k[h * S + j] * scale;
+        const float kk = (kv * k_k[h * S + j]) * scale;
         const float ka = kv * k_a[h * S + j];
-        k_out[base + j] = kv + (av * ka - ka);
+        const float aka = av * ka;
+        k_out[base + j] = kv + (aka - ka);
         neg_kk[base + j] = -kk;
         kk_a[base + j] = kk * av;
     }
@@ -817,7 +865,7 @@ void launch_v7_kprep(const float * k, const float * a, const float * k_k, const 
 }
 
 __global__ __launch_bounds__(256) void k_v7_vmix(float * __restrict__ v, const float * __restrict__ v_first, const float * __restrict__ gate, int64_t n) {
-    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) v[i] = v[i] + (v_first[i] - v[i]) * gate[i];
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) { const float dv = (v_first[i] - v[i]) * gate[i]; v[i] = v[i] + dv; }
 }
 void launch_v7_vmix(float * v, const float * v_first, const float * gate, int64_t n, hipStream_t st) {
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

@@ -44,15 +44,15 @@ def _oracle_logits(path):
 @pytest.mark.parametrize("version", R.HAVE_FP32_FP16)
 def test_fp32(golden_dir, version):
     p = R.fixture_path(golden_dir, version, "FP32")
-    logits = _check(p, golden_dir, version, R.FULL[version]["FP32"], extra_abs=2e-5)
-    assert float(np.abs(logits - _oracle_logits(p)).max()) <= 2e-5
+    logits = _check(p, golden_dir, version, R.FULL[version]["FP32"], extra_abs=1e-5)
+    assert np.array_equal(logits, _oracle_logits(p)), "GPU logits are not bit-identical to the CPU oracle"
 
 
 @pytest.mark.parametrize("version", R.HAVE_FP32_FP16)
 def test_fp16(golden_dir, version):
     p = R.fixture_path(golden_dir, version, "FP16")
     logits = _check(p, golden_dir, version, R.FULL[version]["FP16"])
-    assert float(np.abs(logits - _oracle_logits(p)).max()) <= 2e-2
+    assert np.array_equal(logits, _oracle_logits(p)), "GPU logits are not bit-identical to the CPU oracle"
 
 
 @pytest.mark.parametrize("version", list(R.SHIPPED_Q5))
@@ -60,8 +60,7 @@ def test_fp16(golden_dir, version):
 def test_shipped_q5(golden_dir, version, fmt):
     p = R.fixture_path(golden_dir, version, fmt)
     logits = _check(p, golden_dir, version, R.SHIPPED_Q5[version][fmt])
-    ol = _oracle_logits(p)
-    assert float(np.abs(logits - ol).max()) <= 0.05 * max(1.0, float(np.abs(ol).max()))
+    assert np.array_equal(logits, _oracle_logits(p)), "GPU logits are not bit-identical to the CPU oracle"
 
 
 @pytest.mark.parametrize("version", R.HAVE_FP32_FP16)
@@ -79,5 +78,6 @@ def test_quantize_then_eval(golden_dir, tmp_path, version, source):
         assert filecmp.cmp(out, ref, shallow=False), "product quantiser differs from the oracle's"
         if source == "FP32" and fmt in ("Q5_0", "Q5_1"):
             assert filecmp.cmp(out, R.fixture_path(golden_dir, version, fmt), shallow=False), "differs from the shipped fixture"
-        _check(out, golden_dir, version, table[version][i])
+        logits = _check(out, golden_dir, version, table[version][i])
+        assert np.array_equal(logits, _oracle_logits(out)), (version, source, fmt, "GPU != oracle")
     lib.rwkv_set_print_errors(None, True)
