@@ -155,6 +155,25 @@ static inline float det_tanhf(float x) {
     return (float) (x > 0.0f ? t : -t);
 }
 
+/* the same scalar functions, exported so the tests can compare the GPU's against them */
+void orc_unary(int op, const float * x, float * y, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        const float v = x[i];
+        float r;
+        switch (op) {
+            case 0: r = det_expf(v); break;
+            case 1: r = det_tanhf(v); break;
+            case 2: r = 1.0f / (1.0f + det_expf(-v)); break;
+            case 3: r = v / (1.0f + det_expf(-v)); break;
+            case 4: r = det_expf(-det_expf(v)); break;
+            case 5: r = det_expf((1.0f / (1.0f + det_expf(-v))) * -0.606531f); break;
+            case 6: r = 1.0f / sqrtf(v + 1e-5f); break;
+            default: r = v; break;
+        }
+        y[i] = r;
+    }
+}
+
 /* halving-tree folds: for o = n/2 .. 1: p[i] += p[i + o] */
 static inline double fold_d(double * p, int n) { for (int o = n / 2; o > 0; o >>= 1) for (int i = 0; i < o; i++) p[i] += p[i + o]; return p[0]; }
 static inline float  fold_f(float * p, int n)  { for (int o = n / 2; o > 0; o >>= 1) for (int i = 0; i < o; i++) p[i] += p[i + o]; return p[0]; }

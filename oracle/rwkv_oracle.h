@@ -61,6 +61,9 @@ void   orc_mul_mat(int wtype, const void * W, int64_t K, int64_t N, const float 
 /* file -> file quantiser (rwkv_quantize.inc:16-171). Returns 0 on success. */
 int orc_quantize_file(const char * in_path, const char * out_path, const char * format_name);
 
+/* deterministic scalar functions: 0 exp, 1 tanh, 2 sigmoid, 3 silu, 4 exp(-exp), 5 v7 decay, 6 1/sqrt(x+1e-5) */
+void orc_unary(int op, const float * x, float * y, int64_t n);
+
 uint16_t orc_f32_to_f16(float f);
 float    orc_f16_to_f32(uint16_t h);
 

@@ -303,6 +303,48 @@ RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major
 
 RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled) { ctx->use_graph = enabled; }
 
+// Test hook: the activation quantiser (f32 -> Q8_0/Q8_1 blocks) on standalone buffers.
+RWKV_API bool rwkv_mi_test_quantize_act(const float * x, int64_t n, int8_t * q, float * d, float * s, int32_t * isum) {
+    g_last_error = RWKV_ERROR_NONE;
+    RW_CHECK(RWKV_ERROR_ARGS, false, x && q && d && s && isum && n > 0 && n % 32 == 0, "bad arguments");
+    const size_t nb = (size_t) n / 32;
+    float * dx = nullptr; uint8_t * dq = nullptr;
+    bool ok = hipMalloc((void **) &dx, (size_t) n * 4) == hipSuccess && hipMalloc((void **) &dq, (size_t) n + 3 * nb * 4 + 1024) == hipSuccess &&
+              hipMemcpy(dx, x, (size_t) n * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        QAct qa;
+        qa.q = (int8_t *) dq;
+        qa.d = (float *) (dq + ((size_t) n + 255) / 256 * 256);
+        qa.s = qa.d + nb;
+        qa.isum = (int *) (qa.s + nb);
+        launch_quantize_act(dx, 1, n, qa, nullptr);
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(q, qa.q, (size_t) n, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(d, qa.d, nb * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(s, qa.s, nb * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(isum, qa.isum, nb * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (dx) (void) hipFree(dx);
+    if (dq) (void) hipFree(dq);
+    RW_CHECK(RWKV_ERROR_GRAPH, false, ok, "HIP error: %s", hipGetErrorString(hipGetLastError()));
+    return true;
+}
+
+// Test hook: elementwise deterministic scalar functions on the device.
+RWKV_API bool rwkv_mi_test_unary(int op, const float * x, float * y, int64_t n) {
+    g_last_error = RWKV_ERROR_NONE;
+    RW_CHECK(RWKV_ERROR_ARGS, false, x && y && n > 0, "bad arguments");
+    float *dx = nullptr, *dy = nullptr;
+    bool ok = hipMalloc((void **) &dx, (size_t) n * 4) == hipSuccess && hipMalloc((void **) &dy, (size_t) n * 4) == hipSuccess &&
+              hipMemcpy(dx, x, (size_t) n * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        launch_test_unary(op, dx, dy, n, nullptr);
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(y, dy, (size_t) n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (dx) (void) hipFree(dx);
+    if (dy) (void) hipFree(dy);
+    RW_CHECK(RWKV_ERROR_GRAPH, false, ok, "HIP error: %s", hipGetErrorString(hipGetLastError()));
+    return true;
+}
+
 // Test hook: y[T][N] = W[N][K] . x[T][K] through the production projection kernels (load-time re-pack, activation
 // quantiser, single-token or token-tiled kernel) on standalone buffers. W is in the FILE layout of `type`.
 RWKV_API bool rwkv_mi_test_mul_mat(int type, const void * w, int64_t K, int64_t N, const float * x, int64_t T, float * y) {

@@ -112,6 +112,9 @@ void launch_fill_state_v4(float * state, int64_t n_layer, int64_t D, hipStream_t
 // argmax over logits[n] -> *out (first index of the maximum), used by the on-device greedy decode loop
 void launch_argmax(const float * logits, int64_t n, uint32_t * out, hipStream_t st);
 
+// test hook: deterministic scalar functions (0 exp, 1 tanh, 2 sigmoid, 3 silu, 4 exp(-exp), 5 v7 decay, 6 1/sqrt(x+1e-5))
+void launch_test_unary(int op, const float * x, float * y, int64_t n, hipStream_t st);
+
 // load-time re-pack of quantised blocks (file layout) into planes; see DevTensor
 void launch_repack(int type, const uint8_t * raw, int64_t n_blocks, uint8_t * qs, uint32_t * qh, void * sc, hipStream_t st);
 

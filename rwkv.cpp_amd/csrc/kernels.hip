@@ -76,7 +76,12 @@ __device__ __forceinline__ float det_tanhf(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + det_expf(-x)); }
 __device__ __forceinline__ float h2f_bits(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+// f32 -> f16 -> f32 with the f32 value materialised first: without the barrier LLVM folds a preceding f32 multiply into
+// v_fma_mixlo_f16 (ONE rounding to f16), whereas the reference rounds the f32 product and then converts (two roundings).
+__device__ __forceinline__ float round_f16(float x) {
+    asm volatile("" : "+v"(x));
+    return __half2float(__float2half_rn(x));
+}
 
 // Sum of one double per thread over a 256-thread workgroup, as a halving tree over the 256 partials
 // (p[i] += p[i+128]; p[i] += p[i+64]; then the 64-entry butterfly): the order the oracle's fold_d(.., 256) uses.
@@ -924,6 +929,28 @@ __global__ __launch_bounds__(1024) void k_argmax(const float * __restrict__ logi
 }
 void launch_argmax(const float * logits, int64_t n, uint32_t * out, hipStream_t st) {
     hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, n, out);
+}
+
+// Test hook: the deterministic scalar functions applied elementwise (compared against the oracle's on the CPU).
+__global__ __launch_bounds__(256) void k_test_unary(int op, const float * __restrict__ x, float * __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) {
+        const float v = x[i];
+        float r;
+        switch (op) {
+            case 0: r = det_expf(v); break;
+            case 1: r = det_tanhf(v); break;
+            case 2: r = sigmoid_f(v); break;
+            case 3: r = v / (1.0f + det_expf(-v)); break;
+            case 4: r = det_expf(-det_expf(v)); break;
+            case 5: r = det_expf(sigmoid_f(v) * -0.606531f); break;
+            case 6: r = 1.0f / sqrtf(v + 1e-5f); break;
+            default: r = v; break;
+        }
+        y[i] = r;
+    }
+}
+void launch_test_unary(int op, const float * x, float * y, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_test_unary, dim3(1024), dim3(256), 0, st, op, x, y, n);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

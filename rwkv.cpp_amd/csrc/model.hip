@@ -274,9 +274,23 @@ Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end) 
     m->arena_bytes = total;
     struct ArenaGuard { Model * m; bool armed = true; ~ArenaGuard() { if (armed && m->arena) { (void) hipFree(m->arena); m->arena = nullptr; } } } aguard{m.get()};
 
-    void * d_raw = nullptr;
-    if (max_raw) HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_ALLOC, hipMalloc(&d_raw, max_raw));
-    struct RawGuard { void * p; ~RawGuard() { if (p) (void) hipFree(p); } } rguard{d_raw};
+    // Two raw staging buffers for quantised payloads: the upload of tensor i+1 overlaps the re-pack of tensor i, and a
+    // buffer is only rewritten after the re-pack kernel that read it has finished (explicit event, not stream order:
+    // pageable-memory copies are staged by the runtime and must not be assumed to queue behind earlier kernels).
+    void * d_raw[2] = {nullptr, nullptr};
+    hipEvent_t raw_free[2] = {nullptr, nullptr};
+    struct RawGuard {
+        void ** p; hipEvent_t * e;
+        ~RawGuard() { for (int i = 0; i < 2; i++) { if (p[i]) (void) hipFree(p[i]); if (e[i]) (void) hipEventDestroy(e[i]); } }
+    } rguard{d_raw, raw_free};
+    if (max_raw) {
+        for (int i = 0; i < 2; i++) {
+            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_ALLOC, hipMalloc(&d_raw[i], max_raw));
+            HIP_OK_OR(nullptr, RWKV_ERROR_CTX, hipEventCreateWithFlags(&raw_free[i], hipEventDisableTiming));
+        }
+    }
+    int raw_idx = 0;
+    bool raw_used[2] = {false, false};
 
     // pass 2: payloads. The file is mapped and copied straight from the page cache.
     MappedFile mf;
@@ -307,8 +321,12 @@ Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end) 
             dt->qs = cursor; cursor += p.qs;
             if (p.qh) { dt->qh = (uint32_t *) cursor; cursor += p.qh; }
             dt->sc = cursor; cursor += p.sc;
-            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipMemcpyAsync(d_raw, src, t.nbytes, hipMemcpyHostToDevice, st0));
-            launch_repack(t.type, (const uint8_t *) d_raw, t.nelements() / 32, dt->qs, dt->qh, dt->sc, st0);
+            if (raw_used[raw_idx]) HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipEventSynchronize(raw_free[raw_idx]));
+            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipMemcpyAsync(d_raw[raw_idx], src, t.nbytes, hipMemcpyHostToDevice, st0));
+            launch_repack(t.type, (const uint8_t *) d_raw[raw_idx], t.nelements() / 32, dt->qs, dt->qh, dt->sc, st0);
+            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipEventRecord(raw_free[raw_idx], st0));
+            raw_used[raw_idx] = true;
+            raw_idx ^= 1;
         }
         m->weight_bytes += t.nbytes;
         m->by_name[dt->name] = dt.get();

@@ -23,6 +23,10 @@ def library():
         L = _lib.library
         L.rwkv_mi_test_mul_mat.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.rwkv_mi_test_mul_mat.restype = ctypes.c_bool
+        L.rwkv_mi_test_quantize_act.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4
+        L.rwkv_mi_test_quantize_act.restype = ctypes.c_bool
+        L.rwkv_mi_test_unary.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        L.rwkv_mi_test_unary.restype = ctypes.c_bool
     return _lib
 
 
@@ -37,6 +41,24 @@ def gpu_mul_mat(type_id, w_bytes, K, N, x):
     y = np.empty((T, N), dtype=np.float32)
     ok = library().library.rwkv_mi_test_mul_mat(type_id, w.ctypes.data, K, N, x.ctypes.data, T, y.ctypes.data)
     assert ok, "rwkv_mi_test_mul_mat failed"
+    return y
+
+
+def gpu_quantize_act(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.size
+    q = np.empty(n, dtype=np.int8)
+    d = np.empty(n // 32, dtype=np.float32)
+    s = np.empty(n // 32, dtype=np.float32)
+    isum = np.empty(n // 32, dtype=np.int32)
+    assert library().library.rwkv_mi_test_quantize_act(x.ctypes.data, n, q.ctypes.data, d.ctypes.data, s.ctypes.data, isum.ctypes.data)
+    return q, d, s, isum
+
+
+def gpu_unary(op, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    assert library().library.rwkv_mi_test_unary(op, x.ctypes.data, y.ctypes.data, x.size)
     return y
 
 

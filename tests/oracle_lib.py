@@ -53,6 +53,7 @@ def lib():
         L.orc_mul_mat.argtypes = [ctypes.c_int, P, ctypes.c_int64, ctypes.c_int64, P, ctypes.c_int64, P]
         L.orc_quantize_file.restype = ctypes.c_int
         L.orc_quantize_file.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+        L.orc_unary.argtypes = [ctypes.c_int, P, P, ctypes.c_int64]
         L.orc_f32_to_f16.restype = ctypes.c_uint16
         L.orc_f32_to_f16.argtypes = [ctypes.c_float]
         L.orc_f16_to_f32.restype = ctypes.c_float
@@ -145,6 +146,13 @@ def mul_mat(type_id: int, w_bytes: np.ndarray, K: int, N: int, x: np.ndarray) ->
     w_bytes = np.ascontiguousarray(w_bytes).view(np.uint8)
     y = np.empty((T, N), dtype=np.float32)
     lib().orc_mul_mat(type_id, _p(w_bytes), K, N, _p(x), T, _p(y))
+    return y
+
+
+def unary(op: int, x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().orc_unary(op, _p(x), _p(y), x.size)
     return y
 
 
