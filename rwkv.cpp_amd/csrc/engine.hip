@@ -47,6 +47,11 @@ rwkv_context * create_context(Model * m, uint32_t n_threads) {
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail(e);
     const char * g = getenv("RWKV_MI_NO_GRAPH");
     ctx->use_graph = !(g && g[0] == '1');
+    const char * nf = getenv("RWKV_MI_NO_FUSED");
+    if (!(nf && nf[0] == '1') && fused_v6_supported(*m)) {
+        if ((e = hipMalloc(&ctx->fused_scratch, fused_v6_scratch_bytes(*m))) != hipSuccess) return fail(e);
+        ctx->fused_v6 = true;
+    }
     return ctx.release();
 }
 
@@ -60,6 +65,7 @@ void destroy_context(rwkv_context * ctx) {
     drop_graphs(ctx);
     for (int i = 0; i < 2; i++) if (ctx->state[i]) (void) hipFree(ctx->state[i]);
     if (ctx->scratch) (void) hipFree(ctx->scratch);
+    if (ctx->fused_scratch) (void) hipFree(ctx->fused_scratch);
     if (ctx->d_tokens) (void) hipFree(ctx->d_tokens);
     if (ctx->d_logits) (void) hipFree(ctx->d_logits);
     if (ctx->d_next_token) (void) hipFree(ctx->d_next_token);
@@ -278,6 +284,7 @@ struct Runner {
             const LayerW & L = m.layers[i];
             const float * li = sin + (int64_t) i * per_layer;
             float * lo = sout + (int64_t) i * per_layer;
+            if (T == 1 && ctx->fused_v6) { fused_v6_layer(m, L, b.x, li, lo, ctx->fused_scratch, st); continue; }
             switch (m.arch_major) {
                 case 4: att_v4(L, li, lo); break;
                 case 5: att_v5(L, li, lo); break;

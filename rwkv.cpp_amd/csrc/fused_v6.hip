@@ -1,0 +1,514 @@
+// fused_v6.hip -- the RWKV-6 single-token (decode) layer as SEVEN launches instead of ~25 graph-op kernels:
+//
+//   A  k6_att_prep   LN1 + token shift + maa_x mix + Q8 quantise (every workgroup, redundantly) -> W1 rows + tanh
+//   B  k6_mix2       five data-dependent mixes from the transposed F32 W2, quantised on the fly      (rwkv_graph.inc:313-346)
+//   C  k6_rkvgw      R, K, V, G projections + decay W1 in one launch (silu / tanh epilogues)         (:349-363)
+//   D  k6_wkv        per head: decay W2 + exp(-exp), WKV6 recurrence, GroupNorm * ln_x, gate, quantise (:357-382)
+//   E  k6_att_out    output projection + residual add                                               (:384, :671)
+//   F  k6_ffn_kr     LN2 + token shift + mixes + quantise -> key rows (relu^2, quantised per 32 rows) + receptance rows
+//   G  k6_ffn_v      value projection, x += sigmoid(r) * (Wv k)                                     (:513-531, :672)
+//
+// Every launch boundary is a real all-to-all dependency (a full-vector LayerNorm or a projection that consumes a whole
+// vector). Arithmetic and reduction orders are exactly those of the per-op kernels in kernels.hip,
+// so this path is bit-identical to the generic path and to the CPU oracle; tests/test_gpu_* run through it.
+//
+// Quantised activations travel between these kernels in the "lohi" image: for a vector of nb blocks, bytes
+// [b*16, b*16+16) hold elements 0..15 of block b and bytes [nb*16 + b*16, +16) hold elements 16..31, followed by
+// f32 d[nb], f32 s[nb], i32 isum[nb]. Lane-linear 16-byte LDS reads of that image are bank-conflict free.
+#include "kdev.h"
+#include "model.h"
+
+namespace rwkvmi {
+
+// ---------------------------------------------------------------------------------------------------------------
+// building blocks
+// ---------------------------------------------------------------------------------------------------------------
+
+struct QVec {      // one quantised activation vector in the lohi image (global or LDS)
+    int8_t * q;    // 32 * nb bytes
+    float * d;
+    float * s;
+    int * isum;
+};
+
+__host__ __device__ inline size_t qvec_bytes(int64_t K) { return (size_t) K + (size_t)(K / 32) * 12; }
+__host__ __device__ inline QVec qvec_at(void * base, int64_t K) {
+    QVec v;
+    v.q = (int8_t *) base;
+    v.d = (float *) ((uint8_t *) base + K);
+    v.s = v.d + K / 32;
+    v.isum = (int *) (v.s + K / 32);
+    return v;
+}
+
+// Quantise the 32-element block whose elements sit in the 32 lanes of a half-wave (ggml quantize_row_q8_0 / q8_1).
+__device__ __forceinline__ void quant_block32(float v, int & qi, float & d16, float & s16, int & isum) {
+    float amax = fabsf(v);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, WAVE));
+    const float dd = amax / 127.0f;
+    const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+    qi = (int) roundf(v * id);
+    int sum = qi;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);
+    d16 = round_f16(dd);
+    s16 = round_f16((float) sum * dd);
+    isum = sum;
+}
+
+// store one quantised element (block blk, element e) + the block scalars into a lohi image
+__device__ __forceinline__ void qvec_store(const QVec & v, int nb, int blk, int e, int qi, float d16, float s16, int isum) {
+    v.q[(e < 16 ? 0 : nb * 16) + blk * 16 + (e & 15)] = (int8_t) qi;
+    if (e == 0) { v.d[blk] = d16; v.s[blk] = s16; v.isum[blk] = isum; }
+}
+
+// copy a lohi image global -> LDS with 16-byte accesses (K multiple of 32; the scalar tail is 12 * nb bytes)
+__device__ __forceinline__ void qvec_stage(const void * __restrict__ g, void * l, int64_t K) {
+    const int n16 = (int) (qvec_bytes(K) / 16);  // K + 12*K/32 = K*11/8: multiple of 16 when K % 128 == 0; else a tail remains
+    const int4 * src = reinterpret_cast<const int4 *>(g);
+    int4 * dst = reinterpret_cast<int4 *>(l);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    const int tail0 = n16 * 4, words = (int) (qvec_bytes(K) / 4);
+    for (int i = tail0 + threadIdx.x; i < words; i += blockDim.x) reinterpret_cast<int *>(l)[i] = reinterpret_cast<const int *>(g)[i];
+}
+
+// R consecutive rows of a quantised matrix against an activation image in LDS; every lane returns the R row sums.
+template <int FMT, int R>
+__device__ __forceinline__ void rows_dot(const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh, const void * __restrict__ sc,
+                                         int64_t row0, int64_t N, int nb, const QVec & a, int lane, float (&res)[R]) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0f;
+    for (int b = lane; b < nb; b += WAVE) {
+        WBlk<FMT> w[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
+            load_wblk<FMT>(w[r], qs, qh, sc, row * nb + b);
+        }
+        const int4 alo = *reinterpret_cast<const int4 *>(a.q + b * 16);
+        const int4 ahi = *reinterpret_cast<const int4 *>(a.q + nb * 16 + b * 16);
+        const float dx = a.d[b], sx = a.s[b];
+        const int asum = a.isum[b];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = blk_fma<FMT>(w[r], alo, ahi, dx, sx, asum, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
+}
+
+// LayerNorm of one row by a 256-thread workgroup: the row is in l_row (D floats, overwritten by x - mean);
+// returns scale; afterwards xn_i = ((l_row[i] * scale) * w[i]) + b[i]   (same steps as block_layernorm in kernels.hip)
+__device__ __forceinline__ float block_ln_stats(float * l_row, int64_t D, double * red) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < D; i += 256) s += (double) l_row[i];
+    const float mean = (float)(block_sum_d(s, red) / (double) D);
+    double s2 = 0.0;
+    for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
+    const float var = (float)(block_sum_d(s2, red) / (double) D);
+    return 1.0f / sqrtf(var + 1e-5f);
+}
+
+struct WPl {  // planes of one quantised matrix
+    const uint8_t * qs;
+    const uint32_t * qh;
+    const void * sc;
+};
+static inline WPl planes(const DevTensor * t) { return WPl{t->qs, t->qh, t->sc}; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// A: LN1 + shift + xxx + quantise  ->  W1 rows (+ tanh)
+// ---------------------------------------------------------------------------------------------------------------
+
+struct P6A {
+    const float * x; const float * ln_w; const float * ln_b; const float * att_xx_in; const float * maa_x;
+    float * att_xx_out; float * xn_out; float * sx_out;
+    WPl w1; int64_t n_rows;  // 5 * r
+    float * tl;
+    int64_t D;
+};
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k6_att_prep(P6A p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t D = p.D;
+    const int nb = (int) (D / 32);
+    float * l_row = reinterpret_cast<float *>(smem);
+    unsigned char * l_qv = smem + D * 4;
+    double * red = reinterpret_cast<double *>(l_qv + ((qvec_bytes(D) + 15) / 16) * 16);
+    const QVec lq = qvec_at(l_qv, D);
+    for (int64_t i = threadIdx.x; i < D; i += 256) l_row[i] = p.x[i];
+    __syncthreads();
+    const float scale = block_ln_stats(l_row, D, red);
+    for (int64_t i = threadIdx.x; i < D; i += 256) {
+        const float y = l_row[i] * scale;
+        const float yw = y * p.ln_w[i];
+        const float xn = yw + p.ln_b[i];
+        const float sx = p.att_xx_in[i] - xn;
+        const float sm = sx * p.maa_x[i];
+        const float xxx = sm + xn;
+        if (blockIdx.x == 0) { p.xn_out[i] = xn; p.sx_out[i] = sx; p.att_xx_out[i] = xn; }
+        int qi, isum; float d16, s16;
+        quant_block32(xxx, qi, d16, s16, isum);
+        qvec_store(lq, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t) blockIdx.x * 4 + wave;
+    if (row >= p.n_rows) return;
+    float res[1];
+    rows_dot<FMT, 1>(p.w1.qs, p.w1.qh, p.w1.sc, row, p.n_rows, nb, lq, lane, res);
+    if (lane == 0) p.tl[row] = det_tanhf(res[0]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// B: out_f[d] = (sum_m W2t[f][m][d] * tl[f*R+m] + maa_f[d]) * sx[d] + xn[d], quantised; f order w,k,v,r,g
+// ---------------------------------------------------------------------------------------------------------------
+
+struct P6B {
+    const float * w2t;  // [5][R][D]
+    const float * tl;   // [5R]
+    const float * maa[5];
+    const float * sx; const float * xn;
+    void * out;         // 5 lohi images of D elements, qvec_bytes(D) apart (rounded up to 256)
+    int64_t D, R, out_stride;
+};
+
+__global__ __launch_bounds__(256) void k6_mix2(P6B p) {
+    __shared__ float l_tl[256];
+    const int64_t D = p.D, R = p.R;
+    const int64_t idx = (int64_t) blockIdx.x * 256 + threadIdx.x;  // D % 256 == 0: one f per workgroup
+    const int f = (int) (idx / D);
+    const int64_t d = idx - (int64_t) f * D;
+    for (int m = threadIdx.x; m < R; m += 256) l_tl[m] = p.tl[f * R + m];
+    __syncthreads();
+    const float * col = p.w2t + (int64_t) f * R * D + d;
+    float acc = 0.0f;
+    for (int64_t m = 0; m < R; m++) acc += col[m * D] * l_tl[m];
+    const float mm = (acc + p.maa[f][d]) * p.sx[d];
+    const float o = mm + p.xn[d];
+    int qi, isum; float d16, s16;
+    quant_block32(o, qi, d16, s16, isum);
+    const QVec ov = qvec_at((unsigned char *) p.out + (size_t) f * p.out_stride, D);
+    qvec_store(ov, (int) (D / 32), (int) (d >> 5), (int) (d & 31), qi, d16, s16, isum);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C: R, K, V, G (D x D) and decay W1 (DR x D) in one launch. 32-row groups, 4 waves x 8 rows.
+// ---------------------------------------------------------------------------------------------------------------
+
+struct P6C {
+    WPl w[5];            // r, k, v, g, decay_w1
+    const void * act;    // 5 lohi images (w, k, v, r, g)
+    int64_t act_stride;
+    float * out[5];      // r, k, v, g, dl
+    int64_t D, DR;
+};
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k6_rkvgw(P6C p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t D = p.D;
+    const int nb = (int) (D / 32);
+    const int64_t G = D / 32;
+    int mat = (int) (blockIdx.x / G);
+    int64_t grp = blockIdx.x - (int64_t) mat * G;
+    if (mat > 4) { mat = 4; grp = blockIdx.x - 4 * G; }
+    const int act = (0x04213 >> (4 * mat)) & 0xF;  // projection r,k,v,g,decay -> mix output index (w,k,v,r,g order): 3,1,2,4,0
+    qvec_stage((const unsigned char *) p.act + (size_t) act * p.act_stride, smem, D);
+    __syncthreads();
+    const QVec la = qvec_at(smem, D);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t N = mat == 4 ? p.DR : D;
+    const int64_t row0 = grp * 32 + wave * 8;
+    if (row0 >= N) return;
+    float res[8];
+    rows_dot<FMT, 8>(p.w[mat].qs, p.w[mat].qh, p.w[mat].sc, row0, N, nb, la, lane, res);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (row0 + r >= N) break;
+            float v = res[r];
+            if (mat == 3) v = v / (1.0f + det_expf(-v));
+            else if (mat == 4) v = det_tanhf(v);
+            p.out[mat][row0 + r] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// D: per head -- decay (W2 rows, K = DR), WKV6, GroupNorm * ln_x, gate, quantise. One wave per head, S = 64.
+// ---------------------------------------------------------------------------------------------------------------
+
+struct P6D {
+    const float * dl; WPl w2; const float * time_decay; const float * faaaa;
+    const float * r; const float * k; const float * v; const float * g;
+    const float * state_in; float * state_out;
+    const float * lnx_w; const float * lnx_b;
+    void * y_out;  // lohi image of D elements
+    int64_t D, DR;
+};
+
+template <int FMT, int NBD>
+__global__ __launch_bounds__(64) void k6_wkv(P6D p) {
+    constexpr int S = 64;
+    __shared__ __attribute__((aligned(16))) unsigned char l_dl[NBD * 32 + NBD * 12];
+    __shared__ float l_r[S], l_k[S], l_u[S], l_w[S];
+    const int lane = threadIdx.x;
+    const int64_t h = blockIdx.x, c = h * S + lane;
+    const int64_t D = p.D;
+    // state column first: the long-latency loads fly while the decay is computed
+    float s[S];
+#pragma unroll
+    for (int i = 0; i < S; i++) s[i] = p.state_in[h * S * S + i * S + lane];
+    // 1. quantise dl (DR = 32 * NBD elements): half-wave = block
+    const QVec ldl = qvec_at(l_dl, NBD * 32);
+#pragma unroll
+    for (int e0 = 0; e0 < NBD * 32; e0 += 64) {
+        const int e = e0 + lane;
+        const float val = e < NBD * 32 ? p.dl[e] : 0.0f;
+        int qi, isum; float d16, s16;
+        quant_block32(val, qi, d16, s16, isum);
+        if (e < NBD * 32) qvec_store(ldl, NBD, e >> 5, e & 31, qi, d16, s16, isum);
+    }
+    __syncthreads();
+    // 2. decay row of channel c: NBD partial sums, folded in the order of the 64-entry halving tree (zeros elsewhere)
+    float P[NBD];
+#pragma unroll
+    for (int b = 0; b < NBD; b++) {
+        WBlk<FMT> w;
+        load_wblk<FMT>(w, p.w2.qs, p.w2.qh, p.w2.sc, c * NBD + b);
+        const int4 alo = *reinterpret_cast<const int4 *>(ldl.q + b * 16);
+        const int4 ahi = *reinterpret_cast<const int4 *>(ldl.q + NBD * 16 + b * 16);
+        P[b] = blk_fma<FMT>(w, alo, ahi, ldl.d[b], ldl.s[b], ldl.isum[b], 0.0f);
+    }
+#pragma unroll
+    for (int o = NBD / 2; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < o; i++) P[i] += P[i + o];
+    const float wdec = det_expf(-det_expf(P[0] + p.time_decay[c]));
+    // 3. WKV6 (ggml_rwkv_wkv6): lane j owns value column j
+    l_r[lane] = p.r[c]; l_k[lane] = p.k[c]; l_u[lane] = p.faaaa[c]; l_w[lane] = wdec;
+    __syncthreads();
+    const float vj = p.v[c];
+    float o = 0.0f;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+        const float kv = vj * l_k[i];
+        const float prev = s[i];
+        const float temp = kv * l_u[i] + prev;
+        o += temp * l_r[i];
+        s[i] = prev * l_w[i] + kv;
+    }
+#pragma unroll
+    for (int i = 0; i < S; i++) p.state_out[h * S * S + i * S + lane] = s[i];
+    // 4. GroupNorm over the head (64 partials = 64 lanes), * ln_x, gate
+    const float mean = (float)(wave_sum_d((double) o) / (double) S);
+    const float dv = o - mean;
+    const float var = (float)(wave_sum_d((double)(dv * dv)) / (double) S);
+    const float scale = 1.0f / sqrtf(var + 64e-5f);
+    float y = dv * scale;
+    y = y * p.lnx_w[c];
+    y = y + p.lnx_b[c];
+    y *= p.g[c];
+    // 5. quantise for the output projection: this head is blocks 2h, 2h+1
+    int qi, isum; float d16, s16;
+    quant_block32(y, qi, d16, s16, isum);
+    qvec_store(qvec_at(p.y_out, D), (int) (D / 32), (int) (2 * h + (lane >> 5)), lane & 31, qi, d16, s16, isum);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// E / G: projection with a residual epilogue.  E: x += Wo y.   G: x += sigmoid(r) * (Wv k)
+// ---------------------------------------------------------------------------------------------------------------
+
+struct P6E {
+    WPl w; const void * act; float * x; const float * rgate;  // rgate == nullptr: plain residual add
+    int64_t N, K;
+};
+
+template <int FMT, int R>
+__global__ __launch_bounds__(256) void k6_proj_res(P6E p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    qvec_stage(p.act, smem, p.K);
+    __syncthreads();
+    const QVec la = qvec_at(smem, p.K);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t) blockIdx.x * 4 + wave) * R;
+    if (row0 >= p.N) return;
+    float res[R];
+    rows_dot<FMT, R>(p.w.qs, p.w.qh, p.w.sc, row0, p.N, (int) (p.K / 32), la, lane, res);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (row0 + r >= p.N) break;
+            const int64_t n = row0 + r;
+            if (p.rgate) { const float gte = sigmoid_f(p.rgate[n]) * res[r]; p.x[n] = p.x[n] + gte; }
+            else p.x[n] = p.x[n] + res[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// F: LN2 + shift + two mixes + quantise -> key rows (relu^2, quantised per 32-row group) and receptance rows
+// ---------------------------------------------------------------------------------------------------------------
+
+struct P6F {
+    const float * x; const float * ln_w; const float * ln_b; const float * ffn_xx_in; const float * maa_k; const float * maa_r;
+    float * ffn_xx_out;
+    WPl wk; WPl wr;
+    void * k_out;   // lohi image of F elements (relu(Wk xk)^2 quantised)
+    float * r_out;  // D floats (raw Wr xr)
+    int64_t D, F;
+};
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k6_ffn_kr(P6F p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float l_out[32];
+    const int64_t D = p.D, F = p.F;
+    const int nb = (int) (D / 32);
+    const size_t qb = ((qvec_bytes(D) + 15) / 16) * 16;
+    float * l_row = reinterpret_cast<float *>(smem);
+    unsigned char * l_k = smem + D * 4;
+    unsigned char * l_r = l_k + qb;
+    double * red = reinterpret_cast<double *>(l_r + qb);
+    const QVec qk = qvec_at(l_k, D), qr = qvec_at(l_r, D);
+    for (int64_t i = threadIdx.x; i < D; i += 256) l_row[i] = p.x[i];
+    __syncthreads();
+    const float scale = block_ln_stats(l_row, D, red);
+    for (int64_t i = threadIdx.x; i < D; i += 256) {
+        const float y = l_row[i] * scale;
+        const float yw = y * p.ln_w[i];
+        const float xn = yw + p.ln_b[i];
+        const float sx = p.ffn_xx_in[i] - xn;
+        const float sk = sx * p.maa_k[i];
+        const float xk = sk + xn;
+        const float sr = sx * p.maa_r[i];
+        const float xr = sr + xn;
+        if (blockIdx.x == 0) p.ffn_xx_out[i] = xn;
+        int qi, isum; float d16, s16;
+        quant_block32(xk, qi, d16, s16, isum);
+        qvec_store(qk, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
+        quant_block32(xr, qi, d16, s16, isum);
+        qvec_store(qr, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t GK = F / 32;
+    const bool is_key = (int64_t) blockIdx.x < GK;
+    const int64_t grp = is_key ? blockIdx.x : blockIdx.x - GK;
+    const int64_t N = is_key ? F : D;
+    const WPl & w = is_key ? p.wk : p.wr;
+    const int64_t row0 = grp * 32 + wave * 8;
+    float res[8];
+    rows_dot<FMT, 8>(w.qs, w.qh, w.sc, row0, N, nb, is_key ? qk : qr, lane, res);
+    if (!is_key) {
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) p.r_out[row0 + r] = res[r];
+        }
+        return;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const float t = res[r] > 0.0f ? res[r] : 0.0f; l_out[wave * 8 + r] = t * t; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // whole first wave runs the shuffles; lanes 0..31 hold the block
+        const float v = l_out[threadIdx.x & 31];
+        int qi, isum; float d16, s16;
+        quant_block32(v, qi, d16, s16, isum);
+        if (threadIdx.x < 32) qvec_store(qvec_at(p.k_out, F), (int) (F / 32), (int) grp, threadIdx.x, qi, d16, s16, isum);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+
+struct V6Scratch {
+    float *xn, *sx, *tl, *r, *k, *v, *g, *dl, *rr;
+    void *act5, *yq, *kq;
+    int64_t act_stride;
+};
+
+bool fused_v6_supported(const Model & m) {
+    if (m.arch_major != 6 || m.head_size != 64) return false;
+    const int64_t D = m.n_embed();
+    if (D % 256 != 0) return false;
+    const int fmt = (int) m.header.data_type;
+    if (!dtype_quantized(fmt)) return false;
+    for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
+        const LayerW & L = m.layers[i];
+        const DevTensor * mats[] = {L.att_receptance, L.att_key, L.att_value, L.att_gate, L.att_output, L.att_time_maa_w1,
+                                    L.att_time_decay_w1, L.att_time_decay_w2, L.ffn_key, L.ffn_value, L.ffn_receptance};
+        for (const DevTensor * t : mats) if (!t || t->type != fmt) return false;
+        const int64_t DR = L.att_time_decay_w1->ne[1], R5 = L.att_time_maa_w1->ne[1];
+        if (!(DR == 64 || DR == 128) || R5 / 5 > 256 || L.ffn_key->ne[1] % 32 != 0) return false;
+    }
+    return true;
+}
+
+size_t fused_v6_scratch_bytes(const Model & m) {
+    const size_t D = (size_t) m.n_embed(), F = (size_t) m.ffn_size;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    return 9 * up(D * 4) + up(2048 * 4) + up(256 * 4) + 5 * up(qvec_bytes(D)) + up(qvec_bytes(D)) + up(qvec_bytes(F)) + 4096;
+}
+
+template <int FMT>
+static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st) {
+    const int64_t D = m.n_embed(), F = L.ffn_key->ne[1], H = m.head_count;
+    const int64_t R5 = L.att_time_maa_w1->ne[1], R = R5 / 5, DR = L.att_time_decay_w1->ne[1];
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    unsigned char * p = (unsigned char *) scratch;
+    auto takef = [&](size_t n) { float * r = (float *) p; p += up(n * 4); return r; };
+    V6Scratch s;
+    s.xn = takef(D); s.sx = takef(D); s.r = takef(D); s.k = takef(D); s.v = takef(D); s.g = takef(D); s.rr = takef(D);
+    takef(D); takef(D);
+    s.tl = takef(2048); s.dl = takef(256);
+    s.act_stride = (int64_t) up(qvec_bytes(D));
+    s.act5 = p; p += 5 * s.act_stride;
+    s.yq = p; p += up(qvec_bytes(D));
+    s.kq = p; p += up(qvec_bytes(F));
+    auto f = [](const DevTensor * t) { return (const float *) t->data; };
+    const size_t qbD = ((qvec_bytes(D) + 15) / 16) * 16;
+
+    P6A a{x, f(L.ln1_w), f(L.ln1_b), sin + D, f(L.att_time_maa_x), sout + D, s.xn, s.sx, planes(L.att_time_maa_w1), R5, s.tl, D};
+    hipLaunchKernelGGL((k6_att_prep<FMT>), dim3((unsigned) ((R5 + 3) / 4)), dim3(256), (size_t) D * 4 + qbD + 257 * 8, st, a);
+
+    P6B b{f(L.att_time_maa_w2), s.tl, {f(L.att_time_maa_w), f(L.att_time_maa_k), f(L.att_time_maa_v), f(L.att_time_maa_r), f(L.att_time_maa_g)},
+          s.sx, s.xn, s.act5, D, R, s.act_stride};
+    hipLaunchKernelGGL(k6_mix2, dim3((unsigned) (5 * D / 256)), dim3(256), 0, st, b);
+
+    P6C c{{planes(L.att_receptance), planes(L.att_key), planes(L.att_value), planes(L.att_gate), planes(L.att_time_decay_w1)},
+          s.act5, s.act_stride, {s.r, s.k, s.v, s.g, s.dl}, D, DR};
+    hipLaunchKernelGGL((k6_rkvgw<FMT>), dim3((unsigned) (4 * (D / 32) + (DR + 31) / 32)), dim3(256), qbD, st, c);
+
+    P6D d{s.dl, planes(L.att_time_decay_w2), f(L.att_time_decay), f(L.att_time_faaaa), s.r, s.k, s.v, s.g, sin + 2 * D, sout + 2 * D,
+          f(L.att_ln_x_w), f(L.att_ln_x_b), s.yq, D, DR};
+    if (DR == 128) hipLaunchKernelGGL((k6_wkv<FMT, 4>), dim3((unsigned) H), dim3(64), 0, st, d);
+    else hipLaunchKernelGGL((k6_wkv<FMT, 2>), dim3((unsigned) H), dim3(64), 0, st, d);
+
+    P6E e{planes(L.att_output), s.yq, x, nullptr, D, D};
+    hipLaunchKernelGGL((k6_proj_res<FMT, 4>), dim3((unsigned) ((D + 15) / 16)), dim3(256), qbD, st, e);
+
+    P6F ff{x, f(L.ln2_w), f(L.ln2_b), sin, f(L.ffn_time_maa_k), f(L.ffn_time_maa_r), sout, planes(L.ffn_key), planes(L.ffn_receptance), s.kq, s.rr, D, F};
+    hipLaunchKernelGGL((k6_ffn_kr<FMT>), dim3((unsigned) (F / 32 + D / 32)), dim3(256), (size_t) D * 4 + 2 * qbD + 257 * 8, st, ff);
+
+    P6E g{planes(L.ffn_value), s.kq, x, s.rr, D, F};
+    hipLaunchKernelGGL((k6_proj_res<FMT, 4>), dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);
+}
+
+void fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st) {
+    switch ((int) m.header.data_type) {
+        case T_Q4_0: fused_v6_layer_t<T_Q4_0>(m, L, x, sin, sout, scratch, st); break;
+        case T_Q4_1: fused_v6_layer_t<T_Q4_1>(m, L, x, sin, sout, scratch, st); break;
+        case T_Q5_0: fused_v6_layer_t<T_Q5_0>(m, L, x, sin, sout, scratch, st); break;
+        case T_Q5_1: fused_v6_layer_t<T_Q5_1>(m, L, x, sin, sout, scratch, st); break;
+        case T_Q8_0: fused_v6_layer_t<T_Q8_0>(m, L, x, sin, sout, scratch, st); break;
+        default: break;
+    }
+}
+
+}  // namespace rwkvmi

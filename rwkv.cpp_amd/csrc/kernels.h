@@ -68,7 +68,7 @@ void launch_mix(const MixArgs & a, int64_t T, int64_t D, hipStream_t st);
 // v6 data-dependent mix, second stage (rwkv_graph.inc:323-346): for f in (w,k,v,r,g):
 //   out_f[t,d] = (sum_m W2[f][d][m] * tl[t][f*R+m] + maa_f[d]) * sx[t,d] + xn[t,d]
 struct V6Mix2Args {
-    const float * w2 = nullptr;   // [5][D][R] f32
+    const float * w2 = nullptr;   // [5][R][D] f32 (transposed at load)
     const float * tl = nullptr;   // [T][5R] (already tanh'ed)
     const float * maa[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const float * sx = nullptr;
@@ -114,6 +114,9 @@ void launch_argmax(const float * logits, int64_t n, uint32_t * out, hipStream_t 
 
 // test hook: deterministic scalar functions (0 exp, 1 tanh, 2 sigmoid, 3 silu, 4 exp(-exp), 5 v7 decay, 6 1/sqrt(x+1e-5))
 void launch_test_unary(int op, const float * x, float * y, int64_t n, hipStream_t st);
+
+// load-time transpose of att.time_maa_w2: [5][D][R] -> [5][R][D]
+void launch_transpose_w2(const float * src, float * dst, int64_t D, int64_t R, hipStream_t st);
 
 // load-time re-pack of quantised blocks (file layout) into planes; see DevTensor
 void launch_repack(int type, const uint8_t * raw, int64_t n_blocks, uint8_t * qs, uint32_t * qh, void * sc, hipStream_t st);

@@ -15,180 +15,9 @@
 //    explicit fmaf() inside dot products. exp / tanh are the deterministic double-precision routines below. Together
 //    with the fixed reduction orders this makes the GPU results bit-identical to the CPU oracle (oracle/rwkv_oracle.c),
 //    which the tests assert with array_equal.
-#include "kernels.h"
-
-#include <hip/hip_fp16.h>
+#include "kdev.h"
 
 namespace rwkvmi {
-
-#define WAVE 64
-
-// ---------------------------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-// exp in double (ln2 hi/lo reduction, degree-13 Taylor, fma Horner), rounded once to float; same routine as the oracle's.
-__device__ __forceinline__ double det_exp_d(double x) {
-    const double n = rint(x * 1.4426950408889634074);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;
-    p = fma(p, r, 2.08767569878681e-09);
-    p = fma(p, r, 2.505210838544172e-08);
-    p = fma(p, r, 2.755731922398589e-07);
-    p = fma(p, r, 2.7557319223985893e-06);
-    p = fma(p, r, 2.48015873015873e-05);
-    p = fma(p, r, 1.984126984126984e-04);
-    p = fma(p, r, 1.388888888888889e-03);
-    p = fma(p, r, 8.333333333333333e-03);
-    p = fma(p, r, 4.1666666666666664e-02);
-    p = fma(p, r, 1.6666666666666666e-01);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int) n);
-}
-__device__ __forceinline__ float det_expf(float x) {
-    if (x != x) return x;
-    if (x > 88.72283935546875f) return INFINITY;
-    if (x < -103.97208404541016f) return 0.0f;
-    return (float) det_exp_d((double) x);
-}
-__device__ __forceinline__ float det_tanhf(float x) {
-    if (x != x) return x;
-    const double xd = (double) x;
-    const double ax = fabs(xd);
-    if (ax < 1e-4) return (float) (xd * fma(xd * xd, -1.0 / 3.0, 1.0));
-    if (ax > 20.0) return x > 0.0f ? 1.0f : -1.0f;
-    const double sv = det_exp_d(ax + ax);
-    const double t = 1.0 - 2.0 / (sv + 1.0);
-    return (float) (x > 0.0f ? t : -t);
-}
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + det_expf(-x)); }
-__device__ __forceinline__ float h2f_bits(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-// f32 -> f16 -> f32 with the f32 value materialised first: without the barrier LLVM folds a preceding f32 multiply into
-// v_fma_mixlo_f16 (ONE rounding to f16), whereas the reference rounds the f32 product and then converts (two roundings).
-__device__ __forceinline__ float round_f16(float x) {
-    asm volatile("" : "+v"(x));
-    return __half2float(__float2half_rn(x));
-}
-
-// Sum of one double per thread over a 256-thread workgroup, as a halving tree over the 256 partials
-// (p[i] += p[i+128]; p[i] += p[i+64]; then the 64-entry butterfly): the order the oracle's fold_d(.., 256) uses.
-__device__ __forceinline__ double block_sum_d(double v, double * red /* [257] */) {
-    __syncthreads();
-    red[threadIdx.x] = v;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int i = threadIdx.x;
-        double t = (red[i] + red[i + 128]) + (red[i + 64] + red[i + 192]);
-        t = wave_sum_d(t);
-        if (i == 0) red[256] = t;
-    }
-    __syncthreads();
-    return red[256];
-}
-
-__device__ __forceinline__ float apply_epi(const Epi & e, float acc, int64_t t, int64_t n, int64_t ldy) {
-    switch (e.op) {
-        case EPI_NONE: return acc;
-        case EPI_SIGMOID: return sigmoid_f(acc);
-        case EPI_RELU_SQ: { const float r = acc > 0.0f ? acc : 0.0f; return r * r; }
-        case EPI_SILU: return acc / (1.0f + det_expf(-acc));
-        case EPI_TANH: return det_tanhf(acc);
-        case EPI_ADD_RES: return e.res[t * ldy + n] + acc;
-        case EPI_SIGMUL_ADD_RES: { const float g = sigmoid_f(e.aux[t * ldy + n]) * acc; return e.res[t * ldy + n] + g; }
-        case EPI_BIAS_SIGMOID: return sigmoid_f(acc + e.bias[n]);
-        case EPI_V6_DECAY: return det_expf(-det_expf(acc + e.bias[n]));
-        case EPI_V7_DECAY: return det_expf(sigmoid_f(acc + e.bias[n]) * -0.606531f);
-        default: return acc;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Quantised weight blocks (planes, see DevTensor). One block = 32 weights.
-// ---------------------------------------------------------------------------------------------------------------
-
-template <int FMT> struct QF;
-template <> struct QF<T_Q4_0> { static constexpr int QS = 16; static constexpr bool QH = false, HM = false; static constexpr int OFF = 8; };
-template <> struct QF<T_Q4_1> { static constexpr int QS = 16; static constexpr bool QH = false, HM = true;  static constexpr int OFF = 0; };
-template <> struct QF<T_Q5_0> { static constexpr int QS = 16; static constexpr bool QH = true,  HM = false; static constexpr int OFF = 16; };
-template <> struct QF<T_Q5_1> { static constexpr int QS = 16; static constexpr bool QH = true,  HM = true;  static constexpr int OFF = 0; };
-template <> struct QF<T_Q8_0> { static constexpr int QS = 32; static constexpr bool QH = false, HM = false; static constexpr int OFF = 0; };
-
-// Codes of one block as 8 dwords of 4 x int8: c[0..3] = elements 0..15, c[4..7] = elements 16..31.
-// 4/5-bit codes are left unsigned (0..15 / 0..31); the -8 / -16 offset is applied through the activation sum.
-template <int FMT>
-struct WBlk {
-    int c[8];
-    float d, m;
-};
-
-template <int FMT>
-__device__ __forceinline__ void load_wblk(WBlk<FMT> & w, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
-                                          const void * __restrict__ sc, int64_t blk) {
-    if constexpr (QF<FMT>::QS == 32) {
-        const int4 a = *reinterpret_cast<const int4 *>(qs + blk * 32);
-        const int4 b = *reinterpret_cast<const int4 *>(qs + blk * 32 + 16);
-        w.c[0] = a.x; w.c[1] = a.y; w.c[2] = a.z; w.c[3] = a.w;
-        w.c[4] = b.x; w.c[5] = b.y; w.c[6] = b.z; w.c[7] = b.w;
-    } else {
-        const int4 a = *reinterpret_cast<const int4 *>(qs + blk * 16);
-        const int raw[4] = {a.x, a.y, a.z, a.w};
-        unsigned hbits = 0;
-        if constexpr (QF<FMT>::QH) hbits = qh[blk];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int lo = raw[i] & 0x0F0F0F0F;
-            int hi = (raw[i] >> 4) & 0x0F0F0F0F;
-            if constexpr (QF<FMT>::QH) {
-                // bit j of qh -> bit 4 of byte j (elements 0..15), bit 16+j -> elements 16..31.
-                const unsigned nl = (hbits >> (4 * i)) & 0xFu, nh = (hbits >> (16 + 4 * i)) & 0xFu;
-                lo |= (int)(((nl * 0x00204081u) & 0x01010101u) << 4);
-                hi |= (int)(((nh * 0x00204081u) & 0x01010101u) << 4);
-            }
-            w.c[i] = lo;
-            w.c[4 + i] = hi;
-        }
-    }
-    if constexpr (QF<FMT>::HM) {
-        const uint32_t dm = reinterpret_cast<const uint32_t *>(sc)[blk];
-        w.d = h2f_bits((uint16_t)(dm & 0xFFFFu));
-        w.m = h2f_bits((uint16_t)(dm >> 16));
-    } else {
-        w.d = h2f_bits(reinterpret_cast<const uint16_t *>(sc)[blk]);
-        w.m = 0.0f;
-    }
-}
-
-// acc <- acc + contribution of one weight block against one activation block.
-template <int FMT>
-__device__ __forceinline__ float blk_fma(const WBlk<FMT> & w, const int4 alo, const int4 ahi, float dx, float sx, int asum, float acc) {
-    int s = 0;
-    s = __builtin_amdgcn_sdot4(w.c[0], alo.x, s, false);
-    s = __builtin_amdgcn_sdot4(w.c[1], alo.y, s, false);
-    s = __builtin_amdgcn_sdot4(w.c[2], alo.z, s, false);
-    s = __builtin_amdgcn_sdot4(w.c[3], alo.w, s, false);
-    s = __builtin_amdgcn_sdot4(w.c[4], ahi.x, s, false);
-    s = __builtin_amdgcn_sdot4(w.c[5], ahi.y, s, false);
-    s = __builtin_amdgcn_sdot4(w.c[6], ahi.z, s, false);
-    s = __builtin_amdgcn_sdot4(w.c[7], ahi.w, s, false);
-    if constexpr (QF<FMT>::OFF != 0) s -= QF<FMT>::OFF * asum;
-    const float dd = w.d * dx;
-    acc = fmaf(dd, (float) s, acc);
-    if constexpr (QF<FMT>::HM) acc = fmaf(w.m, sx, acc);
-    return acc;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Projection, quantised weights, single token (decode): the HBM-roofline kernel.
@@ -573,14 +402,10 @@ __global__ __launch_bounds__(256) void k_v6_mix2(V6Mix2Args a, int64_t T, int64_
         const int64_t d = idx % D;
         const int64_t f = (idx / D) % 5;
         const int64_t t = idx / (5 * D);
-        const float * row = a.w2 + (f * D + d) * R;
+        const float * col = a.w2 + f * R * D + d;  // W2 is stored transposed at load: [5][R][D]
         const float * tl = a.tl + t * 5 * R + f * R;
         float acc = 0.0f;
-        for (int64_t m = 0; m < R; m += 4) {
-            const float4 wv = *reinterpret_cast<const float4 *>(row + m);
-            acc += wv.x * tl[m]; acc += wv.y * tl[m + 1];
-            acc += wv.z * tl[m + 2]; acc += wv.w * tl[m + 3];
-        }
+        for (int64_t m = 0; m < R; m++) acc += col[m * D] * tl[m];
         const int64_t o = t * D + d;
         const float mm = (acc + a.maa[f][d]) * a.sx[o];
         a.out[f][o] = mm + a.xn[o];
@@ -951,6 +776,18 @@ __global__ __launch_bounds__(256) void k_test_unary(int op, const float * __rest
 }
 void launch_test_unary(int op, const float * x, float * y, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_test_unary, dim3(1024), dim3(256), 0, st, op, x, y, n);
+}
+
+// load-time transpose of the v6 mix matrix: [5][D][R] (file) -> [5][R][D], so that lanes read consecutive d
+__global__ __launch_bounds__(256) void k_transpose_w2(const float * __restrict__ src, float * __restrict__ dst, int64_t D, int64_t R) {
+    const int64_t n = 5 * D * R;
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) {
+        const int64_t d = i % D, m = (i / D) % R, f = i / (D * R);
+        dst[i] = src[(f * D + d) * R + m];
+    }
+}
+void launch_transpose_w2(const float * src, float * dst, int64_t D, int64_t R, hipStream_t st) {
+    hipLaunchKernelGGL(k_transpose_w2, dim3(1024), dim3(256), 0, st, src, dst, D, R);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

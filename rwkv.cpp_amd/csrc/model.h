@@ -108,6 +108,10 @@ struct rwkv_context {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
+    // fused single-token path (fused_v6.hip) when the model qualifies
+    bool  fused_v6 = false;
+    void * fused_scratch = nullptr;
+
     // Live per-launch timing of the dominant kernel (the quantised single-token projection) with HIP events on this
     // context's stream; filled by rwkv_mi_profile_decode, used by bench.py's roofline figure.
     struct Prof {
@@ -132,6 +136,11 @@ bool state_to_host(rwkv_context * ctx, float * state_out);
 // Runs T tokens (already in ctx->d_tokens) through the layers of this stage. Reads state[cur], writes state[cur^1], flips cur.
 // x_in / x_out: residual stream hand-off for pipeline stages (nullptr on a full model). Logits land in ctx->d_logits.
 bool forward(rwkv_context * ctx, int64_t T, bool want_logits);
+
+// fused RWKV-6 decode layer (fused_v6.hip)
+bool   fused_v6_supported(const Model & m);
+size_t fused_v6_scratch_bytes(const Model & m);
+void   fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
 bool forward_decode(rwkv_context * ctx, bool want_logits);
 

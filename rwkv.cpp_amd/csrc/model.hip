@@ -268,7 +268,8 @@ Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end) 
         if (!wanted(t)) continue;
         const PlaneSizes p = plane_sizes(t);
         total += p.data + p.qs + p.qh + p.sc;
-        if (dtype_quantized(t.type) && t.nbytes > max_raw) max_raw = (size_t) t.nbytes;
+        const bool staged = dtype_quantized(t.type) || (t.type == T_F32 && t.ndim == 3 && t.name.find("att.time_maa_w2") != std::string::npos);
+        if (staged && t.nbytes > max_raw) max_raw = (size_t) t.nbytes;
     }
     HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_ALLOC, hipMalloc(&m->arena, total > 0 ? total : 256));
     m->arena_bytes = total;
@@ -314,7 +315,17 @@ Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end) 
         for (int i = 0; i < 3; i++) dt->ne[i] = t.ne[i];
         const PlaneSizes p = plane_sizes(t);
         const uint8_t * src = mf.base + t.file_offset;
-        if (!dtype_quantized(t.type)) {
+        const bool w2 = t.type == T_F32 && t.ndim == 3 && t.name.find("att.time_maa_w2") != std::string::npos && t.ne[2] == 5;
+        if (w2) {
+            // v6 mix matrix: stored transposed ([5][R][D]) so that the mix kernels read it coalesced
+            dt->data = cursor; cursor += p.data;
+            if (raw_used[raw_idx]) HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipEventSynchronize(raw_free[raw_idx]));
+            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipMemcpyAsync(d_raw[raw_idx], src, t.nbytes, hipMemcpyHostToDevice, st0));
+            launch_transpose_w2((const float *) d_raw[raw_idx], (float *) dt->data, t.ne[1], t.ne[0], st0);
+            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipEventRecord(raw_free[raw_idx], st0));
+            raw_used[raw_idx] = true;
+            raw_idx ^= 1;
+        } else if (!dtype_quantized(t.type)) {
             dt->data = cursor; cursor += p.data;
             HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipMemcpyAsync(dt->data, src, t.nbytes, hipMemcpyHostToDevice, st0));
         } else {
