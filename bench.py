@@ -149,8 +149,8 @@ def main():
         }
         if not args.no_profile:
             p = model.profile_decode(first, min(args.steps, 32))
-            ach = p["bytes"] / (p["kernel_ms"] * 1e-3) / 1e9
-            result["roofline"] = {"bound": "hbm", "kernel": f"k_mvq_t1<{args.dtype}> (quantised single-token projection)", "achieved": ach,
+            ach = p["bytes"] / max(p["kernel_ms"], 1e-9) / 1e6
+            result["roofline"] = {"bound": "hbm", "kernel": f"quantised single-token projection kernels ({args.dtype}): k6_rkvgw, k6_proj_res, k6_ffn_kr", "achieved": ach,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                   "launches": p["launches"], "avg_launch_us": p["kernel_ms"] * 1e3 / p["launches"],
                                   "avg_bytes_per_launch": p["bytes"] / p["launches"]}

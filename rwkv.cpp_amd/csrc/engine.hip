@@ -284,7 +284,7 @@ struct Runner {
             const LayerW & L = m.layers[i];
             const float * li = sin + (int64_t) i * per_layer;
             float * lo = sout + (int64_t) i * per_layer;
-            if (T == 1 && ctx->fused_v6) { fused_v6_layer(m, L, b.x, li, lo, ctx->fused_scratch, st); continue; }
+            if (T == 1 && ctx->fused_v6) { fused_v6_layer(m, L, b.x, li, lo, ctx->fused_scratch, st, &ctx->prof); continue; }
             switch (m.arch_major) {
                 case 4: att_v4(L, li, lo); break;
                 case 5: att_v5(L, li, lo); break;

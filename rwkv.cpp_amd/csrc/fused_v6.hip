@@ -18,6 +18,8 @@
 #include "kdev.h"
 #include "model.h"
 
+#include <hip/hip_ext.h>
+
 namespace rwkvmi {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -43,15 +45,11 @@ __host__ __device__ inline QVec qvec_at(void * base, int64_t K) {
 
 // Quantise the 32-element block whose elements sit in the 32 lanes of a half-wave (ggml quantize_row_q8_0 / q8_1).
 __device__ __forceinline__ void quant_block32(float v, int & qi, float & d16, float & s16, int & isum) {
-    float amax = fabsf(v);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, WAVE));
+    const float amax = half_max_f(fabsf(v));
     const float dd = amax / 127.0f;
     const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
     qi = (int) roundf(v * id);
-    int sum = qi;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);
+    const int sum = half_sum_i(qi);
     d16 = round_f16(dd);
     s16 = round_f16((float) sum * dd);
     isum = sum;
@@ -185,6 +183,7 @@ __global__ __launch_bounds__(256) void k6_mix2(P6B p) {
     __syncthreads();
     const float * col = p.w2t + (int64_t) f * R * D + d;
     float acc = 0.0f;
+#pragma unroll 16
     for (int64_t m = 0; m < R; m++) acc += col[m * D] * l_tl[m];
     const float mm = (acc + p.maa[f][d]) * p.sx[d];
     const float o = mm + p.xn[d];
@@ -254,7 +253,6 @@ template <int FMT, int NBD>
 __global__ __launch_bounds__(64) void k6_wkv(P6D p) {
     constexpr int S = 64;
     __shared__ __attribute__((aligned(16))) unsigned char l_dl[NBD * 32 + NBD * 12];
-    __shared__ float l_r[S], l_k[S], l_u[S], l_w[S];
     const int lane = threadIdx.x;
     const int64_t h = blockIdx.x, c = h * S + lane;
     const int64_t D = p.D;
@@ -288,18 +286,21 @@ __global__ __launch_bounds__(64) void k6_wkv(P6D p) {
 #pragma unroll
         for (int i = 0; i < o; i++) P[i] += P[i + o];
     const float wdec = det_expf(-det_expf(P[0] + p.time_decay[c]));
-    // 3. WKV6 (ggml_rwkv_wkv6): lane j owns value column j
-    l_r[lane] = p.r[c]; l_k[lane] = p.k[c]; l_u[lane] = p.faaaa[c]; l_w[lane] = wdec;
-    __syncthreads();
+    // 3. WKV6 (ggml_rwkv_wkv6): lane j owns value column j; r_i, k_i, u_i, w_i are broadcast from lane i (v_readlane)
+    const int rr_i = __float_as_int(p.r[c]), kk_i = __float_as_int(p.k[c]), uu_i = __float_as_int(p.faaaa[c]), ww_i = __float_as_int(wdec);
     const float vj = p.v[c];
     float o = 0.0f;
 #pragma unroll
     for (int i = 0; i < S; i++) {
-        const float kv = vj * l_k[i];
+        const float ki = __int_as_float(__builtin_amdgcn_readlane(kk_i, i));
+        const float ui = __int_as_float(__builtin_amdgcn_readlane(uu_i, i));
+        const float ri = __int_as_float(__builtin_amdgcn_readlane(rr_i, i));
+        const float wi = __int_as_float(__builtin_amdgcn_readlane(ww_i, i));
+        const float kv = vj * ki;
         const float prev = s[i];
-        const float temp = kv * l_u[i] + prev;
-        o += temp * l_r[i];
-        s[i] = prev * l_w[i] + kv;
+        const float temp = kv * ui + prev;
+        o += temp * ri;
+        s[i] = prev * wi + kv;
     }
 #pragma unroll
     for (int i = 0; i < S; i++) p.state_out[h * S * S + i * S + lane] = s[i];
@@ -456,8 +457,26 @@ size_t fused_v6_scratch_bytes(const Model & m) {
     return 9 * up(D * 4) + up(2048 * 4) + up(256 * 4) + 5 * up(qvec_bytes(D)) + up(qvec_bytes(D)) + up(qvec_bytes(F)) + 4096;
 }
 
+// Launch, optionally bracketed by the kernel's own start/stop timestamps (hipExtLaunchKernelGGL events: the dispatch's
+// begin/end as the profiler sees them, no host-side event overhead inside the interval).
+template <typename Kern, typename Param>
+static void launch6(rwkv_context::Prof * pf, uint64_t bytes, Kern kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, const Param & prm) {
+    if (pf && pf->on && bytes) {
+        if (pf->used * 2 + 2 > pf->events.size()) {
+            hipEvent_t a = nullptr, c = nullptr;
+            (void) hipEventCreate(&a); (void) hipEventCreate(&c);
+            pf->events.push_back(a); pf->events.push_back(c); pf->bytes.push_back(0);
+        }
+        pf->bytes[pf->used] = bytes;
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t) shmem, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, prm);
+        pf->used++;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, prm);
+    }
+}
+
 template <int FMT>
-static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st) {
+static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf) {
     const int64_t D = m.n_embed(), F = L.ffn_key->ne[1], H = m.head_count;
     const int64_t R5 = L.att_time_maa_w1->ne[1], R = R5 / 5, DR = L.att_time_decay_w1->ne[1];
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -475,38 +494,41 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
     const size_t qbD = ((qvec_bytes(D) + 15) / 16) * 16;
 
     P6A a{x, f(L.ln1_w), f(L.ln1_b), sin + D, f(L.att_time_maa_x), sout + D, s.xn, s.sx, planes(L.att_time_maa_w1), R5, s.tl, D};
-    hipLaunchKernelGGL((k6_att_prep<FMT>), dim3((unsigned) ((R5 + 3) / 4)), dim3(256), (size_t) D * 4 + qbD + 257 * 8, st, a);
+    launch6(pf, 0, k6_att_prep<FMT>, dim3((unsigned) ((R5 + 3) / 4)), dim3(256), (size_t) D * 4 + qbD + 257 * 8, st, a);
 
     P6B b{f(L.att_time_maa_w2), s.tl, {f(L.att_time_maa_w), f(L.att_time_maa_k), f(L.att_time_maa_v), f(L.att_time_maa_r), f(L.att_time_maa_g)},
           s.sx, s.xn, s.act5, D, R, s.act_stride};
-    hipLaunchKernelGGL(k6_mix2, dim3((unsigned) (5 * D / 256)), dim3(256), 0, st, b);
+    launch6(pf, 0, k6_mix2, dim3((unsigned) (5 * D / 256)), dim3(256), 0, st, b);
 
     P6C c{{planes(L.att_receptance), planes(L.att_key), planes(L.att_value), planes(L.att_gate), planes(L.att_time_decay_w1)},
           s.act5, s.act_stride, {s.r, s.k, s.v, s.g, s.dl}, D, DR};
-    hipLaunchKernelGGL((k6_rkvgw<FMT>), dim3((unsigned) (4 * (D / 32) + (DR + 31) / 32)), dim3(256), qbD, st, c);
+    const uint64_t actD = qvec_bytes(D);
+    launch6(pf, L.att_receptance->nbytes + L.att_key->nbytes + L.att_value->nbytes + L.att_gate->nbytes + L.att_time_decay_w1->nbytes + 5 * actD + (4 * D + DR) * 4,
+            k6_rkvgw<FMT>, dim3((unsigned) (4 * (D / 32) + (DR + 31) / 32)), dim3(256), qbD, st, c);
 
     P6D d{s.dl, planes(L.att_time_decay_w2), f(L.att_time_decay), f(L.att_time_faaaa), s.r, s.k, s.v, s.g, sin + 2 * D, sout + 2 * D,
           f(L.att_ln_x_w), f(L.att_ln_x_b), s.yq, D, DR};
-    if (DR == 128) hipLaunchKernelGGL((k6_wkv<FMT, 4>), dim3((unsigned) H), dim3(64), 0, st, d);
-    else hipLaunchKernelGGL((k6_wkv<FMT, 2>), dim3((unsigned) H), dim3(64), 0, st, d);
+    if (DR == 128) launch6(pf, 0, k6_wkv<FMT, 4>, dim3((unsigned) H), dim3(64), 0, st, d);
+    else launch6(pf, 0, k6_wkv<FMT, 2>, dim3((unsigned) H), dim3(64), 0, st, d);
 
     P6E e{planes(L.att_output), s.yq, x, nullptr, D, D};
-    hipLaunchKernelGGL((k6_proj_res<FMT, 4>), dim3((unsigned) ((D + 15) / 16)), dim3(256), qbD, st, e);
+    launch6(pf, L.att_output->nbytes + actD + D * 8, k6_proj_res<FMT, 4>, dim3((unsigned) ((D + 15) / 16)), dim3(256), qbD, st, e);
 
     P6F ff{x, f(L.ln2_w), f(L.ln2_b), sin, f(L.ffn_time_maa_k), f(L.ffn_time_maa_r), sout, planes(L.ffn_key), planes(L.ffn_receptance), s.kq, s.rr, D, F};
-    hipLaunchKernelGGL((k6_ffn_kr<FMT>), dim3((unsigned) (F / 32 + D / 32)), dim3(256), (size_t) D * 4 + 2 * qbD + 257 * 8, st, ff);
+    launch6(pf, L.ffn_key->nbytes + L.ffn_receptance->nbytes + D * 12 + qvec_bytes(F) + D * 4, k6_ffn_kr<FMT>, dim3((unsigned) (F / 32 + D / 32)), dim3(256),
+            (size_t) D * 4 + 2 * qbD + 257 * 8, st, ff);
 
     P6E g{planes(L.ffn_value), s.kq, x, s.rr, D, F};
-    hipLaunchKernelGGL((k6_proj_res<FMT, 4>), dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);
+    launch6(pf, L.ffn_value->nbytes + qvec_bytes(F) + D * 12, k6_proj_res<FMT, 4>, dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);
 }
 
-void fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st) {
+void fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf) {
     switch ((int) m.header.data_type) {
-        case T_Q4_0: fused_v6_layer_t<T_Q4_0>(m, L, x, sin, sout, scratch, st); break;
-        case T_Q4_1: fused_v6_layer_t<T_Q4_1>(m, L, x, sin, sout, scratch, st); break;
-        case T_Q5_0: fused_v6_layer_t<T_Q5_0>(m, L, x, sin, sout, scratch, st); break;
-        case T_Q5_1: fused_v6_layer_t<T_Q5_1>(m, L, x, sin, sout, scratch, st); break;
-        case T_Q8_0: fused_v6_layer_t<T_Q8_0>(m, L, x, sin, sout, scratch, st); break;
+        case T_Q4_0: fused_v6_layer_t<T_Q4_0>(m, L, x, sin, sout, scratch, st, pf); break;
+        case T_Q4_1: fused_v6_layer_t<T_Q4_1>(m, L, x, sin, sout, scratch, st, pf); break;
+        case T_Q5_0: fused_v6_layer_t<T_Q5_0>(m, L, x, sin, sout, scratch, st, pf); break;
+        case T_Q5_1: fused_v6_layer_t<T_Q5_1>(m, L, x, sin, sout, scratch, st, pf); break;
+        case T_Q8_0: fused_v6_layer_t<T_Q8_0>(m, L, x, sin, sout, scratch, st, pf); break;
         default: break;
     }
 }

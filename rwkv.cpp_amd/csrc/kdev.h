@@ -15,16 +15,83 @@ namespace rwkvmi {
 // small device helpers
 // ---------------------------------------------------------------------------------------------------------------
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-lane primitives. __shfl_xor lowers to ds_bpermute (LDS crossbar, ~100+ cycles per dependent step); the
+// sequences below use DPP and the gfx950 permlane swaps instead (a few cycles per step) and implement EXACTLY the
+// xor-butterfly pairing (lane l with lane l ^ o, o = 32, 16, 8, 4, 2, 1), i.e. the halving tree of the numerics spec.
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// value of lane (l ^ 4): row_shl:4 feeds banks 0 and 2 (lanes reading l + 4), row_shr:4 banks 1 and 3 (lanes reading l - 4)
+__device__ __forceinline__ int lane_xor4_i(int v) {
+    int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);
+    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);
+}
+__device__ __forceinline__ int lane_xor1_i(int v) { return dpp_i<0xB1>(v); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ int lane_xor2_i(int v) { return dpp_i<0x4E>(v); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ int lane_xor8_i(int v) { return dpp_i<0x128>(v); }  // row_ror:8
+
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    v = v + __int_as_float(lane_xor8_i(__float_as_int(v)));
+    v = v + __int_as_float(lane_xor4_i(__float_as_int(v)));
+    v = v + __int_as_float(lane_xor2_i(__float_as_int(v)));
+    v = v + __int_as_float(lane_xor1_i(__float_as_int(v)));
     return v;
 }
+
+__device__ __forceinline__ double mk_double(unsigned lo, unsigned hi) { return __hiloint2double((int) hi, (int) lo); }
 __device__ __forceinline__ double wave_sum_d(double v) {
+    {
+        const unsigned lo = (unsigned) __double2loint(v), hi = (unsigned) __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = mk_double(a[0], b[0]) + mk_double(a[1], b[1]);
+    }
+    {
+        const unsigned lo = (unsigned) __double2loint(v), hi = (unsigned) __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = mk_double(a[0], b[0]) + mk_double(a[1], b[1]);
+    }
+    v = v + mk_double((unsigned) lane_xor8_i(__double2loint(v)), (unsigned) lane_xor8_i(__double2hiint(v)));
+    v = v + mk_double((unsigned) lane_xor4_i(__double2loint(v)), (unsigned) lane_xor4_i(__double2hiint(v)));
+    v = v + mk_double((unsigned) lane_xor2_i(__double2loint(v)), (unsigned) lane_xor2_i(__double2hiint(v)));
+    v = v + mk_double((unsigned) lane_xor1_i(__double2loint(v)), (unsigned) lane_xor1_i(__double2hiint(v)));
+    return v;
+}
+
+// reference forms (ds_bpermute), kept for the self-test of the fast sequences
+__device__ __forceinline__ float wave_sum_f_ref(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
 }
+__device__ __forceinline__ double wave_sum_d_ref(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// order-free reductions over the 32 lanes of a half-wave (max and integer sum are exact in any order)
+__device__ __forceinline__ float half_max_f(float v) {
+    v = fmaxf(v, __int_as_float(lane_xor1_i(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(lane_xor2_i(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(lane_xor4_i(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(lane_xor8_i(__float_as_int(v))));
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ int half_sum_i(int v) {
+    v += lane_xor1_i(v);
+    v += lane_xor2_i(v);
+    v += lane_xor4_i(v);
+    v += lane_xor8_i(v);
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned) v, (unsigned) v, false, false);
+    return (int) r[0] + (int) r[1];
+}
+
 // exp in double (ln2 hi/lo reduction, degree-13 Taylor, fma Horner), rounded once to float; same routine as the oracle's.
 __device__ __forceinline__ double det_exp_d(double x) {
     const double n = rint(x * 1.4426950408889634074);

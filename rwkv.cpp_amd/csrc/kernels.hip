@@ -261,17 +261,14 @@ __global__ __launch_bounds__(256) void k_quant_act(const float * __restrict__ x,
                                                    float * __restrict__ d, float * __restrict__ s, int * __restrict__ isum) {
     const int64_t blk = ((int64_t) blockIdx.x * 256 + threadIdx.x) >> 5;
     const int e = threadIdx.x & 31;
-    if (blk >= n_blocks) return;
-    const float v = x[blk * 32 + e];
-    float amax = fabsf(v);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, WAVE));
+    const bool live = blk < n_blocks;  // keep whole waves alive: the reductions below use DPP / permlane across the wave
+    const float v = live ? x[blk * 32 + e] : 0.0f;
+    const float amax = half_max_f(fabsf(v));
     const float dd = amax / 127.0f;
     const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
     const int qi = (int) roundf(v * id);
-    int sum = qi;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);
+    const int sum = half_sum_i(qi);
+    if (!live) return;
     q[blk * 32 + e] = (int8_t) qi;
     if (e == 0) {
         d[blk] = round_f16(dd);
@@ -769,6 +766,12 @@ __global__ __launch_bounds__(256) void k_test_unary(int op, const float * __rest
             case 4: r = det_expf(-det_expf(v)); break;
             case 5: r = det_expf(sigmoid_f(v) * -0.606531f); break;
             case 6: r = 1.0f / sqrtf(v + 1e-5f); break;
+            case 7: { const float a = wave_sum_f(v), b = wave_sum_f_ref(v); r = (__float_as_uint(a) == __float_as_uint(b)) ? 1.0f : 0.0f; break; }
+            case 8: { const double xd = (double) v * (1.0 + 1e-9 * (double) (threadIdx.x & 63));
+                      const double a = wave_sum_d(xd), b = wave_sum_d_ref(xd); r = (a == b) ? 1.0f : 0.0f; break; }
+            case 9: { float m = fabsf(v); for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+                      int q = (int) v, sref = q; for (int o = 16; o > 0; o >>= 1) sref += __shfl_xor(sref, o, WAVE);
+                      r = (half_max_f(fabsf(v)) == m && half_sum_i(q) == sref) ? 1.0f : 0.0f; break; }
             default: r = v; break;
         }
         y[i] = r;

@@ -140,7 +140,7 @@ bool forward(rwkv_context * ctx, int64_t T, bool want_logits);
 // fused RWKV-6 decode layer (fused_v6.hip)
 bool   fused_v6_supported(const Model & m);
 size_t fused_v6_scratch_bytes(const Model & m);
-void   fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st);
+void   fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
 bool forward_decode(rwkv_context * ctx, bool want_logits);
 

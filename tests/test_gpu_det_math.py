@@ -45,3 +45,14 @@ def test_activation_quantiser_bit_exact():
     assert np.array_equal(d, od)
     assert np.array_equal(s, os_), (int((s != os_).sum()), s[s != os_][:4], os_[s != os_][:4])
     assert np.array_equal(isum, oq.reshape(-1, 32).astype(np.int32).sum(axis=1))
+
+
+@pytest.mark.parametrize("op", [7, 8, 9])
+def test_fast_wave_reductions_match_the_reference_butterfly(op):
+    # op 7: float xor-butterfly, op 8: double, op 9: half-wave max / int sum; 1.0 where DPP/permlane form == ds_bpermute form
+    rng = np.random.default_rng(op)
+    x = (rng.standard_normal(64 * 4096) * np.repeat(10.0 ** rng.uniform(-6, 6, 4096), 64)).astype(np.float32)
+    if op == 9:
+        x = np.clip(x, -127, 127)
+    ok = gpu_unary(op, x)
+    assert np.all(ok == 1.0), int((ok != 1.0).sum())
