@@ -63,10 +63,18 @@ __device__ __forceinline__ void qvec_store(const QVec & v, int nb, int blk, int 
 
 // copy a lohi image global -> LDS with 16-byte accesses (K multiple of 32; the scalar tail is 12 * nb bytes)
 __device__ __forceinline__ void qvec_stage(const void * __restrict__ g, void * l, int64_t K) {
-    const int n16 = (int) (qvec_bytes(K) / 16);  // K + 12*K/32 = K*11/8: multiple of 16 when K % 128 == 0; else a tail remains
+    const int n16 = (int) (qvec_bytes(K) / 16);  // K + 12*K/32 = K*11/8 bytes; a sub-16-byte tail remains when K % 128 != 0
     const int4 * src = reinterpret_cast<const int4 *>(g);
     int4 * dst = reinterpret_cast<int4 *>(l);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    for (int i0 = threadIdx.x; i0 < n16; i0 += 4 * (int) blockDim.x) {
+        int4 t[4];
+        int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + u * (int) blockDim.x; idx[u] = i < n16 ? i : n16 - 1; t[u] = src[idx[u]]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) dst[idx[u]] = t[u];  // clamped duplicates rewrite the last chunk with the same bytes
+    }
     const int tail0 = n16 * 4, words = (int) (qvec_bytes(K) / 4);
     for (int i = tail0 + threadIdx.x; i < words; i += blockDim.x) reinterpret_cast<int *>(l)[i] = reinterpret_cast<const int *>(g)[i];
 }
@@ -78,22 +86,50 @@ __device__ __forceinline__ void rows_dot(const uint8_t * __restrict__ qs, const 
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
-    for (int b = lane; b < nb; b += WAVE) {
-        WBlk<FMT> w[R];
+    for (int b0 = lane; b0 < nb; b0 += 2 * WAVE) {
+        RawBlk<FMT> raw[2][R];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
-            load_wblk<FMT>(w[r], qs, qh, sc, row * nb + b);
+        for (int u = 0; u < 2; u++) {
+            const int b = b0 + u * WAVE < nb ? b0 + u * WAVE : nb - 1;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
+                load_raw<FMT>(raw[u][r], qs, qh, sc, row * nb + b);
+            }
         }
-        const int4 alo = *reinterpret_cast<const int4 *>(a.q + b * 16);
-        const int4 ahi = *reinterpret_cast<const int4 *>(a.q + nb * 16 + b * 16);
-        const float dx = a.d[b], sx = a.s[b];
-        const int asum = a.isum[b];
+        __builtin_amdgcn_sched_barrier(0);  // every load of the step is in flight before the first use
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = blk_fma<FMT>(w[r], alo, ahi, dx, sx, asum, acc[r]);
+        for (int u = 0; u < 2; u++) {
+            const bool valid = b0 + u * WAVE < nb;
+            const int b = valid ? b0 + u * WAVE : nb - 1;
+            const int4 alo = *reinterpret_cast<const int4 *>(a.q + b * 16);
+            const int4 ahi = *reinterpret_cast<const int4 *>(a.q + nb * 16 + b * 16);
+            const float dx = a.d[b], sx = a.s[b];
+            const int asum = a.isum[b];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                WBlk<FMT> w;
+                unpack_raw<FMT>(w, raw[u][r]);
+                acc[r] = blk_fma<FMT>(w, alo, ahi, dx, sx, asum, acc[r], valid);
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
+}
+
+// copy a row of D floats (D % 4 == 0) global -> LDS with batched 16-byte loads
+__device__ __forceinline__ void fill_row(float * l_row, const float * __restrict__ x, int64_t D) {
+    const int n4 = (int) (D / 4);
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+        float4 t[4];
+        int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + u * 256; idx[u] = i < n4 ? i : n4 - 1; t[u] = reinterpret_cast<const float4 *>(x)[idx[u]]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) reinterpret_cast<float4 *>(l_row)[idx[u]] = t[u];
+    }
 }
 
 // LayerNorm of one row by a 256-thread workgroup: the row is in l_row (D floats, overwritten by x - mean);
@@ -136,21 +172,31 @@ __global__ __launch_bounds__(256) void k6_att_prep(P6A p) {
     unsigned char * l_qv = smem + D * 4;
     double * red = reinterpret_cast<double *>(l_qv + ((qvec_bytes(D) + 15) / 16) * 16);
     const QVec lq = qvec_at(l_qv, D);
-    for (int64_t i = threadIdx.x; i < D; i += 256) l_row[i] = p.x[i];
+    fill_row(l_row, p.x, D);
     __syncthreads();
     const float scale = block_ln_stats(l_row, D, red);
-    for (int64_t i = threadIdx.x; i < D; i += 256) {
+    auto elem = [&](int64_t i, float lw, float lb, float pv, float mx) {
         const float y = l_row[i] * scale;
-        const float yw = y * p.ln_w[i];
-        const float xn = yw + p.ln_b[i];
-        const float sx = p.att_xx_in[i] - xn;
-        const float sm = sx * p.maa_x[i];
+        const float yw = y * lw;
+        const float xn = yw + lb;
+        const float sx = pv - xn;
+        const float sm = sx * mx;
         const float xxx = sm + xn;
         if (blockIdx.x == 0) { p.xn_out[i] = xn; p.sx_out[i] = sx; p.att_xx_out[i] = xn; }
         int qi, isum; float d16, s16;
         quant_block32(xxx, qi, d16, s16, isum);
         qvec_store(lq, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
+    };
+    int64_t i0 = threadIdx.x;
+    for (; i0 + 3 * 256 < D; i0 += 4 * 256) {   // four element steps per trip: 16 independent loads in flight
+        float lw[4], lb[4], pv[4], mx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * 256; lw[u] = p.ln_w[i]; lb[u] = p.ln_b[i]; pv[u] = p.att_xx_in[i]; mx[u] = p.maa_x[i]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) elem(i0 + u * 256, lw[u], lb[u], pv[u], mx[u]);
     }
+    for (; i0 < D; i0 += 256) elem(i0, p.ln_w[i0], p.ln_b[i0], p.att_xx_in[i0], p.maa_x[i0]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = (int64_t) blockIdx.x * 4 + wave;
@@ -375,17 +421,17 @@ __global__ __launch_bounds__(256) void k6_ffn_kr(P6F p) {
     unsigned char * l_r = l_k + qb;
     double * red = reinterpret_cast<double *>(l_r + qb);
     const QVec qk = qvec_at(l_k, D), qr = qvec_at(l_r, D);
-    for (int64_t i = threadIdx.x; i < D; i += 256) l_row[i] = p.x[i];
+    fill_row(l_row, p.x, D);
     __syncthreads();
     const float scale = block_ln_stats(l_row, D, red);
-    for (int64_t i = threadIdx.x; i < D; i += 256) {
+    auto elem = [&](int64_t i, float lw, float lb, float pv, float mk, float mr) {
         const float y = l_row[i] * scale;
-        const float yw = y * p.ln_w[i];
-        const float xn = yw + p.ln_b[i];
-        const float sx = p.ffn_xx_in[i] - xn;
-        const float sk = sx * p.maa_k[i];
+        const float yw = y * lw;
+        const float xn = yw + lb;
+        const float sx = pv - xn;
+        const float sk = sx * mk;
         const float xk = sk + xn;
-        const float sr = sx * p.maa_r[i];
+        const float sr = sx * mr;
         const float xr = sr + xn;
         if (blockIdx.x == 0) p.ffn_xx_out[i] = xn;
         int qi, isum; float d16, s16;
@@ -393,7 +439,17 @@ __global__ __launch_bounds__(256) void k6_ffn_kr(P6F p) {
         qvec_store(qk, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
         quant_block32(xr, qi, d16, s16, isum);
         qvec_store(qr, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
+    };
+    int64_t i0 = threadIdx.x;
+    for (; i0 + 3 * 256 < D; i0 += 4 * 256) {
+        float lw[4], lb[4], pv[4], mk[4], mr[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * 256; lw[u] = p.ln_w[i]; lb[u] = p.ln_b[i]; pv[u] = p.ffn_xx_in[i]; mk[u] = p.maa_k[i]; mr[u] = p.maa_r[i]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) elem(i0 + u * 256, lw[u], lb[u], pv[u], mk[u], mr[u]);
     }
+    for (; i0 < D; i0 += 256) elem(i0, p.ln_w[i0], p.ln_b[i0], p.ffn_xx_in[i0], p.maa_k[i0], p.maa_r[i0]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t GK = F / 32;

@@ -181,6 +181,32 @@ template <> struct QF<T_Q5_0> { static constexpr int QS = 16; static constexpr b
 template <> struct QF<T_Q5_1> { static constexpr int QS = 16; static constexpr bool QH = true,  HM = true;  static constexpr int OFF = 0; };
 template <> struct QF<T_Q8_0> { static constexpr int QS = 32; static constexpr bool QH = false, HM = false; static constexpr int OFF = 0; };
 
+// Raw bytes of one block as they sit in the planes. Loading is split from decoding so that a kernel can issue the
+// loads of ALL the blocks of a step (codes, fifth bits and scales) before the first use -- otherwise the compiler
+// sinks the scale loads behind the dot products and every step pays two dependent memory round trips.
+template <int FMT>
+struct RawBlk {
+    int4 q0;
+    int4 q1;        // Q8_0 only
+    unsigned qh;    // Q5 only
+    unsigned sc;    // fp16 d in the low half (+ fp16 m in the high half for Q4_1 / Q5_1)
+};
+
+template <int FMT>
+__device__ __forceinline__ void load_raw(RawBlk<FMT> & r, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
+                                         const void * __restrict__ sc, int64_t blk) {
+    if constexpr (QF<FMT>::HM) r.sc = reinterpret_cast<const uint32_t *>(sc)[blk];
+    else r.sc = reinterpret_cast<const uint16_t *>(sc)[blk];
+    if constexpr (QF<FMT>::QH) r.qh = qh[blk]; else r.qh = 0;
+    if constexpr (QF<FMT>::QS == 32) {
+        r.q0 = *reinterpret_cast<const int4 *>(qs + blk * 32);
+        r.q1 = *reinterpret_cast<const int4 *>(qs + blk * 32 + 16);
+    } else {
+        r.q0 = *reinterpret_cast<const int4 *>(qs + blk * 16);
+        r.q1 = make_int4(0, 0, 0, 0);
+    }
+}
+
 // Codes of one block as 8 dwords of 4 x int8: c[0..3] = elements 0..15, c[4..7] = elements 16..31.
 // 4/5-bit codes are left unsigned (0..15 / 0..31); the -8 / -16 offset is applied through the activation sum.
 template <int FMT>
@@ -190,25 +216,19 @@ struct WBlk {
 };
 
 template <int FMT>
-__device__ __forceinline__ void load_wblk(WBlk<FMT> & w, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
-                                          const void * __restrict__ sc, int64_t blk) {
+__device__ __forceinline__ void unpack_raw(WBlk<FMT> & w, const RawBlk<FMT> & r) {
     if constexpr (QF<FMT>::QS == 32) {
-        const int4 a = *reinterpret_cast<const int4 *>(qs + blk * 32);
-        const int4 b = *reinterpret_cast<const int4 *>(qs + blk * 32 + 16);
-        w.c[0] = a.x; w.c[1] = a.y; w.c[2] = a.z; w.c[3] = a.w;
-        w.c[4] = b.x; w.c[5] = b.y; w.c[6] = b.z; w.c[7] = b.w;
+        w.c[0] = r.q0.x; w.c[1] = r.q0.y; w.c[2] = r.q0.z; w.c[3] = r.q0.w;
+        w.c[4] = r.q1.x; w.c[5] = r.q1.y; w.c[6] = r.q1.z; w.c[7] = r.q1.w;
     } else {
-        const int4 a = *reinterpret_cast<const int4 *>(qs + blk * 16);
-        const int raw[4] = {a.x, a.y, a.z, a.w};
-        unsigned hbits = 0;
-        if constexpr (QF<FMT>::QH) hbits = qh[blk];
+        const int raw[4] = {r.q0.x, r.q0.y, r.q0.z, r.q0.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             int lo = raw[i] & 0x0F0F0F0F;
             int hi = (raw[i] >> 4) & 0x0F0F0F0F;
             if constexpr (QF<FMT>::QH) {
                 // bit j of qh -> bit 4 of byte j (elements 0..15), bit 16+j -> elements 16..31.
-                const unsigned nl = (hbits >> (4 * i)) & 0xFu, nh = (hbits >> (16 + 4 * i)) & 0xFu;
+                const unsigned nl = (r.qh >> (4 * i)) & 0xFu, nh = (r.qh >> (16 + 4 * i)) & 0xFu;
                 lo |= (int)(((nl * 0x00204081u) & 0x01010101u) << 4);
                 hi |= (int)(((nh * 0x00204081u) & 0x01010101u) << 4);
             }
@@ -216,19 +236,22 @@ __device__ __forceinline__ void load_wblk(WBlk<FMT> & w, const uint8_t * __restr
             w.c[4 + i] = hi;
         }
     }
-    if constexpr (QF<FMT>::HM) {
-        const uint32_t dm = reinterpret_cast<const uint32_t *>(sc)[blk];
-        w.d = h2f_bits((uint16_t)(dm & 0xFFFFu));
-        w.m = h2f_bits((uint16_t)(dm >> 16));
-    } else {
-        w.d = h2f_bits(reinterpret_cast<const uint16_t *>(sc)[blk]);
-        w.m = 0.0f;
-    }
+    w.d = h2f_bits((uint16_t)(r.sc & 0xFFFFu));
+    if constexpr (QF<FMT>::HM) w.m = h2f_bits((uint16_t)(r.sc >> 16)); else w.m = 0.0f;
 }
 
-// acc <- acc + contribution of one weight block against one activation block.
 template <int FMT>
-__device__ __forceinline__ float blk_fma(const WBlk<FMT> & w, const int4 alo, const int4 ahi, float dx, float sx, int asum, float acc) {
+__device__ __forceinline__ void load_wblk(WBlk<FMT> & w, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
+                                          const void * __restrict__ sc, int64_t blk) {
+    RawBlk<FMT> r;
+    load_raw<FMT>(r, qs, qh, sc, blk);
+    unpack_raw<FMT>(w, r);
+}
+
+// acc <- acc + contribution of one weight block against one activation block. `valid` = false turns the step into
+// acc + 0 (used by lanes whose block index is past the row end: loads are clamped, nothing is branched around).
+template <int FMT>
+__device__ __forceinline__ float blk_fma(const WBlk<FMT> & w, const int4 alo, const int4 ahi, float dx, float sx, int asum, float acc, bool valid = true) {
     int s = 0;
     s = __builtin_amdgcn_sdot4(w.c[0], alo.x, s, false);
     s = __builtin_amdgcn_sdot4(w.c[1], alo.y, s, false);
@@ -240,10 +263,9 @@ __device__ __forceinline__ float blk_fma(const WBlk<FMT> & w, const int4 alo, co
     s = __builtin_amdgcn_sdot4(w.c[7], ahi.w, s, false);
     if constexpr (QF<FMT>::OFF != 0) s -= QF<FMT>::OFF * asum;
     const float dd = w.d * dx;
-    acc = fmaf(dd, (float) s, acc);
-    if constexpr (QF<FMT>::HM) acc = fmaf(w.m, sx, acc);
+    acc = fmaf(dd, valid ? (float) s : 0.0f, acc);
+    if constexpr (QF<FMT>::HM) acc = fmaf(w.m, valid ? sx : 0.0f, acc);
     return acc;
 }
-
 
 }  // namespace rwkvmi

@@ -35,19 +35,34 @@ __global__ __launch_bounds__(256) void k_mvq_t1(const uint8_t * __restrict__ qs,
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
-    for (int b = lane; b < nb; b += WAVE) {
-        const int4 alo = reinterpret_cast<const int4 *>(xq)[2 * b];
-        const int4 ahi = reinterpret_cast<const int4 *>(xq)[2 * b + 1];
-        const float dx = xd[b], sx = xs[b];
-        const int asum = xi[b];
-        WBlk<FMT> w[R];
+    for (int b0 = lane; b0 < nb; b0 += 2 * WAVE) {
+        RawBlk<FMT> raw[2][R];
+        int4 alo[2], ahi[2];
+        float dx[2], sx[2];
+        int asum[2];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
-            load_wblk<FMT>(w[r], qs, qh, sc, row * nb + b);
+        for (int u = 0; u < 2; u++) {
+            const int b = b0 + u * WAVE < nb ? b0 + u * WAVE : nb - 1;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
+                load_raw<FMT>(raw[u][r], qs, qh, sc, row * nb + b);
+            }
+            alo[u] = reinterpret_cast<const int4 *>(xq)[2 * b];
+            ahi[u] = reinterpret_cast<const int4 *>(xq)[2 * b + 1];
+            dx[u] = xd[b]; sx[u] = xs[b]; asum[u] = xi[b];
         }
+        __builtin_amdgcn_sched_barrier(0);  // every load of the step is in flight before the first use
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = blk_fma<FMT>(w[r], alo, ahi, dx, sx, asum, acc[r]);
+        for (int u = 0; u < 2; u++) {
+            const bool valid = b0 + u * WAVE < nb;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                WBlk<FMT> w;
+                unpack_raw<FMT>(w, raw[u][r]);
+                acc[r] = blk_fma<FMT>(w, alo[u], ahi[u], dx[u], sx[u], asum[u], acc[r], valid);
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
