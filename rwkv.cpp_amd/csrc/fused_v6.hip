@@ -79,40 +79,62 @@ __device__ __forceinline__ void qvec_stage(const void * __restrict__ g, void * l
     for (int i = tail0 + threadIdx.x; i < words; i += blockDim.x) reinterpret_cast<int *>(l)[i] = reinterpret_cast<const int *>(g)[i];
 }
 
-// R consecutive rows of a quantised matrix against an activation image in LDS; every lane returns the R row sums.
-template <int FMT, int R>
-__device__ __forceinline__ void rows_dot(const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh, const void * __restrict__ sc,
-                                         int64_t row0, int64_t N, int nb, const QVec & a, int lane, float (&res)[R]) {
+// R consecutive rows of a quantised matrix against an activation image in LDS, U block-steps (64 blocks each) per batch.
+// batch_issue puts every load of the batch in flight (codes, fifth bits, scales of R x U blocks per lane);
+// batch_consume decodes and accumulates them in increasing block order (the specified order). Kernels issue the first
+// batch BEFORE their prologue (LayerNorm / activation staging), so the weight stream overlaps it.
+template <int FMT, int R, int U>
+struct Batch { RawBlk<FMT> raw[U][R]; };
+
+template <int FMT, int R, int U>
+__device__ __forceinline__ void batch_issue(Batch<FMT, R, U> & bt, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
+                                            const void * __restrict__ sc, int64_t row0, int64_t N, int nb, int bbase, int lane) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int bb = bbase + u * WAVE + lane;
+        const int b = bb < nb ? bb : nb - 1;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
+            load_raw<FMT>(bt.raw[u][r], qs, qh, sc, row * nb + b);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int FMT, int R, int U>
+__device__ __forceinline__ void batch_consume(const Batch<FMT, R, U> & bt, int nb, int bbase, int lane, const QVec & a, float (&acc)[R]) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int bb = bbase + u * WAVE + lane;
+        const bool valid = bb < nb;
+        const int b = valid ? bb : nb - 1;
+        const int4 alo = *reinterpret_cast<const int4 *>(a.q + b * 16);
+        const int4 ahi = *reinterpret_cast<const int4 *>(a.q + nb * 16 + b * 16);
+        const float dx = a.d[b], sx = a.s[b];
+        const int asum = a.isum[b];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            WBlk<FMT> w;
+            unpack_raw<FMT>(w, bt.raw[u][r]);
+            acc[r] = blk_fma<FMT>(w, alo, ahi, dx, sx, asum, acc[r], valid);
+        }
+    }
+}
+
+// remaining batches after the first one, then the butterfly; every lane returns the R row sums
+template <int FMT, int R, int U>
+__device__ __forceinline__ void rows_finish(Batch<FMT, R, U> & bt, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
+                                            const void * __restrict__ sc, int64_t row0, int64_t N, int nb, const QVec & a, int lane, float (&res)[R]) {
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
-    for (int b0 = lane; b0 < nb; b0 += 2 * WAVE) {
-        RawBlk<FMT> raw[2][R];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int b = b0 + u * WAVE < nb ? b0 + u * WAVE : nb - 1;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
-                load_raw<FMT>(raw[u][r], qs, qh, sc, row * nb + b);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // every load of the step is in flight before the first use
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const bool valid = b0 + u * WAVE < nb;
-            const int b = valid ? b0 + u * WAVE : nb - 1;
-            const int4 alo = *reinterpret_cast<const int4 *>(a.q + b * 16);
-            const int4 ahi = *reinterpret_cast<const int4 *>(a.q + nb * 16 + b * 16);
-            const float dx = a.d[b], sx = a.s[b];
-            const int asum = a.isum[b];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                WBlk<FMT> w;
-                unpack_raw<FMT>(w, raw[u][r]);
-                acc[r] = blk_fma<FMT>(w, alo, ahi, dx, sx, asum, acc[r], valid);
-            }
-        }
+    int bbase = 0;
+    for (;;) {
+        batch_consume<FMT, R, U>(bt, nb, bbase, lane, a, acc);
+        bbase += U * WAVE;
+        if (bbase >= nb) break;
+        batch_issue<FMT, R, U>(bt, qs, qh, sc, row0, N, nb, bbase, lane);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
@@ -172,6 +194,10 @@ __global__ __launch_bounds__(256) void k6_att_prep(P6A p) {
     unsigned char * l_qv = smem + D * 4;
     double * red = reinterpret_cast<double *>(l_qv + ((qvec_bytes(D) + 15) / 16) * 16);
     const QVec lq = qvec_at(l_qv, D);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t) blockIdx.x * 4 + wave;
+    Batch<FMT, 1, 2> bt;
+    batch_issue<FMT, 1, 2>(bt, p.w1.qs, p.w1.qh, p.w1.sc, row < p.n_rows ? row : p.n_rows - 1, p.n_rows, nb, 0, lane);
     fill_row(l_row, p.x, D);
     __syncthreads();
     const float scale = block_ln_stats(l_row, D, red);
@@ -198,11 +224,9 @@ __global__ __launch_bounds__(256) void k6_att_prep(P6A p) {
     }
     for (; i0 < D; i0 += 256) elem(i0, p.ln_w[i0], p.ln_b[i0], p.att_xx_in[i0], p.maa_x[i0]);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row = (int64_t) blockIdx.x * 4 + wave;
     if (row >= p.n_rows) return;
     float res[1];
-    rows_dot<FMT, 1>(p.w1.qs, p.w1.qh, p.w1.sc, row, p.n_rows, nb, lq, lane, res);
+    rows_finish<FMT, 1, 2>(bt, p.w1.qs, p.w1.qh, p.w1.sc, row, p.n_rows, nb, lq, lane, res);
     if (lane == 0) p.tl[row] = det_tanhf(res[0]);
 }
 
@@ -252,7 +276,7 @@ struct P6C {
 };
 
 template <int FMT>
-__global__ __launch_bounds__(256) void k6_rkvgw(P6C p) {
+__global__ __launch_bounds__(256, 3) void k6_rkvgw(P6C p) {  // 3 workgroups per CU: the whole grid (~2 per CU) is resident at once
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int64_t D = p.D;
     const int nb = (int) (D / 32);
@@ -261,15 +285,17 @@ __global__ __launch_bounds__(256) void k6_rkvgw(P6C p) {
     int64_t grp = blockIdx.x - (int64_t) mat * G;
     if (mat > 4) { mat = 4; grp = blockIdx.x - 4 * G; }
     const int act = (0x04213 >> (4 * mat)) & 0xF;  // projection r,k,v,g,decay -> mix output index (w,k,v,r,g order): 3,1,2,4,0
-    qvec_stage((const unsigned char *) p.act + (size_t) act * p.act_stride, smem, D);
-    __syncthreads();
-    const QVec la = qvec_at(smem, D);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t N = mat == 4 ? p.DR : D;
     const int64_t row0 = grp * 32 + wave * 8;
+    Batch<FMT, 8, 2> bt;
+    batch_issue<FMT, 8, 2>(bt, p.w[mat].qs, p.w[mat].qh, p.w[mat].sc, row0 < N ? row0 : N - 1, N, nb, 0, lane);
+    qvec_stage((const unsigned char *) p.act + (size_t) act * p.act_stride, smem, D);
+    __syncthreads();
+    const QVec la = qvec_at(smem, D);
     if (row0 >= N) return;
     float res[8];
-    rows_dot<FMT, 8>(p.w[mat].qs, p.w[mat].qh, p.w[mat].sc, row0, N, nb, la, lane, res);
+    rows_finish<FMT, 8, 2>(bt, p.w[mat].qs, p.w[mat].qh, p.w[mat].sc, row0, N, nb, la, lane, res);
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -374,17 +400,20 @@ struct P6E {
     int64_t N, K;
 };
 
-template <int FMT, int R>
+template <int FMT, int R, int U>
 __global__ __launch_bounds__(256) void k6_proj_res(P6E p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t) blockIdx.x * 4 + wave) * R;
+    const int nb = (int) (p.K / 32);
+    Batch<FMT, R, U> bt;
+    batch_issue<FMT, R, U>(bt, p.w.qs, p.w.qh, p.w.sc, row0 < p.N ? row0 : p.N - 1, p.N, nb, 0, lane);
     qvec_stage(p.act, smem, p.K);
     __syncthreads();
     const QVec la = qvec_at(smem, p.K);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = ((int64_t) blockIdx.x * 4 + wave) * R;
     if (row0 >= p.N) return;
     float res[R];
-    rows_dot<FMT, R>(p.w.qs, p.w.qh, p.w.sc, row0, p.N, (int) (p.K / 32), la, lane, res);
+    rows_finish<FMT, R, U>(bt, p.w.qs, p.w.qh, p.w.sc, row0, p.N, nb, la, lane, res);
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -410,7 +439,7 @@ struct P6F {
 };
 
 template <int FMT>
-__global__ __launch_bounds__(256) void k6_ffn_kr(P6F p) {
+__global__ __launch_bounds__(256, 3) void k6_ffn_kr(P6F p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float l_out[32];
     const int64_t D = p.D, F = p.F;
@@ -421,6 +450,15 @@ __global__ __launch_bounds__(256) void k6_ffn_kr(P6F p) {
     unsigned char * l_r = l_k + qb;
     double * red = reinterpret_cast<double *>(l_r + qb);
     const QVec qk = qvec_at(l_k, D), qr = qvec_at(l_r, D);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t GK = F / 32;
+    const bool is_key = (int64_t) blockIdx.x < GK;
+    const int64_t grp = is_key ? blockIdx.x : blockIdx.x - GK;
+    const int64_t N = is_key ? F : D;
+    const WPl & w = is_key ? p.wk : p.wr;
+    const int64_t row0 = grp * 32 + wave * 8;
+    Batch<FMT, 8, 2> bt;
+    batch_issue<FMT, 8, 2>(bt, w.qs, w.qh, w.sc, row0, N, nb, 0, lane);
     fill_row(l_row, p.x, D);
     __syncthreads();
     const float scale = block_ln_stats(l_row, D, red);
@@ -451,15 +489,8 @@ __global__ __launch_bounds__(256) void k6_ffn_kr(P6F p) {
     }
     for (; i0 < D; i0 += 256) elem(i0, p.ln_w[i0], p.ln_b[i0], p.ffn_xx_in[i0], p.maa_k[i0], p.maa_r[i0]);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t GK = F / 32;
-    const bool is_key = (int64_t) blockIdx.x < GK;
-    const int64_t grp = is_key ? blockIdx.x : blockIdx.x - GK;
-    const int64_t N = is_key ? F : D;
-    const WPl & w = is_key ? p.wk : p.wr;
-    const int64_t row0 = grp * 32 + wave * 8;
     float res[8];
-    rows_dot<FMT, 8>(w.qs, w.qh, w.sc, row0, N, nb, is_key ? qk : qr, lane, res);
+    rows_finish<FMT, 8, 2>(bt, w.qs, w.qh, w.sc, row0, N, nb, is_key ? qk : qr, lane, res);
     if (!is_key) {
         if (lane == 0) {
 #pragma unroll
@@ -568,14 +599,14 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
     else launch6(pf, 0, k6_wkv<FMT, 2>, dim3((unsigned) H), dim3(64), 0, st, d);
 
     P6E e{planes(L.att_output), s.yq, x, nullptr, D, D};
-    launch6(pf, L.att_output->nbytes + actD + D * 8, k6_proj_res<FMT, 4>, dim3((unsigned) ((D + 15) / 16)), dim3(256), qbD, st, e);
+    launch6(pf, L.att_output->nbytes + actD + D * 8, k6_proj_res<FMT, 4, 2>, dim3((unsigned) ((D + 15) / 16)), dim3(256), qbD, st, e);
 
     P6F ff{x, f(L.ln2_w), f(L.ln2_b), sin, f(L.ffn_time_maa_k), f(L.ffn_time_maa_r), sout, planes(L.ffn_key), planes(L.ffn_receptance), s.kq, s.rr, D, F};
     launch6(pf, L.ffn_key->nbytes + L.ffn_receptance->nbytes + D * 12 + qvec_bytes(F) + D * 4, k6_ffn_kr<FMT>, dim3((unsigned) (F / 32 + D / 32)), dim3(256),
             (size_t) D * 4 + 2 * qbD + 257 * 8, st, ff);
 
     P6E g{planes(L.ffn_value), s.kq, x, s.rr, D, F};
-    launch6(pf, L.ffn_value->nbytes + qvec_bytes(F) + D * 12, k6_proj_res<FMT, 4>, dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);
+    launch6(pf, L.ffn_value->nbytes + qvec_bytes(F) + D * 12, k6_proj_res<FMT, 4, 4>, dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);
 }
 
 void fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf) {

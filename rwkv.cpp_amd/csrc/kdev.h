@@ -186,10 +186,9 @@ template <> struct QF<T_Q8_0> { static constexpr int QS = 32; static constexpr b
 // sinks the scale loads behind the dot products and every step pays two dependent memory round trips.
 template <int FMT>
 struct RawBlk {
-    int4 q0;
-    int4 q1;        // Q8_0 only
-    unsigned qh;    // Q5 only
-    unsigned sc;    // fp16 d in the low half (+ fp16 m in the high half for Q4_1 / Q5_1)
+    int4 q[QF<FMT>::QS / 16];   // 16 B of codes (32 B for Q8_0)
+    unsigned qh;                // Q5 only (never touched otherwise)
+    unsigned sc;                // fp16 d in the low half (+ fp16 m in the high half for Q4_1 / Q5_1)
 };
 
 template <int FMT>
@@ -197,13 +196,12 @@ __device__ __forceinline__ void load_raw(RawBlk<FMT> & r, const uint8_t * __rest
                                          const void * __restrict__ sc, int64_t blk) {
     if constexpr (QF<FMT>::HM) r.sc = reinterpret_cast<const uint32_t *>(sc)[blk];
     else r.sc = reinterpret_cast<const uint16_t *>(sc)[blk];
-    if constexpr (QF<FMT>::QH) r.qh = qh[blk]; else r.qh = 0;
+    if constexpr (QF<FMT>::QH) r.qh = qh[blk];
     if constexpr (QF<FMT>::QS == 32) {
-        r.q0 = *reinterpret_cast<const int4 *>(qs + blk * 32);
-        r.q1 = *reinterpret_cast<const int4 *>(qs + blk * 32 + 16);
+        r.q[0] = *reinterpret_cast<const int4 *>(qs + blk * 32);
+        r.q[1] = *reinterpret_cast<const int4 *>(qs + blk * 32 + 16);
     } else {
-        r.q0 = *reinterpret_cast<const int4 *>(qs + blk * 16);
-        r.q1 = make_int4(0, 0, 0, 0);
+        r.q[0] = *reinterpret_cast<const int4 *>(qs + blk * 16);
     }
 }
 
@@ -218,10 +216,10 @@ struct WBlk {
 template <int FMT>
 __device__ __forceinline__ void unpack_raw(WBlk<FMT> & w, const RawBlk<FMT> & r) {
     if constexpr (QF<FMT>::QS == 32) {
-        w.c[0] = r.q0.x; w.c[1] = r.q0.y; w.c[2] = r.q0.z; w.c[3] = r.q0.w;
-        w.c[4] = r.q1.x; w.c[5] = r.q1.y; w.c[6] = r.q1.z; w.c[7] = r.q1.w;
+        w.c[0] = r.q[0].x; w.c[1] = r.q[0].y; w.c[2] = r.q[0].z; w.c[3] = r.q[0].w;
+        w.c[4] = r.q[1].x; w.c[5] = r.q[1].y; w.c[6] = r.q[1].z; w.c[7] = r.q[1].w;
     } else {
-        const int raw[4] = {r.q0.x, r.q0.y, r.q0.z, r.q0.w};
+        const int raw[4] = {r.q[0].x, r.q[0].y, r.q[0].z, r.q[0].w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             int lo = raw[i] & 0x0F0F0F0F;
