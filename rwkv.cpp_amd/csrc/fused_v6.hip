@@ -129,12 +129,11 @@ __device__ __forceinline__ void rows_finish(Batch<FMT, R, U> & bt, const uint8_t
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
-    int bbase = 0;
-    for (;;) {
-        batch_consume<FMT, R, U>(bt, nb, bbase, lane, a, acc);
-        bbase += U * WAVE;
-        if (bbase >= nb) break;
-        batch_issue<FMT, R, U>(bt, qs, qh, sc, row0, N, nb, bbase, lane);
+    batch_consume<FMT, R, U>(bt, nb, 0, lane, a, acc);
+    for (int bbase = U * WAVE; bbase < nb; bbase += U * WAVE) {  // further batches live in their own registers
+        Batch<FMT, R, U> nx;
+        batch_issue<FMT, R, U>(nx, qs, qh, sc, row0, N, nb, bbase, lane);
+        batch_consume<FMT, R, U>(nx, nb, bbase, lane, a, acc);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
@@ -276,7 +275,7 @@ struct P6C {
 };
 
 template <int FMT>
-__global__ __launch_bounds__(256, 3) void k6_rkvgw(P6C p) {  // 3 workgroups per CU: the whole grid (~2 per CU) is resident at once
+__global__ __launch_bounds__(256) void k6_rkvgw(P6C p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int64_t D = p.D;
     const int nb = (int) (D / 32);
@@ -439,7 +438,7 @@ struct P6F {
 };
 
 template <int FMT>
-__global__ __launch_bounds__(256, 3) void k6_ffn_kr(P6F p) {
+__global__ __launch_bounds__(256) void k6_ffn_kr(P6F p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float l_out[32];
     const int64_t D = p.D, F = p.F;
