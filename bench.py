@@ -103,7 +103,7 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl")
 
     def barrier():
         if dist is not None:

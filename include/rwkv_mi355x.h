@@ -46,6 +46,24 @@ RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major
 /* Single-token steps are replayed from a captured hipGraph by default; disable for debugging / profiling per kernel. */
 RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled);
 
+/* ---- layer pipeline: one process per GPU, each owning layers [layer_begin, layer_end) and their slice of the state ----
+ * (supersedes the reference's n_gpu_layers CPU/GPU split, rwkv_model_loading.inc:129-142). The hand-off of the residual
+ * stream between stages is the caller's job (RCCL send/recv over xGMI, see rwkv.cpp_amd/pipeline.py). */
+
+/* Loads only the tensors of layers [layer_begin, layer_end) (plus emb + ln0 on the first stage, ln_out + head on the last). */
+RWKV_API struct rwkv_context * rwkv_mi_init_stage(const char * model_file_path, uint32_t n_threads, uint32_t layer_begin, uint32_t layer_end);
+/* Runs every later call of this context on the given hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+RWKV_API bool rwkv_mi_set_stream(struct rwkv_context * ctx, void * hip_stream);
+/* Floats in one hand-off message: n_embed, or 2 * n_embed for RWKV-7 (x and v_first). */
+RWKV_API size_t rwkv_mi_handoff_len(const struct rwkv_context * ctx);
+RWKV_API void rwkv_mi_stage_range(const struct rwkv_context * ctx, uint32_t * layer_begin, uint32_t * layer_end);
+/* One single-token step of the stage on its stream, not synchronised. First stage: token id read from device memory
+ * (d_token). Other stages: residual stream from x_in (device). Not last: writes x_out (device). Last: ln_out + head,
+ * argmax into d_next_token (device, may be NULL). State stays resident (use rwkv_mi_state_load(ctx, NULL) to reset). */
+RWKV_API bool rwkv_mi_stage_step(struct rwkv_context * ctx, const uint32_t * d_token, const float * x_in, float * x_out, uint32_t * d_next_token);
+/* Device pointer of the context's logits (n_vocab floats), valid after a step that produced logits. */
+RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx);
+
 /* Test hook (used by tests/ only): the activation quantiser; n multiple of 32; d, s, isum have n/32 entries. */
 RWKV_API bool rwkv_mi_test_quantize_act(const float * x, int64_t n, int8_t * q, float * d, float * s, int32_t * isum);
 

@@ -959,36 +959,57 @@ static void ffn(orc_model * m, const orc_layer * L, orc_work * wk, float * st) {
     }
 }
 
-/* rwkv_build_serial_graph (:611-720): embedding, ln0, layer loop, ln_out + head. `state` is updated in place. */
-static int eval_inplace(orc_model * m, uint32_t token, float * state, float * logits_out) {
-    if (token >= m->n_vocab) return 1;
+/* One pipeline stage: layers [lb, le) of the serial graph (rwkv_graph.inc:611-720). The first stage starts from the
+ * token (embedding + ln0), later stages from the residual stream handed over in xio (D floats, plus D floats of v_first
+ * for v7); the last stage finishes with ln_out + head. `state` (full layout) is updated in place for the stage's layers. */
+static int eval_stage_inplace(orc_model * m, uint32_t lb, uint32_t le, uint32_t token, float * xio, float * state, float * logits_out) {
     orc_work wk; get_work(m, &wk);
     const int64_t D = m->n_embed;
-    /* ggml_get_rows (:655): F16 rows are converted to f32 */
-    if (m->emb->type == ORC_F32 || m->emb->type == ORC_F16) {
-        orc_dequantize_row(m->emb->type, m->emb->data + (size_t) token * (size_t) D * orc_type_size(m->emb->type), wk.x, D);
+    if (lb == 0) {
+        if (token >= m->n_vocab) return 1;
+        /* ggml_get_rows (:655): F16 rows are converted to f32 */
+        if (m->emb->type == ORC_F32 || m->emb->type == ORC_F16) {
+            orc_dequantize_row(m->emb->type, m->emb->data + (size_t) token * (size_t) D * orc_type_size(m->emb->type), wk.x, D);
+        } else {
+            orc_dequantize_row(m->emb->type, m->emb->data + (size_t) token * (size_t)(D / QK) * orc_type_size(m->emb->type), wk.x, D);
+        }
+        layer_norm(wk.x, m->ln0_w, m->ln0_b, wk.xn, D);
+        memcpy(wk.x, wk.xn, (size_t) D * 4);
     } else {
-        orc_dequantize_row(m->emb->type, m->emb->data + (size_t) token * (size_t)(D / QK) * orc_type_size(m->emb->type), wk.x, D);
+        memcpy(wk.x, xio, (size_t) D * 4);
+        if (m->arch_major == 7) memcpy(wk.v_first, xio + D, (size_t) D * 4);
     }
-    layer_norm(wk.x, m->ln0_w, m->ln0_b, wk.xn, D);
-    memcpy(wk.x, wk.xn, (size_t) D * 4);
     const size_t per_layer = (m->arch_major >= 5) ? (size_t) D * (2 + (size_t) m->head_size) : (size_t) D * 5;
-    for (int i = 0; i < (int) m->n_layer; i++) {
+    for (uint32_t i = lb; i < le; i++) {
         float * st = state + (size_t) i * per_layer;
         const orc_layer * L = &m->layers[i];
         switch (m->arch_major) {
             case 4: att_v4(m, L, &wk, st); break;
             case 5: att_v5(m, L, &wk, st); break;
             case 6: att_v6(m, L, &wk, st); break;
-            case 7: att_v7(m, L, &wk, st, i); break;
+            case 7: att_v7(m, L, &wk, st, (int) i); break;
         }
         ffn(m, L, &wk, st);
     }
-    if (logits_out) {
-        layer_norm(wk.x, m->ln_out_w, m->ln_out_b, wk.xn, D);
-        orc_mul_mat(m->head->type, m->head->data, D, m->n_vocab, wk.xn, 1, logits_out);
+    if (le == m->n_layer) {
+        if (logits_out) {
+            layer_norm(wk.x, m->ln_out_w, m->ln_out_b, wk.xn, D);
+            orc_mul_mat(m->head->type, m->head->data, D, m->n_vocab, wk.xn, 1, logits_out);
+        }
+    } else if (xio) {
+        memcpy(xio, wk.x, (size_t) D * 4);
+        if (m->arch_major == 7) memcpy(xio + D, wk.v_first, (size_t) D * 4);
     }
     return 0;
+}
+
+int orc_eval_stage(orc_model * m, uint32_t layer_begin, uint32_t layer_end, uint32_t token, float * xio, float * state, float * logits_out) {
+    if (layer_begin >= layer_end || layer_end > m->n_layer) return 1;
+    return eval_stage_inplace(m, layer_begin, layer_end, token, xio, state, logits_out);
+}
+
+static int eval_inplace(orc_model * m, uint32_t token, float * state, float * logits_out) {
+    return eval_stage_inplace(m, 0, m->n_layer, token, NULL, state, logits_out);
 }
 
 /* rwkv_eval (rwkv_eval.inc:38-76) */

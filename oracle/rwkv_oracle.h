@@ -47,6 +47,11 @@ void        orc_set_threads(int n);
 int orc_eval(orc_model * m, uint32_t token, const float * state_in, float * state_out, float * logits_out);
 int orc_eval_sequence(orc_model * m, const uint32_t * tokens, size_t n, const float * state_in, float * state_out, float * logits_out);
 
+/* One pipeline stage (layers [layer_begin, layer_end)) of a single-token step; `state` (full layout) is updated in place.
+ * layer_begin == 0 starts from `token`, otherwise from xio (D floats, + D floats of v_first for v7); unless the stage is the
+ * last one the outgoing residual stream is written back to xio; the last stage writes logits_out (may be NULL). */
+int orc_eval_stage(orc_model * m, uint32_t layer_begin, uint32_t layer_end, uint32_t token, float * xio, float * state, float * logits_out);
+
 /* primitives (row-wise, n multiple of 32 for quantised types) */
 size_t orc_type_size(int type);   /* bytes per block */
 int    orc_block_size(int type);  /* elements per block */

@@ -303,6 +303,73 @@ RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major
 
 RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled) { ctx->use_graph = enabled; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Layer pipeline (one process per GPU; the hand-off itself is done by the caller with RCCL send/recv)
+// ---------------------------------------------------------------------------------------------------------------
+
+RWKV_API struct rwkv_context * rwkv_mi_init_stage(const char * file_path, uint32_t n_threads, uint32_t layer_begin, uint32_t layer_end) {
+    g_last_error = RWKV_ERROR_NONE;
+    RW_CHECK(RWKV_ERROR_ARGS, nullptr, file_path != nullptr, "model_file_path is NULL");
+    Model * m = load_model(file_path, layer_begin, layer_end);
+    if (!m) return nullptr;
+    return create_context(m, n_threads);
+}
+
+RWKV_API bool rwkv_mi_set_stream(struct rwkv_context * ctx, void * hip_stream) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (ctx->graph_exec[a][b]) { (void) hipGraphExecDestroy(ctx->graph_exec[a][b]); ctx->graph_exec[a][b] = nullptr; }
+    if (ctx->owns_stream && ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t) hip_stream;
+    ctx->owns_stream = false;
+    return true;
+}
+
+RWKV_API size_t rwkv_mi_handoff_len(const struct rwkv_context * ctx) { return (size_t) handoff_len(*ctx->model); }
+
+RWKV_API void rwkv_mi_stage_range(const struct rwkv_context * ctx, uint32_t * layer_begin, uint32_t * layer_end) {
+    if (layer_begin) *layer_begin = ctx->model->layer_begin;
+    if (layer_end) *layer_end = ctx->model->layer_end;
+}
+
+// One single-token step of this stage, everything on the context's stream, nothing synchronised:
+//   first stage : reads the token id from device memory (d_token), runs embedding + its layers
+//   other stages: start from x_in (device, rwkv_mi_handoff_len floats)
+//   not last    : writes the outgoing residual stream to x_out (device)
+//   last stage  : ln_out + head into the context's logits, argmax into d_next_token (device, may be NULL)
+RWKV_API bool rwkv_mi_stage_step(struct rwkv_context * ctx, const uint32_t * d_token, const float * x_in, float * x_out, uint32_t * d_next_token) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    Model & m = *ctx->model;
+    HIP_CTX_OK(ctx, hipSetDevice(m.device));
+    const size_t D = (size_t) m.n_embed();
+    if (!ctx->d_tokens) {  // first use: allocate the token slot
+        const uint32_t zero = 0;
+        if (!upload_tokens(ctx, &zero, 1)) return false;
+    }
+    if (!ensure_scratch(ctx, 1)) return false;
+    if (m.has_embed) {
+        RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, d_token != nullptr, "first stage needs a token");
+        HIP_CTX_OK(ctx, hipMemcpyAsync(ctx->d_tokens, d_token, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, x_in != nullptr, "stage needs x_in");
+        HIP_CTX_OK(ctx, hipMemcpyAsync(ctx->b.x, x_in, D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        if (m.arch_major == 7) HIP_CTX_OK(ctx, hipMemcpyAsync(ctx->b.v_first, x_in + D, D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (!forward_decode(ctx, m.has_head)) return false;
+    if (!m.has_head) {
+        RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, x_out != nullptr, "stage needs x_out");
+        HIP_CTX_OK(ctx, hipMemcpyAsync(x_out, ctx->b.x, D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        if (m.arch_major == 7) HIP_CTX_OK(ctx, hipMemcpyAsync(x_out + D, ctx->b.v_first, D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (d_next_token) {
+        launch_argmax(ctx->d_logits, m.n_vocab(), d_next_token, ctx->stream);
+    }
+    return true;
+}
+
+// device pointer of the context's logits buffer (valid after a last-stage step / any eval that produced logits)
+RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx) { return ctx->d_logits; }
+
 // Test hook: the activation quantiser (f32 -> Q8_0/Q8_1 blocks) on standalone buffers.
 RWKV_API bool rwkv_mi_test_quantize_act(const float * x, int64_t n, int8_t * q, float * d, float * s, int32_t * isum) {
     g_last_error = RWKV_ERROR_NONE;

@@ -73,13 +73,13 @@ void destroy_context(rwkv_context * ctx) {
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->prof.events) (void) hipEventDestroy(e);
-    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    if (ctx->stream && ctx->owns_stream) (void) hipStreamDestroy(ctx->stream);
     release_model(ctx->model);
     delete ctx;
 }
 
 // Scratch for T tokens: one allocation carved into named activations.
-static bool ensure_scratch(rwkv_context * ctx, int64_t T) {
+bool ensure_scratch(rwkv_context * ctx, int64_t T) {
     if (T <= ctx->scratch_T) return true;
     Model & m = *ctx->model;
     const size_t D = (size_t) m.n_embed(), F = (size_t) m.ffn_size;
@@ -305,6 +305,8 @@ struct Runner {
 };
 
 }  // namespace
+
+int64_t handoff_len(const Model & m) { return m.arch_major == 7 ? 2 * m.n_embed() : m.n_embed(); }
 
 bool forward(rwkv_context * ctx, int64_t T, bool want_logits) {
     if (!ensure_scratch(ctx, T)) return false;

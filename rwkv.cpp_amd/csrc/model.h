@@ -79,6 +79,7 @@ struct rwkv_context {
     bool print_errors = false;  // a fresh reference context starts silent (rwkv.cpp:74 value-initialises it)
 
     hipStream_t stream = nullptr;
+    bool owns_stream = true;   // false after rwkv_mi_set_stream (the caller's stream, e.g. torch's current stream)
 
     // Device-resident recurrent state, ping-pong (kernels read [cur], write [cur ^ 1]).
     float * state[2] = {nullptr, nullptr};
@@ -143,5 +144,9 @@ size_t fused_v6_scratch_bytes(const Model & m);
 void   fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
 bool forward_decode(rwkv_context * ctx, bool want_logits);
+// grows the per-context activation scratch to hold T tokens
+bool ensure_scratch(rwkv_context * ctx, int64_t T);
+// hand-off buffer size in floats: D, or 2 D for RWKV-7 (x and v_first travel together)
+int64_t handoff_len(const Model & m);
 
 }  // namespace rwkvmi

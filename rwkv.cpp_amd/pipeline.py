@@ -1,0 +1,257 @@
+"""Layer pipeline across the GPUs of one node: one process per GPU, contiguous layer ranges, residual-stream hand-off with
+send/recv (RCCL over xGMI on MI355X; gloo in the CPU tests).
+
+The reference has no multi-device path beyond a static CPU/GPU layer split on ONE GPU (`n_gpu_layers`,
+rwkv_model_loading.inc:129-142). Single-stream decode cannot be sharded for latency (layers are sequential, every
+token depends on the previous one), so the pipeline buys capacity and THROUGHPUT: with S >= N decode streams in flight
+every stage is busy and the node produces ~N x the tokens/s of one GPU, while each stream still runs at single-GPU
+speed minus the hop latency. Message per hop: n_embed floats (16 KiB for RWKV-6 7B; x and v_first for RWKV-7) forward,
+one token id back from the last stage to the first.
+
+The orchestration below is executor-agnostic: `LibStageExecutor` drives librwkv.so's stage API on a GPU,
+tests/test_pipeline_cpu.py plugs in the CPU oracle to check partitioning and protocol with gloo.
+"""
+import ctypes
+import time
+from typing import List, Optional, Sequence, Tuple
+
+
+def partition_layers(layer_costs: Sequence[float], n_stages: int, head_cost: float = 0.0, embed_cost: float = 0.0) -> List[Tuple[int, int]]:
+    """Contiguous ranges [(begin, end)] minimising the largest stage cost (bytes streamed per token).
+    The embedding cost sits on the first stage, the head cost on the last; every stage owns at least one layer."""
+    n = len(layer_costs)
+    if not 1 <= n_stages <= n:
+        raise ValueError(f"cannot split {n} layers into {n_stages} stages")
+    prefix = [0.0]
+    for c in layer_costs:
+        prefix.append(prefix[-1] + c)
+
+    def cost(b, e, s):
+        return prefix[e] - prefix[b] + (embed_cost if s == 0 else 0.0) + (head_cost if s == n_stages - 1 else 0.0)
+
+    INF = float("inf")
+    # best[s][e]: minimal max-cost of covering layers [0, e) with stages 0..s
+    best = [[INF] * (n + 1) for _ in range(n_stages)]
+    cut = [[0] * (n + 1) for _ in range(n_stages)]
+    for e in range(1, n + 1):
+        best[0][e] = cost(0, e, 0)
+    for s in range(1, n_stages):
+        for e in range(s + 1, n + 1):
+            for b in range(s, e):
+                v = max(best[s - 1][b], cost(b, e, s))
+                if v < best[s][e]:
+                    best[s][e], cut[s][e] = v, b
+    ranges, e = [], n
+    for s in range(n_stages - 1, -1, -1):
+        b = cut[s][e] if s > 0 else 0
+        ranges.append((b, e))
+        e = b
+    return ranges[::-1]
+
+
+class StageExecutor:
+    """What the pipeline needs from a stage. Buffers are torch tensors on the executor's device."""
+    is_first: bool
+    is_last: bool
+    handoff_len: int
+
+    def new_stream(self):            # -> opaque per-decode-stream handle (owns that stream's recurrent state)
+        raise NotImplementedError
+
+    def new_buffers(self):           # -> (x_buffer float32[handoff_len], token_buffer int32[1])
+        raise NotImplementedError
+
+    def step(self, handle, token_buf, x_in, x_out, next_token_buf):   # one single-token step, asynchronous
+        raise NotImplementedError
+
+
+class LibStageExecutor(StageExecutor):
+    """A pipeline stage on the current CUDA device through librwkv.so's stage API (include/rwkv_mi355x.h)."""
+
+    def __init__(self, lib, model_path: str, layer_begin: int, layer_end: int, n_layer: int):
+        import torch
+        self.torch = torch
+        self.lib = lib
+        self.L = lib.library
+        self.is_first = layer_begin == 0
+        self.is_last = layer_end == n_layer
+        self.ctx = self.L.rwkv_mi_init_stage(model_path.encode(), 1, layer_begin, layer_end)
+        if not self.ctx:
+            raise ValueError(f"rwkv_mi_init_stage({layer_begin}, {layer_end}) failed")
+        self.handoff_len = int(self.L.rwkv_mi_handoff_len(self.ctx))
+        self._handles = []
+        self._bind(self.ctx)
+
+    def _bind(self, ctx):
+        # run the library's kernels on torch's current stream so that send/recv and compute are stream-ordered
+        if not self.L.rwkv_mi_set_stream(ctx, ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)):
+            raise ValueError("rwkv_mi_set_stream failed")
+        if not self.L.rwkv_mi_state_load(ctx, None):
+            raise ValueError("rwkv_mi_state_load failed")
+
+    def new_stream(self):
+        if not self._handles:
+            ctx = self.ctx
+        else:
+            ctx = self.L.rwkv_clone_context(self.ctx, 1)   # shares the weights, owns its state
+            if not ctx:
+                raise ValueError("rwkv_clone_context failed")
+            self._bind(ctx)
+        self._handles.append(ctx)
+        return ctx
+
+    def new_buffers(self):
+        t = self.torch
+        return t.zeros(self.handoff_len, dtype=t.float32, device="cuda"), t.zeros(1, dtype=t.int32, device="cuda")
+
+    def reset(self, handle):
+        if not self.L.rwkv_mi_state_load(handle, None):
+            raise ValueError("rwkv_mi_state_load failed")
+
+    def step(self, handle, token_buf, x_in, x_out, next_token_buf):
+        ok = self.L.rwkv_mi_stage_step(
+            handle,
+            ctypes.c_void_p(token_buf.data_ptr()) if self.is_first else None,
+            None if self.is_first else ctypes.c_void_p(x_in.data_ptr()),
+            None if self.is_last else ctypes.c_void_p(x_out.data_ptr()),
+            ctypes.c_void_p(next_token_buf.data_ptr()) if self.is_last else None)
+        if not ok:
+            raise ValueError("rwkv_mi_stage_step failed")
+
+    def bytes_per_token(self) -> int:
+        return int(self.L.rwkv_mi_bytes_per_token(self.ctx))
+
+    def close(self):
+        for h in self._handles[1:]:
+            self.L.rwkv_free(h)
+        self.L.rwkv_free(self.ctx)
+        self._handles = []
+
+
+def run_pipeline(ex: StageExecutor, dist, rank: int, world: int, first_tokens: Sequence[int], n_tokens: int, handles=None,
+                 sync=None, fb_group=None) -> Tuple[Optional[List[List[int]]], float]:
+    """Greedy-decodes len(first_tokens) independent streams for n_tokens tokens each through the pipeline.
+
+    Every rank calls this with the same arguments. Per (token step, stream): the first stage takes the stream's current
+    token (the seed, or the argmax sent back by the last stage), every stage runs its layers and forwards the residual
+    stream, the last stage takes the argmax and returns it to the first. Returns (generated tokens per stream on the LAST
+    rank else None, elapsed seconds of the loop on this rank).
+
+    `fb_group`: process group for the token feedback (last -> first). Pass a SEPARATE group (dist.new_group over all ranks):
+    point-to-point operations of one communicator are serialised per process, and with the forward hops and the feedback
+    on the same communicator a 2-rank pipeline deadlocks (rank 0 queues send x(t, j+1) before recv token(t, j) while rank 1
+    queues send token(t, j) before recv x(t, j+1)). Forward hops form a chain without cycles and stay on the default group.
+    """
+    import torch
+    S = len(first_tokens)
+    handles = handles or [ex.new_stream() for _ in range(S)]
+    bufs = [ex.new_buffers() for _ in range(S)]          # incoming x / current token per stream
+    outs = [ex.new_buffers() for _ in range(S)]          # outgoing x / produced token per stream
+    history = [[] for _ in range(S)]
+    hist_dev = [[] for _ in range(S)]
+    if ex.is_first:
+        for j, tok in enumerate(first_tokens):
+            bufs[j][1].fill_(int(tok))
+    # sends are non-blocking (a blocking send of x(t, j+1) on the first stage and of token(t, j) on the last stage would wait
+    # for each other); a stream's out-buffer is only rewritten after its previous send has completed
+    pending = [None] * S
+    if sync:
+        sync()
+    t0 = time.perf_counter()
+    for t in range(n_tokens):
+        for j in range(S):
+            x_in, tok = bufs[j]
+            x_out, nxt = outs[j]
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
+            if ex.is_first:
+                if t > 0 and world > 1:
+                    dist.recv(tok, src=world - 1, group=fb_group)
+            else:
+                dist.recv(x_in, src=rank - 1)
+            ex.step(handles[j], tok, x_in, x_out, nxt)
+            if ex.is_last:
+                hist_dev[j].append(nxt.clone())
+                if world > 1:
+                    if t < n_tokens - 1:
+                        pending[j] = dist.isend(nxt, dst=0, group=fb_group)
+                else:
+                    tok.copy_(nxt)
+            else:
+                pending[j] = dist.isend(x_out, dst=rank + 1)
+    for j in range(S):
+        if pending[j] is not None:
+            pending[j].wait()
+    if sync:
+        sync()
+    elapsed = time.perf_counter() - t0
+    if ex.is_last:
+        for j in range(S):
+            history[j] = [int(v) for v in torch.stack(hist_dev[j]).flatten().cpu().tolist()]
+        return history, elapsed
+    return None, elapsed
+
+
+def stage_costs(spec, dtype: str):
+    """Per-layer / head / embedding bytes streamed per decoded token for a synthetic spec (used to balance the stages)."""
+    from . import synth
+    bb = {"FP32": 4.0, "FP16": 2.0}
+    q = synth.BLOCK_BYTES.get(dtype)
+    per_w = (q / 32.0) if q else bb[dtype]
+    D, F = spec.n_embed, spec.ffn
+    mats = 4 * D * D + 2 * D * F + (D * D if spec.arch != "7" else 0) + (D * D if spec.arch in ("5.2", "6") else 0)
+    layer = mats * per_w
+    if spec.arch == "6":
+        layer += (5 * spec.mix_rank * D + 2 * spec.decay_rank * D) * per_w + 5 * spec.mix_rank * D * 4
+    state = 2 * D * (2 + spec.head_size) * 4 if spec.arch != "4" else 2 * 5 * D * 4
+    head = D * spec.n_vocab * (2.0 if dtype != "FP32" else 4.0)
+    return [layer + state] * spec.n_layer, head, 0.0
+
+
+def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
+    """bench.py's N > 1 leg: layer pipeline over RCCL, `world` decode streams in flight (plus a single-stream pass)."""
+    import torch
+    costs, head, emb = stage_costs(spec, args.dtype)
+    ranges = partition_layers(costs, world, head_cost=head, embed_cost=emb)
+    lb, le = ranges[rank]
+    ex = LibStageExecutor(lib, path, lb, le, spec.n_layer)
+    first = [(1103515245 * (j + 1)) % spec.n_vocab for j in range(world)]
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    handles = [ex.new_stream() for _ in range(world)]
+    fb = dist.new_group(list(range(world)))   # own communicator (and stream) for the token feedback
+
+    def timed(streams, steps, warmup):
+        hs = handles[:len(streams)]
+        for h in hs:
+            ex.reset(h)
+        if warmup:
+            run_pipeline(ex, dist, rank, world, streams, warmup, handles=hs, sync=sync, fb_group=fb)
+        _, el = run_pipeline(ex, dist, rank, world, streams, steps, handles=hs, sync=sync, fb_group=fb)
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    single = timed(first[:1], args.steps, args.warmup)
+    multi = timed(first, args.steps, args.warmup)
+    bpt = torch.tensor([ex.bytes_per_token()], dtype=torch.float64, device="cuda")
+    dist.all_reduce(bpt, op=dist.ReduceOp.SUM)
+    total_tok_s = world * args.steps / multi
+    result = {
+        "metric": "tokens/sec single-stream decode", "value": total_tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": multi * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int8 x int4 dot, f32 accumulate (Q4_0 weights, Q8_0 activations); f16 head", "data": "synthetic",
+        "config": {"workload": f"{spec.name} {args.dtype} greedy decode, layer pipeline over RCCL send/recv, {world} independent decode "
+                               f"streams in flight (one step = one token on every stream), state resident in HBM",
+                   "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": f"pp{world}", "stage_layers": ranges},
+        "single_stream": {"tokens_per_s": args.steps / single, "ms_per_token": single * 1e3 / args.steps,
+                          "note": "one stream through the same pipeline: layers are sequential, so this cannot exceed the 1-GPU rate"},
+        "hbm": {"algorithmic_bytes_per_token": int(bpt.item()), "achieved_GBps_aggregate": bpt.item() * total_tok_s / 1e9},
+    }
+    ex.close()
+    return result

@@ -92,6 +92,16 @@ class RWKVSharedLibrary:
         L.rwkv_mi_weight_bytes.restype = ctypes.c_uint64
         L.rwkv_mi_get_arch.argtypes = [c_ctx, P_UINT32, P_UINT32, P_UINT32, P_UINT32]
         L.rwkv_mi_get_arch.restype = None
+        L.rwkv_mi_init_stage.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        L.rwkv_mi_init_stage.restype = c_ctx
+        L.rwkv_mi_set_stream.argtypes = [c_ctx, ctypes.c_void_p]
+        L.rwkv_mi_set_stream.restype = ctypes.c_bool
+        L.rwkv_mi_handoff_len.argtypes = [c_ctx]
+        L.rwkv_mi_handoff_len.restype = ctypes.c_size_t
+        L.rwkv_mi_stage_step.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.rwkv_mi_stage_step.restype = ctypes.c_bool
+        L.rwkv_mi_logits_device_ptr.argtypes = [c_ctx]
+        L.rwkv_mi_logits_device_ptr.restype = ctypes.c_void_p
         L.rwkv_mi_set_graph_enabled.argtypes = [c_ctx, ctypes.c_bool]
         L.rwkv_mi_set_graph_enabled.restype = None
 

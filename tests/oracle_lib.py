@@ -47,6 +47,8 @@ def lib():
         L.orc_eval.argtypes = [P, ctypes.c_uint32, P, P, P]
         L.orc_eval_sequence.restype = ctypes.c_int
         L.orc_eval_sequence.argtypes = [P, P, ctypes.c_size_t, P, P, P]
+        L.orc_eval_stage.restype = ctypes.c_int
+        L.orc_eval_stage.argtypes = [P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, P, P, P]
         L.orc_quantize_row.argtypes = [ctypes.c_int, P, P, ctypes.c_int64]
         L.orc_dequantize_row.argtypes = [ctypes.c_int, P, P, ctypes.c_int64]
         L.orc_quantize_act.argtypes = [P, ctypes.c_int64, P, P, P]
@@ -102,6 +104,14 @@ class OracleModel:
         if rc != 0:
             raise ValueError("orc_eval_sequence failed")
         return logits, state_out
+
+    def eval_stage(self, layer_begin, layer_end, token, xio, state, want_logits):
+        """In-place stage step on `state`; returns logits (last stage, when wanted) or None. xio: np.float32 hand-off buffer."""
+        logits = np.empty(self.n_vocab, dtype=np.float32) if (want_logits and layer_end == self.n_layer) else None
+        rc = self._l.orc_eval_stage(self._m, layer_begin, layer_end, int(token), _p(xio), _p(state), _p(logits))
+        if rc != 0:
+            raise ValueError("orc_eval_stage failed")
+        return logits
 
     def free(self):
         if self._m:
