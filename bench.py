@@ -98,12 +98,13 @@ def main():
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1", file=sys.stderr)
     import torch
 
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("RWKV_BENCH_BACKEND", "nccl")   # "gloo" only for smoke-testing the N > 1 path on a single GPU
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=backend)
 
     def barrier():
         if dist is not None:

@@ -144,6 +144,21 @@ def run_pipeline(ex: StageExecutor, dist, rank: int, world: int, first_tokens: S
     """
     import torch
     S = len(first_tokens)
+    # gloo cannot move CUDA tensors point-to-point: stage them through the host (CPU tests and the single-GPU smoke run of
+    # the N > 1 bench path only; on the real node the backend is nccl = RCCL and tensors go GPU to GPU over xGMI)
+    via_host = world > 1 and dist.get_backend() == "gloo"
+
+    def recv(t, src, group=None):
+        if via_host and t.is_cuda:
+            h = torch.empty_like(t, device="cpu")
+            dist.recv(h, src=src, group=group)
+            t.copy_(h)
+        else:
+            dist.recv(t, src=src, group=group)
+
+    def isend(t, dst, group=None):
+        return dist.isend(t.cpu() if (via_host and t.is_cuda) else t, dst=dst, group=group)
+
     handles = handles or [ex.new_stream() for _ in range(S)]
     bufs = [ex.new_buffers() for _ in range(S)]          # incoming x / current token per stream
     outs = [ex.new_buffers() for _ in range(S)]          # outgoing x / produced token per stream
@@ -167,19 +182,19 @@ def run_pipeline(ex: StageExecutor, dist, rank: int, world: int, first_tokens: S
                 pending[j] = None
             if ex.is_first:
                 if t > 0 and world > 1:
-                    dist.recv(tok, src=world - 1, group=fb_group)
+                    recv(tok, world - 1, fb_group)
             else:
-                dist.recv(x_in, src=rank - 1)
+                recv(x_in, rank - 1)
             ex.step(handles[j], tok, x_in, x_out, nxt)
             if ex.is_last:
                 hist_dev[j].append(nxt.clone())
                 if world > 1:
                     if t < n_tokens - 1:
-                        pending[j] = dist.isend(nxt, dst=0, group=fb_group)
+                        pending[j] = isend(nxt, 0, fb_group)
                 else:
                     tok.copy_(nxt)
             else:
-                pending[j] = dist.isend(x_out, dst=rank + 1)
+                pending[j] = isend(x_out, rank + 1)
     for j in range(S):
         if pending[j] is not None:
             pending[j].wait()
@@ -223,6 +238,7 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
         dist.barrier()
         torch.cuda.synchronize()
 
+    red_dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
     handles = [ex.new_stream() for _ in range(world)]
     fb = dist.new_group(list(range(world)))   # own communicator (and stream) for the token feedback
 
@@ -233,13 +249,13 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
         if warmup:
             run_pipeline(ex, dist, rank, world, streams, warmup, handles=hs, sync=sync, fb_group=fb)
         _, el = run_pipeline(ex, dist, rank, world, streams, steps, handles=hs, sync=sync, fb_group=fb)
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     single = timed(first[:1], args.steps, args.warmup)
     multi = timed(first, args.steps, args.warmup)
-    bpt = torch.tensor([ex.bytes_per_token()], dtype=torch.float64, device="cuda")
+    bpt = torch.tensor([ex.bytes_per_token()], dtype=torch.float64, device=red_dev)
     dist.all_reduce(bpt, op=dist.ReduceOp.SUM)
     total_tok_s = world * args.steps / multi
     result = {
