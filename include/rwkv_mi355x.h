@@ -61,6 +61,8 @@ RWKV_API void rwkv_mi_stage_range(const struct rwkv_context * ctx, uint32_t * la
  * (d_token). Other stages: residual stream from x_in (device). Not last: writes x_out (device). Last: ln_out + head,
  * argmax into d_next_token (device, may be NULL). State stays resident (use rwkv_mi_state_load(ctx, NULL) to reset). */
 RWKV_API bool rwkv_mi_stage_step(struct rwkv_context * ctx, const uint32_t * d_token, const float * x_in, float * x_out, uint32_t * d_next_token);
+/* Copies the context's logits (n_vocab floats, from the last step that produced any) to host memory. */
+RWKV_API bool rwkv_mi_logits_store(struct rwkv_context * ctx, float * logits_out);
 /* Device pointer of the context's logits (n_vocab floats), valid after a step that produced logits. */
 RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx);
 

@@ -367,6 +367,14 @@ RWKV_API bool rwkv_mi_stage_step(struct rwkv_context * ctx, const uint32_t * d_t
     return true;
 }
 
+// copies the context's logits (of the last step that produced any) to host memory, synchronising the context's stream
+RWKV_API bool rwkv_mi_logits_store(struct rwkv_context * ctx, float * logits_out) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, logits_out != nullptr, "logits_out is NULL");
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    return fetch_outputs(ctx, nullptr, logits_out);
+}
+
 // device pointer of the context's logits buffer (valid after a last-stage step / any eval that produced logits)
 RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx) { return ctx->d_logits; }
 

@@ -64,6 +64,10 @@ class StageExecutor:
     def step(self, handle, token_buf, x_in, x_out, next_token_buf):   # one single-token step, asynchronous
         raise NotImplementedError
 
+    def stream_context(self):        # context manager making the executor's device stream current (no-op on CPU)
+        import contextlib
+        return contextlib.nullcontext()
+
 
 class LibStageExecutor(StageExecutor):
     """A pipeline stage on the current CUDA device through librwkv.so's stage API (include/rwkv_mi355x.h)."""
@@ -80,11 +84,17 @@ class LibStageExecutor(StageExecutor):
             raise ValueError(f"rwkv_mi_init_stage({layer_begin}, {layer_end}) failed")
         self.handoff_len = int(self.L.rwkv_mi_handoff_len(self.ctx))
         self._handles = []
+        # A dedicated (non-default) torch stream: the library's kernels, the hipGraph replays and the send/recv of the hand-off
+        # are all ordered on it (the legacy default stream cannot be captured into a graph).
+        self.stream = torch.cuda.Stream()
         self._bind(self.ctx)
 
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
     def _bind(self, ctx):
-        # run the library's kernels on torch's current stream so that send/recv and compute are stream-ordered
-        if not self.L.rwkv_mi_set_stream(ctx, ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)):
+        self.L.rwkv_set_print_errors(ctx, True)
+        if not self.L.rwkv_mi_set_stream(ctx, ctypes.c_void_p(self.stream.cuda_stream)):
             raise ValueError("rwkv_mi_set_stream failed")
         if not self.L.rwkv_mi_state_load(ctx, None):
             raise ValueError("rwkv_mi_state_load failed")
@@ -142,6 +152,11 @@ def run_pipeline(ex: StageExecutor, dist, rank: int, world: int, first_tokens: S
     on the same communicator a 2-rank pipeline deadlocks (rank 0 queues send x(t, j+1) before recv token(t, j) while rank 1
     queues send token(t, j) before recv x(t, j+1)). Forward hops form a chain without cycles and stay on the default group.
     """
+    with ex.stream_context():
+        return _run_pipeline(ex, dist, rank, world, first_tokens, n_tokens, handles, sync, fb_group)
+
+
+def _run_pipeline(ex, dist, rank, world, first_tokens, n_tokens, handles, sync, fb_group):
     import torch
     S = len(first_tokens)
     # gloo cannot move CUDA tensors point-to-point: stage them through the host (CPU tests and the single-GPU smoke run of

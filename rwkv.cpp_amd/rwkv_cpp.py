@@ -100,6 +100,8 @@ class RWKVSharedLibrary:
         L.rwkv_mi_handoff_len.restype = ctypes.c_size_t
         L.rwkv_mi_stage_step.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.rwkv_mi_stage_step.restype = ctypes.c_bool
+        L.rwkv_mi_logits_store.argtypes = [c_ctx, P_FLOAT]
+        L.rwkv_mi_logits_store.restype = ctypes.c_bool
         L.rwkv_mi_logits_device_ptr.argtypes = [c_ctx]
         L.rwkv_mi_logits_device_ptr.restype = ctypes.c_void_p
         L.rwkv_mi_set_graph_enabled.argtypes = [c_ctx, ctypes.c_bool]

@@ -18,6 +18,14 @@ _lib = None
 def library():
     global _lib
     if _lib is None:
+        # When torch is going to touch the GPU in this process it must initialise HIP BEFORE librwkv.so is loaded: torch wheels
+        # bundle their own libamdhip64 and a second runtime loaded afterwards finds "No HIP GPUs" (same soname, first one wins).
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
         pkg.build_library()
         _lib = pkg.load_rwkv_shared_library()
         L = _lib.library

@@ -25,16 +25,15 @@ def _chain_decode(lib, path, n_layer, cuts, first, n_tokens):
     out = []
     for _ in range(n_tokens):
         for i, s in enumerate(stages):
-            s.step(handles[i], tok, xs[i], xs[i + 1], nxt)
-        torch.cuda.synchronize()
+            s.step(handles[i], tok, xs[i], xs[i + 1], nxt)   # each stage runs on its own stream: synchronise between them
+            torch.cuda.synchronize()
         out.append(int(nxt.item()))
         tok.copy_(nxt)
-    logits = np.empty(lib.rwkv_get_n_vocab(type("C", (), {"ptr": handles[-1]})()), dtype=np.float32)
+        torch.cuda.synchronize()
     import ctypes
-    ptr = lib.library.rwkv_mi_logits_device_ptr(handles[-1])
-    t = torch.empty(logits.size, dtype=torch.float32, device="cuda")
-    ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(ptr), logits.size * 4, 3)
-    logits = t.cpu().numpy()
+    n_vocab = int(lib.library.rwkv_get_n_vocab(handles[-1]))
+    logits = np.empty(n_vocab, dtype=np.float32)
+    assert lib.library.rwkv_mi_logits_store(handles[-1], logits.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     for s in stages:
         s.close()
     return out, logits
