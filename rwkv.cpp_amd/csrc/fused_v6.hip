@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k6_mix2(P6B p) {
     __syncthreads();
     const float * col = p.w2t + (int64_t) f * R * D + d;
     float acc = 0.0f;
-#pragma unroll 16
+#pragma unroll 32
     for (int64_t m = 0; m < R; m++) acc += col[m * D] * l_tl[m];
     const float mm = (acc + p.maa[f][d]) * p.sx[d];
     const float o = mm + p.xn[d];
@@ -435,12 +435,17 @@ struct P6F {
     void * k_out;   // lohi image of F elements (relu(Wk xk)^2 quantised)
     float * r_out;  // D floats (raw Wr xr)
     int64_t D, F;
+    int groups_per_block;
 };
 
+// Workgroup = 8 waves, several 32-row groups (key groups first, then receptance groups). Waves 0-3 run the prologue
+// (its reduction trees are defined for 256 threads); waves 4-7 have nothing to wait for and put their first weight batch in
+// flight immediately -- a wave's vmcnt retires loads in order, so the prologue's own loads must not sit behind weight
+// loads of the same wave. Fat workgroups also cut the replication of the (VALU-heavy) prologue from one per 32 rows to one
+// per CU.
 template <int FMT>
-__global__ __launch_bounds__(256) void k6_ffn_kr(P6F p) {
+__global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float l_out[32];
     const int64_t D = p.D, F = p.F;
     const int nb = (int) (D / 32);
     const size_t qb = ((qvec_bytes(D) + 15) / 16) * 16;
@@ -448,65 +453,92 @@ __global__ __launch_bounds__(256) void k6_ffn_kr(P6F p) {
     unsigned char * l_k = smem + D * 4;
     unsigned char * l_r = l_k + qb;
     double * red = reinterpret_cast<double *>(l_r + qb);
+    float * l_out = reinterpret_cast<float *>(red + 258);
     const QVec qk = qvec_at(l_k, D), qr = qvec_at(l_r, D);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t GK = F / 32;
-    const bool is_key = (int64_t) blockIdx.x < GK;
-    const int64_t grp = is_key ? blockIdx.x : blockIdx.x - GK;
-    const int64_t N = is_key ? F : D;
-    const WPl & w = is_key ? p.wk : p.wr;
-    const int64_t row0 = grp * 32 + wave * 8;
-    Batch<FMT, 8, 2> bt;
-    batch_issue<FMT, 8, 2>(bt, w.qs, w.qh, w.sc, row0, N, nb, 0, lane);
-    fill_row(l_row, p.x, D);
+    const bool pro = threadIdx.x < 256;
+
+    const int64_t GK = F / 32, GT = GK + D / 32;
+    const int gpb = p.groups_per_block;
+    const int64_t g0 = (int64_t) blockIdx.x * gpb;
+    const int ng = (int) ((GT - g0) < gpb ? (GT - g0) : gpb);
+    auto group_w = [&](int64_t g) -> const WPl & { return g < GK ? p.wk : p.wr; };
+    auto group_row0 = [&](int64_t g) { return (g < GK ? g : g - GK) * 32 + wave * 4; };
+    auto group_n = [&](int64_t g) { return g < GK ? F : D; };
+
+    Batch<FMT, 4, 2> cur;
+    if (!pro) { const WPl & w = group_w(g0); batch_issue<FMT, 4, 2>(cur, w.qs, w.qh, w.sc, group_row0(g0), group_n(g0), nb, 0, lane); }
+
+    // ---- prologue (threads 0..255 work, everybody keeps the barriers) ----
+    if (pro) fill_row(l_row, p.x, D);
     __syncthreads();
-    const float scale = block_ln_stats(l_row, D, red);
-    auto elem = [&](int64_t i, float lw, float lb, float pv, float mk, float mr) {
-        const float y = l_row[i] * scale;
-        const float yw = y * lw;
-        const float xn = yw + lb;
-        const float sx = pv - xn;
-        const float sk = sx * mk;
-        const float xk = sk + xn;
-        const float sr = sx * mr;
-        const float xr = sr + xn;
-        if (blockIdx.x == 0) p.ffn_xx_out[i] = xn;
-        int qi, isum; float d16, s16;
-        quant_block32(xk, qi, d16, s16, isum);
-        qvec_store(qk, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
-        quant_block32(xr, qi, d16, s16, isum);
-        qvec_store(qr, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
-    };
-    int64_t i0 = threadIdx.x;
-    for (; i0 + 3 * 256 < D; i0 += 4 * 256) {
-        float lw[4], lb[4], pv[4], mk[4], mr[4];
+    double sacc = 0.0;
+    if (pro) for (int64_t i = threadIdx.x; i < D; i += 256) sacc += (double) l_row[i];
+    const float mean = (float)(block_sum_d_8w(sacc, red) / (double) D);
+    double s2 = 0.0;
+    if (pro) for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
+    const float var = (float)(block_sum_d_8w(s2, red) / (double) D);
+    const float scale = 1.0f / sqrtf(var + 1e-5f);
+    if (pro) {
+        auto elem = [&](int64_t i, float lw, float lb, float pv, float mk, float mr) {
+            const float y = l_row[i] * scale;
+            const float yw = y * lw;
+            const float xn = yw + lb;
+            const float sx = pv - xn;
+            const float sk = sx * mk;
+            const float xk = sk + xn;
+            const float sr = sx * mr;
+            const float xr = sr + xn;
+            if (blockIdx.x == 0) p.ffn_xx_out[i] = xn;
+            int qi, isum; float d16, s16;
+            quant_block32(xk, qi, d16, s16, isum);
+            qvec_store(qk, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
+            quant_block32(xr, qi, d16, s16, isum);
+            qvec_store(qr, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
+        };
+        int64_t i0 = threadIdx.x;
+        for (; i0 + 3 * 256 < D; i0 += 4 * 256) {
+            float lw[4], lb[4], pv[4], mk[4], mr[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * 256; lw[u] = p.ln_w[i]; lb[u] = p.ln_b[i]; pv[u] = p.ffn_xx_in[i]; mk[u] = p.maa_k[i]; mr[u] = p.maa_r[i]; }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * 256; lw[u] = p.ln_w[i]; lb[u] = p.ln_b[i]; pv[u] = p.ffn_xx_in[i]; mk[u] = p.maa_k[i]; mr[u] = p.maa_r[i]; }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; u++) elem(i0 + u * 256, lw[u], lb[u], pv[u], mk[u], mr[u]);
+            for (int u = 0; u < 4; u++) elem(i0 + u * 256, lw[u], lb[u], pv[u], mk[u], mr[u]);
+        }
+        for (; i0 < D; i0 += 256) elem(i0, p.ln_w[i0], p.ln_b[i0], p.ffn_xx_in[i0], p.maa_k[i0], p.maa_r[i0]);
+        const WPl & w = group_w(g0);
+        batch_issue<FMT, 4, 2>(cur, w.qs, w.qh, w.sc, group_row0(g0), group_n(g0), nb, 0, lane);
     }
-    for (; i0 < D; i0 += 256) elem(i0, p.ln_w[i0], p.ln_b[i0], p.ffn_xx_in[i0], p.maa_k[i0], p.maa_r[i0]);
     __syncthreads();
-    float res[8];
-    rows_finish<FMT, 8, 2>(bt, w.qs, w.qh, w.sc, row0, N, nb, is_key ? qk : qr, lane, res);
-    if (!is_key) {
+
+    // ---- rows: consume the group in flight while the next group's first batch is already issued ----
+    for (int gi = 0; gi < ng; gi++) {
+        const int64_t g = g0 + gi;
+        const WPl & w = group_w(g);
+        Batch<FMT, 4, 2> nxt;
+        if (gi + 1 < ng) { const WPl & wn = group_w(g + 1); batch_issue<FMT, 4, 2>(nxt, wn.qs, wn.qh, wn.sc, group_row0(g + 1), group_n(g + 1), nb, 0, lane); }
+        float res[4];
+        rows_finish<FMT, 4, 2>(cur, w.qs, w.qh, w.sc, group_row0(g), group_n(g), nb, g < GK ? qk : qr, lane, res);
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) p.r_out[row0 + r] = res[r];
+            for (int r = 0; r < 4; r++) {
+                if (g < GK) { const float t = res[r] > 0.0f ? res[r] : 0.0f; l_out[gi * 32 + wave * 4 + r] = t * t; }
+                else p.r_out[group_row0(g) + r] = res[r];
+            }
         }
-        return;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) { const float t = res[r] > 0.0f ? res[r] : 0.0f; l_out[wave * 8 + r] = t * t; }
+        if (gi + 1 < ng) cur = nxt;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {  // whole first wave runs the shuffles; lanes 0..31 hold the block
-        const float v = l_out[threadIdx.x & 31];
-        int qi, isum; float d16, s16;
-        quant_block32(v, qi, d16, s16, isum);
-        if (threadIdx.x < 32) qvec_store(qvec_at(p.k_out, F), (int) (F / 32), (int) grp, threadIdx.x, qi, d16, s16, isum);
+    // ---- quantise the key groups (relu^2 outputs) for the value projection: wave 0, one group per pass ----
+    if (threadIdx.x < 64) {
+        for (int gi = 0; gi < ng; gi++) {
+            const int64_t g = g0 + gi;
+            if (g >= GK) break;
+            const float v = l_out[gi * 32 + (threadIdx.x & 31)];
+            int qi, isum; float d16, s16;
+            quant_block32(v, qi, d16, s16, isum);
+            if (threadIdx.x < 32) qvec_store(qvec_at(p.k_out, F), (int) (F / 32), (int) g, threadIdx.x, qi, d16, s16, isum);
+        }
     }
 }
 
@@ -600,9 +632,11 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
     P6E e{planes(L.att_output), s.yq, x, nullptr, D, D};
     launch6(pf, L.att_output->nbytes + actD + D * 8, k6_proj_res<FMT, 4, 2>, dim3((unsigned) ((D + 15) / 16)), dim3(256), qbD, st, e);
 
-    P6F ff{x, f(L.ln2_w), f(L.ln2_b), sin, f(L.ffn_time_maa_k), f(L.ffn_time_maa_r), sout, planes(L.ffn_key), planes(L.ffn_receptance), s.kq, s.rr, D, F};
-    launch6(pf, L.ffn_key->nbytes + L.ffn_receptance->nbytes + D * 12 + qvec_bytes(F) + D * 4, k6_ffn_kr<FMT>, dim3((unsigned) (F / 32 + D / 32)), dim3(256),
-            (size_t) D * 4 + 2 * qbD + 257 * 8, st, ff);
+    const int64_t groups = F / 32 + D / 32;
+    const int gpb = (int) ((groups + 255) / 256);   // at most one workgroup per CU: the prologue runs once per CU
+    P6F ff{x, f(L.ln2_w), f(L.ln2_b), sin, f(L.ffn_time_maa_k), f(L.ffn_time_maa_r), sout, planes(L.ffn_key), planes(L.ffn_receptance), s.kq, s.rr, D, F, gpb};
+    launch6(pf, L.ffn_key->nbytes + L.ffn_receptance->nbytes + D * 12 + qvec_bytes(F) + D * 4, k6_ffn_kr<FMT>, dim3((unsigned) ((groups + gpb - 1) / gpb)), dim3(512),
+            (size_t) D * 4 + 2 * qbD + 258 * 8 + (size_t) gpb * 32 * 4, st, ff);
 
     P6E g{planes(L.ffn_value), s.kq, x, s.rr, D, F};
     launch6(pf, L.ffn_value->nbytes + qvec_bytes(F) + D * 12, k6_proj_res<FMT, 4, 4>, dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);

@@ -154,6 +154,22 @@ __device__ __forceinline__ double block_sum_d(double v, double * red /* [257] */
     return red[256];
 }
 
+// Same tree for a 512-thread workgroup in which only threads 0..255 carry a partial (the others pass anything and just
+// keep the barriers): identical result to block_sum_d.
+__device__ __forceinline__ double block_sum_d_8w(double v, double * red /* [257] */) {
+    __syncthreads();
+    if (threadIdx.x < 256) red[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        double t = (red[i] + red[i + 128]) + (red[i + 64] + red[i + 192]);
+        t = wave_sum_d(t);
+        if (i == 0) red[256] = t;
+    }
+    __syncthreads();
+    return red[256];
+}
+
 __device__ __forceinline__ float apply_epi(const Epi & e, float acc, int64_t t, int64_t n, int64_t ldy) {
     switch (e.op) {
         case EPI_NONE: return acc;
