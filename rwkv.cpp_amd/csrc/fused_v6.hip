@@ -122,18 +122,34 @@ __device__ __forceinline__ void batch_consume(const Batch<FMT, R, U> & bt, int n
     }
 }
 
-// remaining batches after the first one, then the butterfly; every lane returns the R row sums
-template <int FMT, int R, int U>
+// remaining batches after the first one, then the butterfly; every lane returns the R row sums.
+// DB = true keeps TWO batches in flight (the next batch is issued before the current one is consumed): for long rows
+// (channel-mixing value projection, K = 14336) at the price of twice the staging registers.
+template <int FMT, int R, int U, bool DB = false>
 __device__ __forceinline__ void rows_finish(Batch<FMT, R, U> & bt, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
                                             const void * __restrict__ sc, int64_t row0, int64_t N, int nb, const QVec & a, int lane, float (&res)[R]) {
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
-    batch_consume<FMT, R, U>(bt, nb, 0, lane, a, acc);
-    for (int bbase = U * WAVE; bbase < nb; bbase += U * WAVE) {  // further batches live in their own registers
-        Batch<FMT, R, U> nx;
-        batch_issue<FMT, R, U>(nx, qs, qh, sc, row0, N, nb, bbase, lane);
-        batch_consume<FMT, R, U>(nx, nb, bbase, lane, a, acc);
+    if constexpr (!DB) {
+        batch_consume<FMT, R, U>(bt, nb, 0, lane, a, acc);
+        for (int bbase = U * WAVE; bbase < nb; bbase += U * WAVE) {  // further batches live in their own registers
+            Batch<FMT, R, U> nx;
+            batch_issue<FMT, R, U>(nx, qs, qh, sc, row0, N, nb, bbase, lane);
+            batch_consume<FMT, R, U>(nx, nb, bbase, lane, a, acc);
+        }
+    } else {
+        Batch<FMT, R, U> b2;
+        for (int bbase = 0;; bbase += 2 * U * WAVE) {
+            const bool more1 = bbase + U * WAVE < nb;
+            if (more1) batch_issue<FMT, R, U>(b2, qs, qh, sc, row0, N, nb, bbase + U * WAVE, lane);
+            batch_consume<FMT, R, U>(bt, nb, bbase, lane, a, acc);
+            if (!more1) break;
+            const bool more2 = bbase + 2 * U * WAVE < nb;
+            if (more2) batch_issue<FMT, R, U>(bt, qs, qh, sc, row0, N, nb, bbase + 2 * U * WAVE, lane);
+            batch_consume<FMT, R, U>(b2, nb, bbase + U * WAVE, lane, a, acc);
+            if (!more2) break;
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
@@ -399,7 +415,7 @@ struct P6E {
     int64_t N, K;
 };
 
-template <int FMT, int R, int U>
+template <int FMT, int R, int U, bool DB>
 __global__ __launch_bounds__(256) void k6_proj_res(P6E p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(256) void k6_proj_res(P6E p) {
     const QVec la = qvec_at(smem, p.K);
     if (row0 >= p.N) return;
     float res[R];
-    rows_finish<FMT, R, U>(bt, p.w.qs, p.w.qh, p.w.sc, row0, p.N, nb, la, lane, res);
+    rows_finish<FMT, R, U, DB>(bt, p.w.qs, p.w.qh, p.w.sc, row0, p.N, nb, la, lane, res);
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -466,8 +482,15 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
     auto group_row0 = [&](int64_t g) { return (g < GK ? g : g - GK) * 32 + wave * 4; };
     auto group_n = [&](int64_t g) { return g < GK ? F : D; };
 
-    Batch<FMT, 4, 2> cur;
-    if (!pro) { const WPl & w = group_w(g0); batch_issue<FMT, 4, 2>(cur, w.qs, w.qh, w.sc, group_row0(g0), group_n(g0), nb, 0, lane); }
+    constexpr int MAXG = 3;   // groups per workgroup (host guarantees gpb <= MAXG)
+    Batch<FMT, 4, 2> bt[MAXG];
+    auto issue_all = [&]() {
+#pragma unroll
+        for (int gi = 0; gi < MAXG; gi++) {
+            if (gi < ng) { const WPl & w = group_w(g0 + gi); batch_issue<FMT, 4, 2>(bt[gi], w.qs, w.qh, w.sc, group_row0(g0 + gi), group_n(g0 + gi), nb, 0, lane); }
+        }
+    };
+    if (!pro) issue_all();   // waves 4-7: every first batch of every group is in flight during the whole prologue
 
     // ---- prologue (threads 0..255 work, everybody keeps the barriers) ----
     if (pro) fill_row(l_row, p.x, D);
@@ -506,27 +529,26 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
             for (int u = 0; u < 4; u++) elem(i0 + u * 256, lw[u], lb[u], pv[u], mk[u], mr[u]);
         }
         for (; i0 < D; i0 += 256) elem(i0, p.ln_w[i0], p.ln_b[i0], p.ffn_xx_in[i0], p.maa_k[i0], p.maa_r[i0]);
-        const WPl & w = group_w(g0);
-        batch_issue<FMT, 4, 2>(cur, w.qs, w.qh, w.sc, group_row0(g0), group_n(g0), nb, 0, lane);
+        issue_all();
     }
     __syncthreads();
 
-    // ---- rows: consume the group in flight while the next group's first batch is already issued ----
-    for (int gi = 0; gi < ng; gi++) {
-        const int64_t g = g0 + gi;
-        const WPl & w = group_w(g);
-        Batch<FMT, 4, 2> nxt;
-        if (gi + 1 < ng) { const WPl & wn = group_w(g + 1); batch_issue<FMT, 4, 2>(nxt, wn.qs, wn.qh, wn.sc, group_row0(g + 1), group_n(g + 1), nb, 0, lane); }
-        float res[4];
-        rows_finish<FMT, 4, 2>(cur, w.qs, w.qh, w.sc, group_row0(g), group_n(g), nb, g < GK ? qk : qr, lane, res);
-        if (lane == 0) {
+    // ---- rows ----
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (g < GK) { const float t = res[r] > 0.0f ? res[r] : 0.0f; l_out[gi * 32 + wave * 4 + r] = t * t; }
-                else p.r_out[group_row0(g) + r] = res[r];
+    for (int gi = 0; gi < MAXG; gi++) {
+        if (gi < ng) {
+            const int64_t g = g0 + gi;
+            const WPl & w = group_w(g);
+            float res[4];
+            rows_finish<FMT, 4, 2>(bt[gi], w.qs, w.qh, w.sc, group_row0(g), group_n(g), nb, g < GK ? qk : qr, lane, res);
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (g < GK) { const float t = res[r] > 0.0f ? res[r] : 0.0f; l_out[gi * 32 + wave * 4 + r] = t * t; }
+                    else p.r_out[group_row0(g) + r] = res[r];
+                }
             }
         }
-        if (gi + 1 < ng) cur = nxt;
     }
     __syncthreads();
     // ---- quantise the key groups (relu^2 outputs) for the value projection: wave 0, one group per pass ----
@@ -630,16 +652,16 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
     else launch6(pf, 0, k6_wkv<FMT, 2>, dim3((unsigned) H), dim3(64), 0, st, d);
 
     P6E e{planes(L.att_output), s.yq, x, nullptr, D, D};
-    launch6(pf, L.att_output->nbytes + actD + D * 8, k6_proj_res<FMT, 4, 2>, dim3((unsigned) ((D + 15) / 16)), dim3(256), qbD, st, e);
+    launch6(pf, L.att_output->nbytes + actD + D * 8, k6_proj_res<FMT, 4, 2, false>, dim3((unsigned) ((D + 15) / 16)), dim3(256), qbD, st, e);
 
     const int64_t groups = F / 32 + D / 32;
-    const int gpb = (int) ((groups + 255) / 256);   // at most one workgroup per CU: the prologue runs once per CU
+    const int gpb = (int) ((groups + 255) / 256) < 3 ? (int) ((groups + 255) / 256) : 3;   // ~one workgroup per CU: the prologue runs once per CU
     P6F ff{x, f(L.ln2_w), f(L.ln2_b), sin, f(L.ffn_time_maa_k), f(L.ffn_time_maa_r), sout, planes(L.ffn_key), planes(L.ffn_receptance), s.kq, s.rr, D, F, gpb};
     launch6(pf, L.ffn_key->nbytes + L.ffn_receptance->nbytes + D * 12 + qvec_bytes(F) + D * 4, k6_ffn_kr<FMT>, dim3((unsigned) ((groups + gpb - 1) / gpb)), dim3(512),
             (size_t) D * 4 + 2 * qbD + 258 * 8 + (size_t) gpb * 32 * 4, st, ff);
 
     P6E g{planes(L.ffn_value), s.kq, x, s.rr, D, F};
-    launch6(pf, L.ffn_value->nbytes + qvec_bytes(F) + D * 12, k6_proj_res<FMT, 4, 4>, dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);
+    launch6(pf, L.ffn_value->nbytes + qvec_bytes(F) + D * 12, k6_proj_res<FMT, 4, 4, true>, dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);
 }
 
 void fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf) {
