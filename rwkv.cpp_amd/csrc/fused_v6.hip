@@ -55,6 +55,49 @@ __device__ __forceinline__ void quant_block32(float v, int & qi, float & d16, fl
     isum = sum;
 }
 
+// NQ independent blocks at once (one per array slot, each across the half-wave): same arithmetic per block, written stage by
+// stage so that the NQ dependent chains (DPP reductions, two f32 divisions, roundf) interleave instead of running back to back.
+template <int NQ>
+__device__ __forceinline__ void quant_blocks(const float (&v)[NQ], int (&qi)[NQ], float (&d16)[NQ], float (&s16)[NQ], int (&isum)[NQ]) {
+    float am[NQ], dd[NQ], id[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; u++) am[u] = fabsf(v[u]);
+#pragma unroll
+    for (int u = 0; u < NQ; u++) am[u] = fmaxf(am[u], __int_as_float(lane_xor1_i(__float_as_int(am[u]))));
+#pragma unroll
+    for (int u = 0; u < NQ; u++) am[u] = fmaxf(am[u], __int_as_float(lane_xor2_i(__float_as_int(am[u]))));
+#pragma unroll
+    for (int u = 0; u < NQ; u++) am[u] = fmaxf(am[u], __int_as_float(lane_xor4_i(__float_as_int(am[u]))));
+#pragma unroll
+    for (int u = 0; u < NQ; u++) am[u] = fmaxf(am[u], __int_as_float(lane_xor8_i(__float_as_int(am[u]))));
+#pragma unroll
+    for (int u = 0; u < NQ; u++) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(am[u]), __float_as_uint(am[u]), false, false);
+        am[u] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; u++) dd[u] = am[u] / 127.0f;
+#pragma unroll
+    for (int u = 0; u < NQ; u++) id[u] = dd[u] != 0.0f ? 1.0f / dd[u] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < NQ; u++) qi[u] = (int) roundf(v[u] * id[u]);
+#pragma unroll
+    for (int u = 0; u < NQ; u++) isum[u] = qi[u] + lane_xor1_i(qi[u]);
+#pragma unroll
+    for (int u = 0; u < NQ; u++) isum[u] += lane_xor2_i(isum[u]);
+#pragma unroll
+    for (int u = 0; u < NQ; u++) isum[u] += lane_xor4_i(isum[u]);
+#pragma unroll
+    for (int u = 0; u < NQ; u++) isum[u] += lane_xor8_i(isum[u]);
+#pragma unroll
+    for (int u = 0; u < NQ; u++) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned) isum[u], (unsigned) isum[u], false, false);
+        isum[u] = (int) r[0] + (int) r[1];
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; u++) { d16[u] = round_f16(dd[u]); s16[u] = round_f16((float) isum[u] * dd[u]); }
+}
+
 // store one quantised element (block blk, element e) + the block scalars into a lohi image
 __device__ __forceinline__ void qvec_store(const QVec & v, int nb, int blk, int e, int qi, float d16, float s16, int isum) {
     v.q[(e < 16 ? 0 : nb * 16) + blk * 16 + (e & 15)] = (int8_t) qi;
@@ -201,8 +244,9 @@ struct P6A {
 };
 
 template <int FMT>
-__global__ __launch_bounds__(256) void k6_att_prep(P6A p) {
+__global__ __launch_bounds__(1024) void k6_att_prep(P6A p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = 1024;
     const int64_t D = p.D;
     const int nb = (int) (D / 32);
     float * l_row = reinterpret_cast<float *>(smem);
@@ -210,36 +254,50 @@ __global__ __launch_bounds__(256) void k6_att_prep(P6A p) {
     double * red = reinterpret_cast<double *>(l_qv + ((qvec_bytes(D) + 15) / 16) * 16);
     const QVec lq = qvec_at(l_qv, D);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool pro = threadIdx.x < 256;   // the LayerNorm reduction tree is defined over 256 partials
     const int64_t row = (int64_t) blockIdx.x * 4 + wave;
+    const bool has_row = wave < 4 && row < p.n_rows;
     Batch<FMT, 1, 2> bt;
-    batch_issue<FMT, 1, 2>(bt, p.w1.qs, p.w1.qh, p.w1.sc, row < p.n_rows ? row : p.n_rows - 1, p.n_rows, nb, 0, lane);
-    fill_row(l_row, p.x, D);
+    if (wave < 4) batch_issue<FMT, 1, 2>(bt, p.w1.qs, p.w1.qh, p.w1.sc, row < p.n_rows ? row : p.n_rows - 1, p.n_rows, nb, 0, lane);
+    if (pro) fill_row(l_row, p.x, D);
     __syncthreads();
-    const float scale = block_ln_stats(l_row, D, red);
-    auto elem = [&](int64_t i, float lw, float lb, float pv, float mx) {
+    double sacc = 0.0;
+    if (pro) for (int64_t i = threadIdx.x; i < D; i += 256) sacc += (double) l_row[i];
+    const float mean = (float)(block_sum_d_8w(sacc, red) / (double) D);
+    double s2 = 0.0;
+    if (pro) for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
+    const float var = (float)(block_sum_d_8w(s2, red) / (double) D);
+    const float scale = 1.0f / sqrtf(var + 1e-5f);
+    // elementwise + quantise: every thread, 4 independent element steps interleaved
+    auto fin = [&](int64_t i, float lw, float lb, float pv, float mx) -> float {
         const float y = l_row[i] * scale;
         const float yw = y * lw;
         const float xn = yw + lb;
         const float sx = pv - xn;
         const float sm = sx * mx;
-        const float xxx = sm + xn;
         if (blockIdx.x == 0) { p.xn_out[i] = xn; p.sx_out[i] = sx; p.att_xx_out[i] = xn; }
-        int qi, isum; float d16, s16;
-        quant_block32(xxx, qi, d16, s16, isum);
-        qvec_store(lq, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
+        return sm + xn;
     };
     int64_t i0 = threadIdx.x;
-    for (; i0 + 3 * 256 < D; i0 += 4 * 256) {   // four element steps per trip: 16 independent loads in flight
-        float lw[4], lb[4], pv[4], mx[4];
+    for (; i0 + 3 * NT < D; i0 += 4 * NT) {
+        float lw[4], lb[4], pv[4], mx[4], xv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * 256; lw[u] = p.ln_w[i]; lb[u] = p.ln_b[i]; pv[u] = p.att_xx_in[i]; mx[u] = p.maa_x[i]; }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * NT; lw[u] = p.ln_w[i]; lb[u] = p.ln_b[i]; pv[u] = p.att_xx_in[i]; mx[u] = p.maa_x[i]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) elem(i0 + u * 256, lw[u], lb[u], pv[u], mx[u]);
+        for (int u = 0; u < 4; u++) xv[u] = fin(i0 + u * NT, lw[u], lb[u], pv[u], mx[u]);
+        int qi[4], isum[4]; float d16[4], s16[4];
+        quant_blocks<4>(xv, qi, d16, s16, isum);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * NT; qvec_store(lq, nb, (int) (i >> 5), (int) (i & 31), qi[u], d16[u], s16[u], isum[u]); }
     }
-    for (; i0 < D; i0 += 256) elem(i0, p.ln_w[i0], p.ln_b[i0], p.att_xx_in[i0], p.maa_x[i0]);
+    for (; i0 < D; i0 += NT) {   // D % 64 == 0: whole waves in or out
+        const float xxx = fin(i0, p.ln_w[i0], p.ln_b[i0], p.att_xx_in[i0], p.maa_x[i0]);
+        int qi, isum; float d16, s16;
+        quant_block32(xxx, qi, d16, s16, isum);
+        qvec_store(lq, nb, (int) (i0 >> 5), (int) (i0 & 31), qi, d16, s16, isum);
+    }
     __syncthreads();
-    if (row >= p.n_rows) return;
+    if (!has_row) return;
     float res[1];
     rows_finish<FMT, 1, 2>(bt, p.w1.qs, p.w1.qh, p.w1.sc, row, p.n_rows, nb, lq, lane, res);
     if (lane == 0) p.tl[row] = det_tanhf(res[0]);
@@ -454,11 +512,11 @@ struct P6F {
     int groups_per_block;
 };
 
-// Workgroup = 8 waves, several 32-row groups (key groups first, then receptance groups). Waves 0-3 run the prologue
-// (its reduction trees are defined for 256 threads); waves 4-7 have nothing to wait for and put their first weight batch in
-// flight immediately -- a wave's vmcnt retires loads in order, so the prologue's own loads must not sit behind weight
-// loads of the same wave. Fat workgroups also cut the replication of the (VALU-heavy) prologue from one per 32 rows to one
-// per CU.
+// Workgroup = 8 waves owning up to three 32-row groups (key groups first, then receptance groups): about one workgroup per
+// CU, so the VALU-heavy prologue (two f32 divisions, DPP reductions, roundf per element and quantised vector) is replicated
+// once per CU instead of once per 32 rows. Its statistics run on threads 0..255 (the reduction tree is defined over 256
+// partials); the elementwise + quantise part is spread over all 512 threads with four independent chains interleaved per
+// thread (measured: the serial 16-step version of this loop was 2/3 of k6_att_prep's 25k cycles).
 template <int FMT>
 __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -483,6 +541,7 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
     auto group_n = [&](int64_t g) { return g < GK ? F : D; };
 
     constexpr int MAXG = 3;   // groups per workgroup (host guarantees gpb <= MAXG)
+    constexpr int NT = 512;
     Batch<FMT, 4, 2> bt[MAXG];
     auto issue_all = [&]() {
 #pragma unroll
@@ -490,9 +549,8 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
             if (gi < ng) { const WPl & w = group_w(g0 + gi); batch_issue<FMT, 4, 2>(bt[gi], w.qs, w.qh, w.sc, group_row0(g0 + gi), group_n(g0 + gi), nb, 0, lane); }
         }
     };
-    if (!pro) issue_all();   // waves 4-7: every first batch of every group is in flight during the whole prologue
 
-    // ---- prologue (threads 0..255 work, everybody keeps the barriers) ----
+    // ---- prologue: statistics on threads 0..255 (the tree is defined over 256 partials), elementwise + quantise on all ----
     if (pro) fill_row(l_row, p.x, D);
     __syncthreads();
     double sacc = 0.0;
@@ -502,35 +560,42 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
     if (pro) for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
     const float var = (float)(block_sum_d_8w(s2, red) / (double) D);
     const float scale = 1.0f / sqrtf(var + 1e-5f);
-    if (pro) {
-        auto elem = [&](int64_t i, float lw, float lb, float pv, float mk, float mr) {
-            const float y = l_row[i] * scale;
-            const float yw = y * lw;
-            const float xn = yw + lb;
-            const float sx = pv - xn;
-            const float sk = sx * mk;
-            const float xk = sk + xn;
-            const float sr = sx * mr;
-            const float xr = sr + xn;
-            if (blockIdx.x == 0) p.ffn_xx_out[i] = xn;
-            int qi, isum; float d16, s16;
-            quant_block32(xk, qi, d16, s16, isum);
-            qvec_store(qk, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
-            quant_block32(xr, qi, d16, s16, isum);
-            qvec_store(qr, nb, (int) (i >> 5), (int) (i & 31), qi, d16, s16, isum);
-        };
-        int64_t i0 = threadIdx.x;
-        for (; i0 + 3 * 256 < D; i0 += 4 * 256) {
-            float lw[4], lb[4], pv[4], mk[4], mr[4];
+    auto fin = [&](int64_t i, float lw, float lb, float pv, float mk, float mr, float & xk, float & xr) {
+        const float y = l_row[i] * scale;
+        const float yw = y * lw;
+        const float xn = yw + lb;
+        const float sx = pv - xn;
+        const float sk = sx * mk;
+        xk = sk + xn;
+        const float sr = sx * mr;
+        xr = sr + xn;
+        if (blockIdx.x == 0) p.ffn_xx_out[i] = xn;
+    };
+    int64_t i0 = threadIdx.x;
+    for (; i0 + 3 * NT < D; i0 += 4 * NT) {
+        float lw[4], lb[4], pv[4], mk[4], mr[4], xk[4], xr[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * 256; lw[u] = p.ln_w[i]; lb[u] = p.ln_b[i]; pv[u] = p.ffn_xx_in[i]; mk[u] = p.maa_k[i]; mr[u] = p.maa_r[i]; }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * NT; lw[u] = p.ln_w[i]; lb[u] = p.ln_b[i]; pv[u] = p.ffn_xx_in[i]; mk[u] = p.maa_k[i]; mr[u] = p.maa_r[i]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) elem(i0 + u * 256, lw[u], lb[u], pv[u], mk[u], mr[u]);
-        }
-        for (; i0 < D; i0 += 256) elem(i0, p.ln_w[i0], p.ln_b[i0], p.ffn_xx_in[i0], p.maa_k[i0], p.maa_r[i0]);
-        issue_all();
+        for (int u = 0; u < 4; u++) fin(i0 + u * NT, lw[u], lb[u], pv[u], mk[u], mr[u], xk[u], xr[u]);
+        int qi[4], isum[4]; float d16[4], s16[4];
+        quant_blocks<4>(xk, qi, d16, s16, isum);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * NT; qvec_store(qk, nb, (int) (i >> 5), (int) (i & 31), qi[u], d16[u], s16[u], isum[u]); }
+        quant_blocks<4>(xr, qi, d16, s16, isum);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * NT; qvec_store(qr, nb, (int) (i >> 5), (int) (i & 31), qi[u], d16[u], s16[u], isum[u]); }
     }
+    for (; i0 < D; i0 += NT) {
+        float xk, xr;
+        fin(i0, p.ln_w[i0], p.ln_b[i0], p.ffn_xx_in[i0], p.maa_k[i0], p.maa_r[i0], xk, xr);
+        int qi, isum; float d16, s16;
+        quant_block32(xk, qi, d16, s16, isum);
+        qvec_store(qk, nb, (int) (i0 >> 5), (int) (i0 & 31), qi, d16, s16, isum);
+        quant_block32(xr, qi, d16, s16, isum);
+        qvec_store(qr, nb, (int) (i0 >> 5), (int) (i0 & 31), qi, d16, s16, isum);
+    }
+    issue_all();
     __syncthreads();
 
     // ---- rows ----
@@ -634,7 +699,7 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
     const size_t qbD = ((qvec_bytes(D) + 15) / 16) * 16;
 
     P6A a{x, f(L.ln1_w), f(L.ln1_b), sin + D, f(L.att_time_maa_x), sout + D, s.xn, s.sx, planes(L.att_time_maa_w1), R5, s.tl, D};
-    launch6(pf, 0, k6_att_prep<FMT>, dim3((unsigned) ((R5 + 3) / 4)), dim3(256), (size_t) D * 4 + qbD + 257 * 8, st, a);
+    launch6(pf, 0, k6_att_prep<FMT>, dim3((unsigned) ((R5 + 3) / 4)), dim3(1024), (size_t) D * 4 + qbD + 257 * 8, st, a);
 
     P6B b{f(L.att_time_maa_w2), s.tl, {f(L.att_time_maa_w), f(L.att_time_maa_k), f(L.att_time_maa_v), f(L.att_time_maa_r), f(L.att_time_maa_g)},
           s.sx, s.xn, s.act5, D, R, s.act_stride};
