@@ -348,7 +348,15 @@ __device__ __forceinline__ void block_layernorm(float * l_row, int64_t D, const 
     for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
     const float var = (float)(block_sum_d(s2, red) / (double) D);
     const float scale = 1.0f / sqrtf(var + eps);
-    for (int64_t i = threadIdx.x; i < D; i += 256) { const float y = l_row[i] * scale; const float yw = y * w[i]; out[i] = yw + b[i]; }
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 256 < D; i += 4 * 256) {
+        float wv[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { wv[u] = w[i + u * 256]; bv[u] = b[i + u * 256]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const float y = l_row[i + u * 256] * scale; const float yw = y * wv[u]; out[i + u * 256] = yw + bv[u]; }
+    }
+    for (; i < D; i += 256) { const float y = l_row[i] * scale; const float yw = y * w[i]; out[i] = yw + b[i]; }
 }
 
 __global__ __launch_bounds__(256) void k_embed_ln0(EmbView emb, const uint32_t * __restrict__ tokens, int64_t D,
@@ -357,7 +365,17 @@ __global__ __launch_bounds__(256) void k_embed_ln0(EmbView emb, const uint32_t *
     __shared__ double red[257];
     const int64_t t = blockIdx.x;
     const int64_t row = tokens[t];
-    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) l_row[i] = emb_elem(emb, row, D, i);
+    int64_t i = threadIdx.x;
+    if (emb.type == T_F16 || emb.type == T_F32) {
+        for (; i + 3 * 256 < D; i += 4 * 256) {   // 4 loads in flight per trip
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = emb_elem(emb, row, D, i + u * 256);
+#pragma unroll
+            for (int u = 0; u < 4; u++) l_row[i + u * 256] = v[u];
+        }
+    }
+    for (; i < D; i += 256) l_row[i] = emb_elem(emb, row, D, i);
     __syncthreads();
     block_layernorm(l_row, D, w, b, 1e-5f, x + t * D, red);
 }
@@ -367,7 +385,15 @@ __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x,
     extern __shared__ __attribute__((aligned(16))) float l_row[];
     __shared__ double red[257];
     const int64_t t = blockIdx.x;
-    for (int64_t i = threadIdx.x; i < D; i += blockDim.x) l_row[i] = x[t * D + i];
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 256 < D; i += 4 * 256) {   // 4 loads in flight per trip
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = x[t * D + i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 4; u++) l_row[i + u * 256] = v[u];
+    }
+    for (; i < D; i += 256) l_row[i] = x[t * D + i];
     __syncthreads();
     block_layernorm(l_row, D, w, b, 1e-5f, y + t * D, red);
 }
@@ -745,7 +771,15 @@ __global__ __launch_bounds__(1024) void k_argmax(const float * __restrict__ logi
     __shared__ int l_i[16];
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    int64_t i = threadIdx.x;
+    for (; i + 7 * (int64_t) blockDim.x < n; i += 8 * (int64_t) blockDim.x) {   // 8 loads in flight per trip
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = logits[i + u * (int64_t) blockDim.x];
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (v[u] > best) { best = v[u]; bi = (int) (i + u * (int64_t) blockDim.x); }
+    }
+    for (; i < n; i += blockDim.x) {
         const float v = logits[i];
         if (v > best) { best = v; bi = (int) i; }  // strided scan keeps the smallest index per thread for ties
     }
