@@ -224,40 +224,6 @@ __device__ __forceinline__ float block_ln_stats(float * l_row, int64_t D, double
     return 1.0f / sqrtf(var + 1e-5f);
 }
 
-// Weight prefetch: the latency-bound launches (A, B, D) leave most CUs and all of HBM idle; extra workgroups appended to
-// their grids stream the planes the NEXT projection launch will read, so that those lines wait in the Infinity Cache (256 MiB).
-// The loads are plain reads whose values are only folded into a never-true store condition.
-struct PfList {
-    const void * ptr[8];
-    unsigned long long bytes[8];
-    int n;
-    int first_block;   // blockIdx.x >= first_block are prefetch workgroups
-    int n_blocks;
-};
-
-__device__ __forceinline__ void prefetch_regions(const PfList & pf, int * sink) {
-    const int part = (int) blockIdx.x - pf.first_block;
-    int acc = 0;
-    for (int r = 0; r < pf.n; r++) {
-        const int4 * base = reinterpret_cast<const int4 *>(pf.ptr[r]);
-        const long long n16 = (long long) (pf.bytes[r] / 16);
-        long long i = (long long) part * blockDim.x + threadIdx.x;
-        const long long stride = (long long) pf.n_blocks * blockDim.x;
-        for (; i + 3 * stride < n16; i += 4 * stride) {
-            const int4 a = base[i], b = base[i + stride], c = base[i + 2 * stride], d = base[i + 3 * stride];
-            acc ^= a.x ^ b.y ^ c.z ^ d.w;
-        }
-        for (; i < n16; i += stride) acc ^= base[i].x;
-    }
-    if (acc == 0x5eedf00d && sink) *sink = acc;   // keeps the loads alive; practically never taken
-}
-
-static inline void pf_add(PfList & l, const DevTensor * t) {
-    const size_t nblk = (size_t) (t->ne[0] * t->ne[1] * t->ne[2]) / 32;
-    if (l.n < 8) { l.ptr[l.n] = t->qs; l.bytes[l.n] = nblk * (t->type == T_Q8_0 ? 32 : 16); l.n++; }
-    if (l.n < 8) { l.ptr[l.n] = t->sc; l.bytes[l.n] = nblk * ((t->type == T_Q4_1 || t->type == T_Q5_1) ? 4 : 2); l.n++; }
-}
-
 struct WPl {  // planes of one quantised matrix
     const uint8_t * qs;
     const uint32_t * qh;
@@ -275,14 +241,12 @@ struct P6A {
     WPl w1; int64_t n_rows;  // 5 * r
     float * tl;
     int64_t D;
-    PfList pf; int * sink;
 };
 
 template <int FMT>
 __global__ __launch_bounds__(1024) void k6_att_prep(P6A p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 1024;
-    if ((int) blockIdx.x >= p.pf.first_block) { prefetch_regions(p.pf, p.sink); return; }
     const int64_t D = p.D;
     const int nb = (int) (D / 32);
     float * l_row = reinterpret_cast<float *>(smem);
@@ -350,12 +314,10 @@ struct P6B {
     const float * sx; const float * xn;
     void * out;         // 5 lohi images of D elements, qvec_bytes(D) apart (rounded up to 256)
     int64_t D, R, out_stride;
-    PfList pf; int * sink;
 };
 
 __global__ __launch_bounds__(256) void k6_mix2(P6B p) {
     __shared__ float l_tl[256];
-    if ((int) blockIdx.x >= p.pf.first_block) { prefetch_regions(p.pf, p.sink); return; }
     const int64_t D = p.D, R = p.R;
     const int64_t idx = (int64_t) blockIdx.x * 256 + threadIdx.x;  // D % 256 == 0: one f per workgroup
     const int f = (int) (idx / D);
@@ -430,14 +392,12 @@ struct P6D {
     const float * lnx_w; const float * lnx_b;
     void * y_out;  // lohi image of D elements
     int64_t D, DR;
-    PfList pf; int * sink;
 };
 
 template <int FMT, int NBD>
 __global__ __launch_bounds__(64) void k6_wkv(P6D p) {
     constexpr int S = 64;
     __shared__ __attribute__((aligned(16))) unsigned char l_dl[NBD * 32 + NBD * 12];
-    if ((int) blockIdx.x >= p.pf.first_block) { prefetch_regions(p.pf, p.sink); return; }
     const int lane = threadIdx.x;
     const int64_t h = blockIdx.x, c = h * S + lane;
     const int64_t D = p.D;
@@ -738,21 +698,13 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
     auto f = [](const DevTensor * t) { return (const float *) t->data; };
     const size_t qbD = ((qvec_bytes(D) + 15) / 16) * 16;
 
-    static const bool use_pf = !(getenv("RWKV_MI_NO_PREFETCH") && getenv("RWKV_MI_NO_PREFETCH")[0] == '1');
-    int * sink = (int *) s.dl + 255;
-    auto mk_pf = [&](int base_blocks, int extra, std::initializer_list<const DevTensor *> ts) {
-        PfList l{}; l.first_block = base_blocks; l.n_blocks = use_pf ? extra : 0;
-        if (use_pf) for (const DevTensor * t : ts) pf_add(l, t);
-        return l;
-    };
     const int gridA = (int) ((R5 + 3) / 4);
-    const PfList pfa = mk_pf(gridA, 176, {L.att_receptance, L.att_key});
-    P6A a{x, f(L.ln1_w), f(L.ln1_b), sin + D, f(L.att_time_maa_x), sout + D, s.xn, s.sx, planes(L.att_time_maa_w1), R5, s.tl, D, pfa, sink};
-    launch6(pf, 0, k6_att_prep<FMT>, dim3((unsigned) (gridA + pfa.n_blocks)), dim3(1024), (size_t) D * 4 + qbD + 257 * 8, st, a);
+    P6A a{x, f(L.ln1_w), f(L.ln1_b), sin + D, f(L.att_time_maa_x), sout + D, s.xn, s.sx, planes(L.att_time_maa_w1), R5, s.tl, D};
+    launch6(pf, 0, k6_att_prep<FMT>, dim3((unsigned) gridA), dim3(1024), (size_t) D * 4 + qbD + 257 * 8, st, a);
 
     P6B b{f(L.att_time_maa_w2), s.tl, {f(L.att_time_maa_w), f(L.att_time_maa_k), f(L.att_time_maa_v), f(L.att_time_maa_r), f(L.att_time_maa_g)},
-          s.sx, s.xn, s.act5, D, R, s.act_stride, mk_pf((int) (5 * D / 256), 176, {L.att_value, L.att_gate, L.att_time_decay_w1}), sink};
-    launch6(pf, 0, k6_mix2, dim3((unsigned) (5 * D / 256 + b.pf.n_blocks)), dim3(256), 0, st, b);
+          s.sx, s.xn, s.act5, D, R, s.act_stride};
+    launch6(pf, 0, k6_mix2, dim3((unsigned) (5 * D / 256)), dim3(256), 0, st, b);
 
     P6C c{{planes(L.att_receptance), planes(L.att_key), planes(L.att_value), planes(L.att_gate), planes(L.att_time_decay_w1)},
           s.act5, s.act_stride, {s.r, s.k, s.v, s.g, s.dl}, D, DR};
@@ -761,9 +713,9 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
             k6_rkvgw<FMT>, dim3((unsigned) (4 * (D / 32) + (DR + 31) / 32)), dim3(256), qbD, st, c);
 
     P6D d{s.dl, planes(L.att_time_decay_w2), f(L.att_time_decay), f(L.att_time_faaaa), s.r, s.k, s.v, s.g, sin + 2 * D, sout + 2 * D,
-          f(L.att_ln_x_w), f(L.att_ln_x_b), s.yq, D, DR, mk_pf((int) H, 768, {L.att_output, L.ffn_key, L.ffn_receptance}), sink};
-    if (DR == 128) launch6(pf, 0, k6_wkv<FMT, 4>, dim3((unsigned) (H + d.pf.n_blocks)), dim3(64), 0, st, d);
-    else launch6(pf, 0, k6_wkv<FMT, 2>, dim3((unsigned) (H + d.pf.n_blocks)), dim3(64), 0, st, d);
+          f(L.att_ln_x_w), f(L.att_ln_x_b), s.yq, D, DR};
+    if (DR == 128) launch6(pf, 0, k6_wkv<FMT, 4>, dim3((unsigned) H), dim3(64), 0, st, d);
+    else launch6(pf, 0, k6_wkv<FMT, 2>, dim3((unsigned) H), dim3(64), 0, st, d);
 
     P6E e{planes(L.att_output), s.yq, x, nullptr, D, D};
     launch6(pf, L.att_output->nbytes + actD + D * 8, k6_proj_res<FMT, 4, 2, false>, dim3((unsigned) ((D + 15) / 16)), dim3(256), qbD, st, e);
