@@ -46,6 +46,11 @@ RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major
 /* Single-token steps are replayed from a captured hipGraph by default; disable for debugging / profiling per kernel. */
 RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled);
 
+/* Which single-token path this context runs: 0 = one kernel per graph op, 1 = fused RWKV-6 layer (seven launches per layer),
+ * 2 = persistent whole-stage kernel (one launch per token; needs the device to itself). The choice is made
+ * at context creation from the model geometry, the weight format and the environment (RWKV_MI_NO_FUSED / RWKV_MI_NO_MEGA). */
+RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx);
+
 /* ---- layer pipeline: one process per GPU, each owning layers [layer_begin, layer_end) and their slice of the state ----
  * (supersedes the reference's n_gpu_layers CPU/GPU split, rwkv_model_loading.inc:129-142). The hand-off of the residual
  * stream between stages is the caller's job (RCCL send/recv over xGMI, see rwkv.cpp_amd/pipeline.py). */

@@ -55,6 +55,8 @@ static bool fetch_outputs(rwkv_context * ctx, float * state_out, float * logits_
     if (state_out && !state_to_host(ctx, state_out)) return false;
     if (logits_out) HIP_CTX_OK(ctx, hipMemcpyAsync(logits_out, ctx->d_logits, (size_t) ctx->model->n_vocab() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, !(ctx->mega && mega_v6_aborted(ctx->mega)),
+                 "persistent decode kernel timed out waiting for a workgroup (is the GPU shared with another process?)");
     return true;
 }
 
@@ -255,6 +257,8 @@ RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_to
     }
     (void) hipFree(d_hist);
     RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, ok, "greedy decode failed: %s", hipGetErrorString(hipGetLastError()));
+    RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, !(ctx->mega && mega_v6_aborted(ctx->mega)),
+                 "persistent decode kernel timed out waiting for a workgroup (is the GPU shared with another process?)");
     return true;
 }
 
@@ -302,6 +306,8 @@ RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major
 }
 
 RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled) { ctx->use_graph = enabled; }
+
+RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx) { return ctx->mega ? 2 : (ctx->fused_v6 ? 1 : 0); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Layer pipeline (one process per GPU; the hand-off itself is done by the caller with RCCL send/recv)

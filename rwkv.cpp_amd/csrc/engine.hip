@@ -51,6 +51,8 @@ rwkv_context * create_context(Model * m, uint32_t n_threads) {
     if (!(nf && nf[0] == '1') && fused_v6_supported(*m)) {
         if ((e = hipMalloc(&ctx->fused_scratch, fused_v6_scratch_bytes(*m))) != hipSuccess) return fail(e);
         ctx->fused_v6 = true;
+        const char * nm = getenv("RWKV_MI_NO_MEGA");
+        if (!(nm && nm[0] == '1')) ctx->mega = mega_v6_create(*m);
     }
     return ctx.release();
 }
@@ -66,6 +68,7 @@ void destroy_context(rwkv_context * ctx) {
     for (int i = 0; i < 2; i++) if (ctx->state[i]) (void) hipFree(ctx->state[i]);
     if (ctx->scratch) (void) hipFree(ctx->scratch);
     if (ctx->fused_scratch) (void) hipFree(ctx->fused_scratch);
+    if (ctx->mega) mega_v6_destroy(ctx->mega);
     if (ctx->d_tokens) (void) hipFree(ctx->d_tokens);
     if (ctx->d_logits) (void) hipFree(ctx->d_logits);
     if (ctx->d_next_token) (void) hipFree(ctx->d_next_token);
@@ -280,6 +283,9 @@ struct Runner {
         float * sout = ctx->state[ctx->cur ^ 1];
         const int64_t per_layer = m.state_per_layer();
         if (m.has_embed) launch_embed_ln0(*m.emb, ctx->d_tokens, T, D, f(m.ln0_w), f(m.ln0_b), b.x, st);
+        if (T == 1 && ctx->mega) {
+            mega_v6_forward(ctx->mega, b.x, sin + (int64_t) m.layer_begin * per_layer, sout + (int64_t) m.layer_begin * per_layer, st, &ctx->prof);
+        } else
         for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
             const LayerW & L = m.layers[i];
             const float * li = sin + (int64_t) i * per_layer;

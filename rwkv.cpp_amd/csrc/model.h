@@ -112,6 +112,8 @@ struct rwkv_context {
     // fused single-token path (fused_v6.hip) when the model qualifies
     bool  fused_v6 = false;
     void * fused_scratch = nullptr;
+    // persistent whole-stage decode kernel (mega_v6.hip) when the model and the device qualify; takes precedence
+    void * mega = nullptr;
 
     // Live per-launch timing of the dominant kernel (the quantised single-token projection) with HIP events on this
     // context's stream; filled by rwkv_mi_profile_decode, used by bench.py's roofline figure.
@@ -142,6 +144,12 @@ bool forward(rwkv_context * ctx, int64_t T, bool want_logits);
 bool   fused_v6_supported(const Model & m);
 size_t fused_v6_scratch_bytes(const Model & m);
 void   fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf);
+// persistent single-launch RWKV-6 decode over all layers of the stage (mega_v6.hip)
+void *   mega_v6_create(const Model & m);   // nullptr: not applicable
+void     mega_v6_destroy(void * h);
+void     mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf);
+bool     mega_v6_aborted(void * h);
+uint64_t mega_v6_bytes(void * h);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
 bool forward_decode(rwkv_context * ctx, bool want_logits);
 // grows the per-context activation scratch to hold T tokens

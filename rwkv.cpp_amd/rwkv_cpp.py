@@ -106,6 +106,8 @@ class RWKVSharedLibrary:
         L.rwkv_mi_logits_device_ptr.restype = ctypes.c_void_p
         L.rwkv_mi_set_graph_enabled.argtypes = [c_ctx, ctypes.c_bool]
         L.rwkv_mi_set_graph_enabled.restype = None
+        L.rwkv_mi_decode_path.argtypes = [c_ctx]
+        L.rwkv_mi_decode_path.restype = ctypes.c_int
 
     # --- rwkv.h ---------------------------------------------------------------------------------------------
 
@@ -308,6 +310,10 @@ class RWKVModel:
 
     def set_graph_enabled(self, enabled: bool) -> None:
         self._library.library.rwkv_mi_set_graph_enabled(self._ctx.ptr, enabled)
+
+    def decode_path(self) -> int:
+        """0 = per-op kernels, 1 = fused RWKV-6 layer, 2 = persistent whole-stage kernel."""
+        return int(self._library.library.rwkv_mi_decode_path(self._ctx.ptr))
 
     def clone(self, thread_count: int = 1) -> "RWKVModel":
         other = object.__new__(RWKVModel)
