@@ -384,6 +384,16 @@ RWKV_API bool rwkv_mi_logits_store(struct rwkv_context * ctx, float * logits_out
 // device pointer of the context's logits buffer (valid after a last-stage step / any eval that produced logits)
 RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx) { return ctx->d_logits; }
 
+RWKV_API bool rwkv_mi_debug_mega_trace(struct rwkv_context * ctx, uint32_t token, int layer, int n, long long * out) {
+    if (!ctx->mega) return false;
+    const bool g = ctx->use_graph; ctx->use_graph = false;
+    bool ok = mega_v6_trace(ctx->mega, layer, out, false);
+    for (int i = 0; i < n && ok; i++) ok = run_tokens(ctx, &token, 1, true);
+    (void) hipStreamSynchronize(ctx->stream);
+    ctx->use_graph = g;
+    return ok && mega_v6_trace(ctx->mega, layer, out, true);
+}
+
 // Test hook: the activation quantiser (f32 -> Q8_0/Q8_1 blocks) on standalone buffers.
 RWKV_API bool rwkv_mi_test_quantize_act(const float * x, int64_t n, int8_t * q, float * d, float * s, int32_t * isum) {
     g_last_error = RWKV_ERROR_NONE;

@@ -118,14 +118,25 @@ struct Batch { RawBlk<FMT> raw[U][R]; };
 template <int FMT, int R, int U>
 __device__ __forceinline__ void batch_issue(Batch<FMT, R, U> & bt, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
                                             const void * __restrict__ sc, int64_t row0, int64_t N, int nb, int bbase, int lane) {
+    // Row bases are formed first (wave-uniform when row0 is: scalar base + 32-bit lane offset addressing, no 64-bit
+    // address pair per load), then every load of the batch is issued.
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int bb = bbase + u * WAVE + lane;
-        const int b = bb < nb ? bb : nb - 1;
+        unsigned b = (unsigned) (bb < nb ? bb : nb - 1);
+        // (opaque copy: instruction selection works per basic block and only forms "scalar base + 32-bit lane offset"
+        //  addresses when the zero-extension of the offset sits in the block of the load)
+        asm volatile("" : "+v"(b));
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
-            load_raw<FMT>(bt.raw[u][r], qs, qh, sc, row * nb + b);
+            const uint8_t * rq = qs + row * nb * QF<FMT>::QS;
+            RawBlk<FMT> & o = bt.raw[u][r];
+            if constexpr (QF<FMT>::HM) o.sc = (reinterpret_cast<const uint32_t *>(sc) + row * nb)[b];
+            else o.sc = (reinterpret_cast<const uint16_t *>(sc) + row * nb)[b];
+            if constexpr (QF<FMT>::QH) o.qh = (qh + row * nb)[b];
+            o.q[0] = *reinterpret_cast<const int4 *>(rq + b * QF<FMT>::QS);
+            if constexpr (QF<FMT>::QS == 32) o.q[1] = *reinterpret_cast<const int4 *>(rq + b * QF<FMT>::QS + 16);
         }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -27,19 +27,33 @@ namespace rwkvmi {
 
 typedef unsigned long long u64;
 
+// Per-layer table in HBM: byte offsets from the parameter arena. A pointer READ FROM MEMORY is generic to the compiler and
+// generic (FLAT) loads also count on the LDS counter -- every LDS wait would then wait for the weight prefetch in flight;
+// arena (a kernel argument, known global) + offset keeps the weight stream on vmcnt alone. Fields are fetched with
+// scalar loads where they are used, not held across the layer.
+struct M6Off { long long qs, qh, sc; };
 struct M6Layer {
-    const float *ln1_w, *ln1_b, *maa_x, *maa[5], *w2t, *time_decay, *faaaa, *lnx_w, *lnx_b, *ln2_w, *ln2_b, *fmaa_k, *fmaa_r;
-    WPl w1, rkvg[4], dw1, dw2, wo, fk, fr, fv;
+    long long ln1_w, ln1_b, maa_x, maa[5], w2t, time_decay, faaaa, lnx_w, lnx_b, ln2_w, ln2_b, fmaa_k, fmaa_r;
+    M6Off w1, rkvg[4], dw1, dw2, wo, fk, fr, fv;
+};
+struct M6Arena {
+    const unsigned char * base;
+    __device__ __forceinline__ const float * f(long long off) const { return reinterpret_cast<const float *>(base + off); }
+    __device__ __forceinline__ WPl w(const M6Off & o) const {
+        return WPl{base + o.qs, reinterpret_cast<const uint32_t *>(base + o.qh), reinterpret_cast<const void *>(base + o.sc)};
+    }
 };
 
 struct M6P {
     const M6Layer * layers; int n_layers;
+    const unsigned char * arena;
     float * x;                                       // plain residual stream: input of the first layer, output of the last
     const float * sin; float * sout; long long state_stride;
     u64 *tl, *act5, *rkvg, *dl, *yq, *xatt, *kq, *rr, *xffn;   // tagged exchange buffers
     long long act_stride;                            // units between the five mix images
     unsigned * ctl;                                  // [0] tag generation, [1] abort
     int F, DR, R, H, gpb;
+    long long * trace; int trace_layer;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -75,17 +89,38 @@ __device__ __forceinline__ void poll_ptrs(Poll & pl, const u64 * const (&ptr)[N]
     for (int u = 0; u < N; u++) out[u] = (unsigned) v[u];
 }
 
-// Threads tid, tid + NT, ... own units of a contiguous range; sink(i, payload) runs once per unit afterwards.
+// Threads tid, tid + NT, ... own units of a contiguous range; sink(i, payload) runs once per unit.
+// The buffer is padded to MAXU * NT units, so every slot is loaded unclamped (base + immediate offset addressing, no
+// per-slot address registers); slots past n are simply not checked. Long ranges are polled in rounds of at most 24
+// loads per lane (48 result registers): the first round absorbs the wait, the others normally pass at once.
+template <int MAXU, int NT, int U0, int UN, typename Sink>
+__device__ __forceinline__ void poll_round(Poll & pl, const u64 * mine, int n, unsigned tag, int tid, Sink && sink) {
+    u64 v[UN];
+    for (unsigned spin = 0;; spin++) {
+#pragma unroll
+        for (int u = 0; u < UN; u++) v[u] = tg_load(mine + (U0 + u) * NT);
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < UN; u++) ok = ok && (tid + (U0 + u) * NT >= n || (unsigned) (v[u] >> 32) == tag);
+        if (__all(ok) || pl.dead) break;
+        if ((spin & 63u) == 63u) {
+            if (__hip_atomic_load(pl.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) pl.dead = true;
+            else if (spin > 3000000u) { __hip_atomic_store(pl.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pl.dead = true; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) if (tid + (U0 + u) * NT < n) sink(tid + (U0 + u) * NT, (unsigned) v[u]);
+}
+
 template <int MAXU, int NT, typename Sink>
 __device__ __forceinline__ void poll_units(Poll & pl, const u64 * src, int n, unsigned tag, int tid, Sink && sink) {
-    const u64 * ptr[MAXU];
-    bool valid[MAXU];
-    unsigned out[MAXU];
-#pragma unroll
-    for (int u = 0; u < MAXU; u++) { const int i = tid + u * NT; valid[u] = i < n; ptr[u] = src + (valid[u] ? i : n - 1); }
-    poll_ptrs<MAXU>(pl, ptr, valid, tag, out);
-#pragma unroll
-    for (int u = 0; u < MAXU; u++) if (valid[u]) sink(tid + u * NT, out[u]);
+    constexpr int CH = 24;
+    const u64 * mine = src + tid;
+    poll_round<MAXU, NT, 0, (MAXU < CH ? MAXU : CH)>(pl, mine, n, tag, tid, sink);
+    if constexpr (MAXU > CH) poll_round<MAXU, NT, CH, (MAXU - CH < CH ? MAXU - CH : CH)>(pl, mine, n, tag, tid, sink);
+    if constexpr (MAXU > 2 * CH) poll_round<MAXU, NT, 2 * CH, (MAXU - 2 * CH < CH ? MAXU - 2 * CH : CH)>(pl, mine, n, tag, tid, sink);
+    static_assert(MAXU <= 3 * CH, "poll_units: range too long");
 }
 
 // A quantised vector of K elements travels as 10 units per 32-element block: units [0, 8 nb) are the dwords of the lohi
@@ -133,489 +168,639 @@ __device__ __forceinline__ void batch_zero(Batch<FMT, R, U> & bt) {
 // Opaque copy: derived per-lane offsets (poll addresses, row offsets) are recomputed where they are used instead of
 // being hoisted out of the layer loop as ~100 loop-invariant registers.
 __device__ __forceinline__ int opq(int v) { asm volatile("" : "+v"(v)); return v; }
+// same for a wave-uniform value: the per-layer table entries are re-fetched (scalar loads) in the phase that uses them
+// instead of occupying ~80 SGPRs across the whole layer
+__device__ __forceinline__ int opq_s(int v) { asm volatile("" : "+s"(v)); return v; }
+
+// Branch-free issue for a (wave-uniform) optional job: an absent job loads block 0 of row 0 on every lane -- one 16-byte
+// request, no bandwidth -- so that the issue sequence is straight-line code. With control flow around the loads the
+// compiler's wait-count bookkeeping degrades to s_waitcnt vmcnt(0), i.e. "wait for the whole prefetch", at every use.
+template <int FMT, int R, int U>
+__device__ __forceinline__ void batch_issue_opt(bool has, Batch<FMT, R, U> & bt, const WPl & w, int row0, int N, int nb, int bbase, int lane) {
+    batch_issue<FMT, R, U>(bt, w.qs, w.qh, w.sc, has ? row0 : 0, has ? N : 1, has ? nb : 1, has ? bbase : 0, has ? lane : 0);
+}
 
 // lane r of the wave picks res[r] (res is wave-uniform after the butterfly)
 template <int R>
 __device__ __forceinline__ float pick_lane(const float (&res)[R], int lane) {
+    // (the values pass through an opaque copy: otherwise LLVM turns the select chain into an indexed load from a
+    //  scratch array, and a scratch load waits behind every prefetch load in flight)
     float v = res[0];
 #pragma unroll
-    for (int r = 1; r < R; r++) v = lane == r ? res[r] : v;
+    for (int r = 1; r < R; r++) { float t = res[r]; asm volatile("" : "+v"(t)); v = lane == r ? t : v; }
     return v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// the kernel. EPT = D / 512 (elements of a D-vector per thread), KQU = poll slots per thread for the F-vector,
-// NBD = decay rank / 32.
+// the kernel. EPT = D / 512, KQU = ceil(10 (F/32) / 64) poll slots per lane for the F-vector, NBD = decay rank / 32,
+// GPB = key groups (32 rows of ffn.key) per workgroup = ceil((F/32) / 256). The grid is exactly NBLK workgroups.
+//
+// Roles inside a workgroup (8 waves):
+//   wave 0      "comm": polls every tagged input of the workgroup into LDS, runs the WKV head (phase D) of workgroups
+//               0..H-1 and quantises the key groups. It never has weight loads in flight, so its polls return at
+//               memory latency instead of queueing behind a prefetch (vector-memory results return in order per wave).
+//   waves 1..7  "workers": own fixed rows of every matrix, keep the NEXT phase's weights in flight, and only ever wait
+//               on the workgroup barrier and on their own loads. They never poll.
+// The two roles run different code (two loops over the layers) with the same sequence of workgroup barriers.
 // ---------------------------------------------------------------------------------------------------------------
 
 enum { SLOT_TL = 0, SLOT_ACT = 1, SLOT_RKVG = 2, SLOT_YQ = 3, SLOT_XATT = 4, SLOT_KQ = 5, SLOT_XFFN = 6 };
 
 __host__ __device__ inline size_t m6_round16(size_t v) { return (v + 15) / 16 * 16; }
 
-struct M6Lds { size_t x, xn, sx, q1, q2, act, actw, yq, kq, tl, red, out, dl, total; };
+struct M6Lds { size_t x, xn, sx, q1, q2, act, actw, yq, kq, tl, red, out, rr, dl, total; };
 __host__ __device__ inline M6Lds m6_lds(int D, int F) {
     M6Lds o; size_t p = 0;
     auto take = [&](size_t n) { const size_t r = p; p += m6_round16(n); return r; };
     o.x = take((size_t) D * 4); o.xn = take((size_t) D * 4); o.sx = take((size_t) D * 4);
     o.q1 = take(qvec_bytes(D)); o.q2 = take(qvec_bytes(D)); o.act = take(qvec_bytes(D)); o.actw = take(qvec_bytes(D)); o.yq = take(qvec_bytes(D));
-    o.kq = take(qvec_bytes(F)); o.tl = take(1280 * 4); o.red = take(258 * 8); o.out = take(2 * 32 * 4); o.dl = take(8 * 192);
+    o.kq = take(qvec_bytes(F)); o.tl = take(1280 * 4); o.red = take(258 * 8); o.out = take(2 * 32 * 4); o.rr = take(64 * 4); o.dl = take(192);
     o.total = p;
     return o;
 }
 
-template <int FMT, int EPT, int KQU, int NBD>
-__global__ __launch_bounds__(512) void k6_mega(M6P p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NT = 512, S = 64;
-    constexpr int D = EPT * NT;
-    constexpr int nb = D / 32;                     // blocks of a D-vector
-    constexpr int UD = nb / 64 > 0 ? nb / 64 : 1;  // 64-block steps covering K = D
-    constexpr int DU = (10 * nb + NT - 1) / NT;    // poll slots per thread for a quantised D-vector
-    const int tid0 = threadIdx.x;
-    const int tid = tid0, lane = tid0 & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // wave-uniform: row bases and work predicates stay in SGPRs
-    const int blk = blockIdx.x, NB = gridDim.x;
-    const int F = p.F, DR = p.DR, R = p.R, H = p.H;
-    const int nbF = F / 32;
-
-    const M6Lds lo = m6_lds(D, F);
-    float * l_x = reinterpret_cast<float *>(smem + lo.x);
-    float * l_xn = reinterpret_cast<float *>(smem + lo.xn);
-    float * l_sx = reinterpret_cast<float *>(smem + lo.sx);
-    unsigned char * l_q1 = smem + lo.q1;
-    unsigned char * l_q2 = smem + lo.q2;
-    unsigned char * l_act = smem + lo.act;
-    unsigned char * l_actw = smem + lo.actw;
-    unsigned char * l_yq = smem + lo.yq;
-    unsigned char * l_kq = smem + lo.kq;
-    float * l_tl = reinterpret_cast<float *>(smem + lo.tl);
-    double * red = reinterpret_cast<double *>(smem + lo.red);
-    float * l_out = reinterpret_cast<float *>(smem + lo.out);
-    unsigned char * l_dl = smem + lo.dl + wave * 192;
-
-    Poll pl{p.ctl, false};
-    const unsigned base = p.ctl[0];
-
-    // ---- static work assignment ----
-    // A: W1 row (5R rows, one per wave, interleaved over workgroups)
-    const int a_row = wave * NB + blk;
-    const bool a_has = a_row < 5 * R;
-    // B: 64-element chunk of the five mixes
-    const int b_chunk = wave * NB + blk;
-    const bool b_has = b_chunk < 5 * (D / 64);
-    const int b_f = b_has ? b_chunk / (D / 64) : 0;
-    const int b_d0 = (b_has ? b_chunk % (D / 64) : 0) * 64;
-    // C: 8-row set of r/k/v/g (workgroup-major: one activation image per workgroup) + one decay-W1 row on wave 7
-    const int c_set = blk * 8 + wave;
-    const bool c_has = c_set < 4 * (D / 8);
-    const int c_mat = c_has ? c_set / (D / 8) : 0;
-    const int c_row0 = (c_has ? c_set % (D / 8) : 0) * 8;
-    const int c_act = (0x4213 >> (4 * c_mat)) & 0xF;   // r,k,v,g -> mix image (w,k,v,r,g order)
-    const int blk_mat = (blk * 8) / (D / 8);           // matrix of this workgroup's sets (uniform: (D/8) % 8 == 0)
-    const bool blk_c_has = blk * 8 < 4 * (D / 8);
-    const int blk_act = (0x4213 >> (4 * (blk_mat & 3))) & 0xF;
-    const int c_xrow = blk + NB * (7 - wave);
-    const bool c_xhas = c_xrow < DR;
-    const bool blk_xhas = blk < DR;                    // wave 7 of this workgroup has a decay row
-    // D: head
-    const int d_head = blk + NB * wave;
-    const bool d_has = d_head < H;
-    // E / G / F-receptance: 2-row set, interleaved over workgroups (the same wave owns x[n] in E and G)
-    const int e_set = wave * NB + blk;
-    const bool e_has = e_set < D / 2;
-    const int e_row0 = e_has ? e_set * 2 : 0;
-    // F: key groups of 32 rows, gpb consecutive groups per workgroup, wave w owns rows 4w..4w+3 of each
-    const int GK = nbF;
-    const int gpb = p.gpb;
-
-    float xown = 0.0f;  // lane r < 2 of an owner wave: x[e_row0 + r]
-    if (e_has && lane < 2) xown = p.x[e_row0 + lane];
-
-    // ---- prefetch registers ----
-    struct PA { float lw[EPT], lb[EPT], pv[EPT], mx[EPT]; } pa;
-    struct PF { float lw[EPT], lb[EPT], pv[EPT], mk[EPT], mr[EPT]; } pf;
-    Batch<FMT, 1, UD> wA;
-    float wB[64]; float wBmaa = 0.0f;
-    Batch<FMT, 8, UD> wC; Batch<FMT, 1, UD> wCx;
-    struct WD { float s[S]; RawBlk<FMT> w2[NBD]; float td, u, lw, lb; } wD;
-    Batch<FMT, 2, UD> wE;
-    Batch<FMT, 4, UD> wFk[2]; Batch<FMT, 2, UD> wFr;
-    Batch<FMT, 2, 4> wG[2];
-
-    auto issue_A = [&](const M6Layer & L, const float * sin_l, int tid, int lane) {
+// 4 consecutive elements per lane, 8 lanes per 32-element block (ggml quantize_row_q8_0 / q8_1; max and integer sum are
+// order-free, so this is the same result as quant_block32 on the lane-per-element layout)
+__device__ __forceinline__ void quant_vec4(const float (&v)[4], unsigned & packed, float & d16, float & s16, int & isum) {
+    float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    am = fmaxf(am, __int_as_float(lane_xor1_i(__float_as_int(am))));
+    am = fmaxf(am, __int_as_float(lane_xor2_i(__float_as_int(am))));
+    am = fmaxf(am, __int_as_float(lane_xor4_i(__float_as_int(am))));
+    const float dd = am / 127.0f;
+    const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+    int q[4];
 #pragma unroll
-        for (int u = 0; u < EPT; u++) {
-            const int i = tid + u * NT;
-            pa.lw[u] = L.ln1_w[i]; pa.lb[u] = L.ln1_b[i]; pa.pv[u] = sin_l[D + i]; pa.mx[u] = L.maa_x[i];
-        }
-        if (a_has) batch_issue<FMT, 1, UD>(wA, L.w1.qs, L.w1.qh, L.w1.sc, a_row, 5 * R, nb, 0, lane);
-        else batch_zero<FMT, 1, UD>(wA);
+    for (int j = 0; j < 4; j++) q[j] = (int) roundf(v[j] * id);
+    int sm = (q[0] + q[1]) + (q[2] + q[3]);
+    sm += lane_xor1_i(sm);
+    sm += lane_xor2_i(sm);
+    sm += lane_xor4_i(sm);
+    packed = (unsigned) (q[0] & 0xFF) | ((unsigned) (q[1] & 0xFF) << 8) | ((unsigned) (q[2] & 0xFF) << 16) | ((unsigned) (q[3] & 0xFF) << 24);
+    isum = sm;
+    d16 = round_f16(dd);
+    s16 = round_f16((float) sm * dd);
+}
+
+// store the packed dword of elements [i, i+4) (i % 4 == 0) + the block scalars into a lohi image in LDS
+__device__ __forceinline__ void qvec_store4(const QVec & v, int nb, int i, unsigned packed, float d16, float s16, int isum) {
+    const int blk = i >> 5, e = i & 31;
+    *reinterpret_cast<unsigned *>(v.q + (e < 16 ? 0 : nb * 16) + blk * 16 + (e & 15)) = packed;
+    if (e == 0) { v.d[blk] = d16; v.s[blk] = s16; v.isum[blk] = isum; }
+}
+
+#define STAMP(K) do { if (p.trace && li == p.trace_layer && (tidst & 63) == 0) p.trace[((long long) blockIdx.x * 8 + (tidst >> 6)) * 32 + (K)] = (long long) __builtin_readcyclecounter(); } while (0)
+
+template <int FMT, int EPT, int KQU, int NBD, int GPB>
+struct K6 {
+    static constexpr int NT = 512, S = 64, NBLK = 256, NWK = 7;
+    static constexpr int D = EPT * NT;
+    static constexpr int nb = D / 32;
+    static constexpr int UD = nb / 64 > 0 ? nb / 64 : 1;
+    static constexpr int V4 = D / (4 * NT);              // float4 groups per thread in the prologues
+    static constexpr int RPB_C = 4 * D / NBLK;           // r/k/v/g rows per workgroup (all of one matrix)
+    static constexpr int NSC = (RPB_C / 2 + NWK - 1) / NWK;
+    static constexpr int RPB_E = D / NBLK;               // output / receptance / value rows per workgroup
+    static constexpr int NSE = (RPB_E + NWK - 1) / NWK;
+    static constexpr int NSK = (GPB * 16 + NWK - 1) / NWK;
+    static constexpr int XU = D / 64;                    // poll slots per lane for an f32 D-vector
+    static constexpr int DU = (10 * nb + 63) / 64;       // ... for a quantised D-vector
+
+    struct Lds {
+        float *x, *xn, *sx, *tl, *out, *rr;
+        unsigned char *q1, *q2, *act, *actw, *yq, *kq, *dl;
+        double * red;
     };
 
-    issue_A(p.layers[0], p.sin, tid, lane);
+    struct PA { float4 lw[V4], lb[V4], pv[V4], mx[V4]; };
+    struct PF { float4 lw[V4], lb[V4], pv[V4], mk[V4], mr[V4]; };
 
-    for (int li = 0; li < p.n_layers; li++) {
-        const M6Layer & L = p.layers[li];
-        const float * sin_l = p.sin + (long long) li * p.state_stride;
-        float * sout_l = p.sout + (long long) li * p.state_stride;
-        const unsigned tagL = base + (unsigned) li * 8u;
-        unsigned dq[6] = {0, 0, 0, 0, 0, 0};
-        unsigned rrv[1] = {0};
+    // LayerNorm statistics of the row in l.x (256 partials, threads 0..255); leaves x - mean in l.x
+    static __device__ __forceinline__ float ln_stats(const Lds & l, int tid) {
+        const bool pro = tid < 256;
+        double sacc = 0.0;
+        if (pro) for (int i = tid; i < D; i += 256) sacc += (double) l.x[i];
+        const float mean = (float) (block_sum_d_8w(sacc, l.red) / (double) D);
+        double s2 = 0.0;
+        if (pro) for (int i = tid; i < D; i += 256) { const float v = l.x[i] - mean; l.x[i] = v; s2 += (double) (v * v); }
+        const float var = (float) (block_sum_d_8w(s2, l.red) / (double) D);
+        return 1.0f / sqrtf(var + 1e-5f);
+    }
 
-        // =========================================== A ===========================================
-        {
-        const int tid = opq(tid0), lane = tid & 63;
-        if (li == 0) {
+    static __device__ __forceinline__ void issue_pa(PA & pa, const M6Arena & ar, const M6Layer & L, const float * sin_l, int tid) {
+        const float * ln1_w = ar.f(L.ln1_w), * ln1_b = ar.f(L.ln1_b), * maa_x = ar.f(L.maa_x);
 #pragma unroll
-            for (int u = 0; u < EPT; u++) l_x[tid + u * NT] = p.x[tid + u * NT];
-        } else {
-            poll_units<EPT, NT>(pl, p.xffn, D, tagL - 8u + SLOT_XFFN, tid, [&](int i, unsigned v) { l_x[i] = __uint_as_float(v); });
-        }
-        __syncthreads();
-        // next phase's weights: the W2 column of this wave's chunk
-        if (b_has) {
-            const int b_d = b_d0 + lane;
-            const float * col = L.w2t + (long long) b_f * R * D + b_d;
-#pragma unroll
-            for (int m = 0; m < 64; m++) wB[m] = col[(long long) (m < R ? m : R - 1) * D];
-            wBmaa = L.maa[b_f][b_d];
-        } else {
-#pragma unroll
-            for (int m = 0; m < 64; m++) wB[m] = 0.0f;
-            wBmaa = 0.0f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const bool pro = tid < 256;
-            double sacc = 0.0;
-            if (pro) for (int i = tid; i < D; i += 256) sacc += (double) l_x[i];
-            const float mean = (float) (block_sum_d_8w(sacc, red) / (double) D);
-            double s2 = 0.0;
-            if (pro) for (int i = tid; i < D; i += 256) { const float v = l_x[i] - mean; l_x[i] = v; s2 += (double) (v * v); }
-            const float var = (float) (block_sum_d_8w(s2, red) / (double) D);
-            const float scale = 1.0f / sqrtf(var + 1e-5f);
-            const QVec lq = qvec_at(l_q1, D);
-            auto fin = [&](int u) -> float {
-                const int i = tid + u * NT;
-                const float y = l_x[i] * scale;
-                const float yw = y * pa.lw[u];
-                const float xn = yw + pa.lb[u];
-                const float sx = pa.pv[u] - xn;
-                const float sm = sx * pa.mx[u];
-                l_xn[i] = xn; l_sx[i] = sx;
-                if (blk == 0) sout_l[D + i] = xn;
-                return sm + xn;
-            };
-            int u0 = 0;
-#pragma unroll
-            for (; u0 + 3 < EPT; u0 += 4) {
-                float xv[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) xv[u] = fin(u0 + u);
-                int qi[4], isum[4]; float d16[4], s16[4];
-                quant_blocks<4>(xv, qi, d16, s16, isum);
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const int i = tid + (u0 + u) * NT; qvec_store(lq, nb, i >> 5, i & 31, qi[u], d16[u], s16[u], isum[u]); }
-            }
-#pragma unroll
-            for (; u0 < EPT; u0++) {
-                const float xxx = fin(u0);
-                int qi, isum; float d16, s16;
-                quant_block32(xxx, qi, d16, s16, isum);
-                const int i = tid + u0 * NT;
-                qvec_store(lq, nb, i >> 5, i & 31, qi, d16, s16, isum);
-            }
-            __syncthreads();
-            if (a_has) {
-                float res[1];
-                rows_finish<FMT, 1, UD>(wA, L.w1.qs, L.w1.qh, L.w1.sc, a_row, 5 * R, nb, lq, lane, res);
-                if (lane == 0) tg_store(p.tl + a_row, __float_as_uint(det_tanhf(res[0])), tagL + SLOT_TL);
-            }
-        }
-        }
-
-        // =========================================== B ===========================================
-        {
-        const int tid = opq(tid0), lane = tid & 63;
-        poll_units<3, NT>(pl, p.tl, 5 * R, tagL + SLOT_TL, tid, [&](int i, unsigned v) { l_tl[i] = __uint_as_float(v); });
-        __syncthreads();
-        if (c_has) batch_issue<FMT, 8, UD>(wC, L.rkvg[c_mat].qs, L.rkvg[c_mat].qh, L.rkvg[c_mat].sc, c_row0, D, nb, 0, lane);
-        else batch_zero<FMT, 8, UD>(wC);
-        if (c_xhas) batch_issue<FMT, 1, UD>(wCx, L.dw1.qs, L.dw1.qh, L.dw1.sc, c_xrow, DR, nb, 0, lane);
-        else batch_zero<FMT, 1, UD>(wCx);
-        __builtin_amdgcn_sched_barrier(0);
-        if (b_has) {
-            const int b_d = b_d0 + lane;
-            const float * tlf = l_tl + b_f * R;
-            float acc = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 64; m++) if (m < R) acc += wB[m] * tlf[m];
-            const float mm = (acc + wBmaa) * l_sx[b_d];
-            const float o = mm + l_xn[b_d];
-            int qi, isum; float d16, s16;
-            quant_block32(o, qi, d16, s16, isum);
-            tq_store_block(p.act5 + (long long) b_f * p.act_stride, nb, b_d >> 5, lane & 31, qi, d16, s16, isum, tagL + SLOT_ACT);
-        }
-        }
-
-        // =========================================== C ===========================================
-        {
-        const int tid = opq(tid0), lane = tid & 63;
-        if (blk_c_has) stage_qvec<DU, NT>(pl, p.act5 + (long long) blk_act * p.act_stride, D, tagL + SLOT_ACT, l_act, tid);
-        if (blk_xhas) stage_qvec<DU, NT>(pl, p.act5, D, tagL + SLOT_ACT, l_actw, tid);
-        __syncthreads();
-        if (d_has) {
-            const float * st = sin_l + 2 * D + (long long) d_head * S * S;
-#pragma unroll
-            for (int i = 0; i < S; i++) wD.s[i] = st[i * S + lane];
-            const int c = d_head * S + lane;
-#pragma unroll
-            for (int b = 0; b < NBD; b++) load_raw<FMT>(wD.w2[b], L.dw2.qs, L.dw2.qh, L.dw2.sc, (long long) c * NBD + b);
-            wD.td = L.time_decay[c]; wD.u = L.faaaa[c]; wD.lw = L.lnx_w[c]; wD.lb = L.lnx_b[c];
-        } else {
-#pragma unroll
-            for (int i = 0; i < S; i++) wD.s[i] = 0.0f;
-#pragma unroll
-            for (int b = 0; b < NBD; b++) { wD.w2[b].q[0] = make_int4(0, 0, 0, 0); if (QF<FMT>::QS == 32) wD.w2[b].q[QF<FMT>::QS / 16 - 1] = make_int4(0, 0, 0, 0); wD.w2[b].qh = 0; wD.w2[b].sc = 0; }
-            wD.td = 0.0f; wD.u = 0.0f; wD.lw = 0.0f; wD.lb = 0.0f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (c_has) {
-            const QVec la = qvec_at(l_act, D);
-            float res[8];
-            rows_finish<FMT, 8, UD>(wC, L.rkvg[c_mat].qs, L.rkvg[c_mat].qh, L.rkvg[c_mat].sc, c_row0, D, nb, la, lane, res);
-            float v = pick_lane<8>(res, lane);
-            if (c_mat == 3) v = v / (1.0f + det_expf(-v));
-            if (lane < 8) tg_store(p.rkvg + (long long) c_mat * D + c_row0 + lane, __float_as_uint(v), tagL + SLOT_RKVG);
-        }
-        if (c_xhas) {
-            const QVec la = qvec_at(l_actw, D);
-            float res[1];
-            rows_finish<FMT, 1, UD>(wCx, L.dw1.qs, L.dw1.qh, L.dw1.sc, c_xrow, DR, nb, la, lane, res);
-            if (lane == 0) tg_store(p.dl + c_xrow, __float_as_uint(det_tanhf(res[0])), tagL + SLOT_RKVG);
-        }
-        }
-
-        // =========================================== D ===========================================
-        {
-        const int tid = opq(tid0), lane = tid & 63;
-        if (d_has) {
-            const int c = d_head * S + lane;
-            const u64 * ptr[6] = {p.rkvg + c, p.rkvg + D + c, p.rkvg + 2 * D + c, p.rkvg + 3 * D + c, p.dl + lane, p.dl + (NBD > 2 ? 64 + lane : lane)};
-            const bool valid[6] = {true, true, true, true, true, NBD > 2};
-            poll_ptrs<6>(pl, ptr, valid, tagL + SLOT_RKVG, dq);
-        }
-        if (e_has) batch_issue<FMT, 2, UD>(wE, L.wo.qs, L.wo.qh, L.wo.sc, e_row0, D, nb, 0, lane);
-        else batch_zero<FMT, 2, UD>(wE);
-        __builtin_amdgcn_sched_barrier(0);
-        if (d_has) {
-            const int c = d_head * S + lane;
-            // 1. quantise dl (DR = 32 NBD elements) into this wave's LDS slot: half-wave = block
-            const QVec ldl = qvec_at(l_dl, NBD * 32);
-#pragma unroll
-            for (int j = 0; j < (NBD * 32 + 63) / 64; j++) {
-                const int e = j * 64 + lane;
-                const float val = e < NBD * 32 ? __uint_as_float(dq[4 + j]) : 0.0f;
-                int qi, isum; float d16, s16;
-                quant_block32(val, qi, d16, s16, isum);
-                if (e < NBD * 32) qvec_store(ldl, NBD, e >> 5, e & 31, qi, d16, s16, isum);
-            }
-            __builtin_amdgcn_wave_barrier();
-            // 2. decay row of channel c (order of the 64-entry halving tree, zeros elsewhere)
-            float P[NBD];
-#pragma unroll
-            for (int b = 0; b < NBD; b++) {
-                WBlk<FMT> w;
-                unpack_raw<FMT>(w, wD.w2[b]);
-                const int4 alo = *reinterpret_cast<const int4 *>(ldl.q + b * 16);
-                const int4 ahi = *reinterpret_cast<const int4 *>(ldl.q + NBD * 16 + b * 16);
-                P[b] = blk_fma<FMT>(w, alo, ahi, ldl.d[b], ldl.s[b], ldl.isum[b], 0.0f);
-            }
-#pragma unroll
-            for (int o = NBD / 2; o > 0; o >>= 1)
-#pragma unroll
-                for (int i = 0; i < o; i++) P[i] += P[i + o];
-            const float wdec = det_expf(-det_expf(P[0] + wD.td));
-            // 3. WKV6: lane j owns value column j; r_i, k_i, u_i, w_i are broadcast from lane i
-            const int rr_i = (int) dq[0], kk_i = (int) dq[1], uu_i = __float_as_int(wD.u), ww_i = __float_as_int(wdec);
-            const float vj = __uint_as_float(dq[2]);
-            float o = 0.0f;
-            float * so = sout_l + 2 * D + (long long) d_head * S * S;
-#pragma unroll
-            for (int i = 0; i < S; i++) {
-                const float ki = __int_as_float(__builtin_amdgcn_readlane(kk_i, i));
-                const float ui = __int_as_float(__builtin_amdgcn_readlane(uu_i, i));
-                const float ri = __int_as_float(__builtin_amdgcn_readlane(rr_i, i));
-                const float wi = __int_as_float(__builtin_amdgcn_readlane(ww_i, i));
-                const float kv = vj * ki;
-                const float prev = wD.s[i];
-                const float temp = kv * ui + prev;
-                o += temp * ri;
-                so[i * S + lane] = prev * wi + kv;
-            }
-            // 4. GroupNorm over the head, * ln_x, gate
-            const float mean = (float) (wave_sum_d((double) o) / (double) S);
-            const float dv = o - mean;
-            const float var = (float) (wave_sum_d((double) (dv * dv)) / (double) S);
-            const float scale = 1.0f / sqrtf(var + 64e-5f);
-            float y = dv * scale;
-            y = y * wD.lw;
-            y = y + wD.lb;
-            y *= __uint_as_float(dq[3]);
-            int qi, isum; float d16, s16;
-            quant_block32(y, qi, d16, s16, isum);
-            tq_store_block(p.yq, nb, 2 * d_head + (lane >> 5), lane & 31, qi, d16, s16, isum, tagL + SLOT_YQ);
-            (void) c;
-        }
-        }
-
-        // =========================================== E ===========================================
-        {
-        const int tid = opq(tid0), lane = tid & 63;
-        stage_qvec<DU, NT>(pl, p.yq, D, tagL + SLOT_YQ, l_yq, tid);
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < EPT; u++) {
-            const int i = tid + u * NT;
-            pf.lw[u] = L.ln2_w[i]; pf.lb[u] = L.ln2_b[i]; pf.pv[u] = sin_l[i]; pf.mk[u] = L.fmaa_k[i]; pf.mr[u] = L.fmaa_r[i];
-        }
-#pragma unroll
-        for (int gi = 0; gi < 2; gi++) {
-            const int g = blk * gpb + gi;
-            if (gi < gpb && g < GK) batch_issue<FMT, 4, UD>(wFk[gi], L.fk.qs, L.fk.qh, L.fk.sc, g * 32 + wave * 4, F, nb, 0, lane);
-            else batch_zero<FMT, 4, UD>(wFk[gi]);
-        }
-        if (e_has) batch_issue<FMT, 2, UD>(wFr, L.fr.qs, L.fr.qh, L.fr.sc, e_row0, D, nb, 0, lane);
-        else batch_zero<FMT, 2, UD>(wFr);
-        __builtin_amdgcn_sched_barrier(0);
-        if (e_has) {
-            const QVec la = qvec_at(l_yq, D);
-            float res[2];
-            rows_finish<FMT, 2, UD>(wE, L.wo.qs, L.wo.qh, L.wo.sc, e_row0, D, nb, la, lane, res);
-            const float v = pick_lane<2>(res, lane);
-            if (lane < 2) { xown = xown + v; tg_store(p.xatt + e_row0 + lane, __float_as_uint(xown), tagL + SLOT_XATT); }
-        }
-        }
-
-        // =========================================== F ===========================================
-        {
-        const int tid = opq(tid0), lane = tid & 63;
-        poll_units<EPT, NT>(pl, p.xatt, D, tagL + SLOT_XATT, tid, [&](int i, unsigned v) { l_x[i] = __uint_as_float(v); });
-        __syncthreads();
-        {
-            const bool pro = tid < 256;
-            double sacc = 0.0;
-            if (pro) for (int i = tid; i < D; i += 256) sacc += (double) l_x[i];
-            const float mean = (float) (block_sum_d_8w(sacc, red) / (double) D);
-            double s2 = 0.0;
-            if (pro) for (int i = tid; i < D; i += 256) { const float v = l_x[i] - mean; l_x[i] = v; s2 += (double) (v * v); }
-            const float var = (float) (block_sum_d_8w(s2, red) / (double) D);
-            const float scale = 1.0f / sqrtf(var + 1e-5f);
-            const QVec qk = qvec_at(l_q1, D), qr = qvec_at(l_q2, D);
-            auto fin = [&](int u, float & xk, float & xr) {
-                const int i = tid + u * NT;
-                const float y = l_x[i] * scale;
-                const float yw = y * pf.lw[u];
-                const float xn = yw + pf.lb[u];
-                const float sx = pf.pv[u] - xn;
-                const float sk = sx * pf.mk[u];
-                xk = sk + xn;
-                const float sr = sx * pf.mr[u];
-                xr = sr + xn;
-                if (blk == 0) sout_l[i] = xn;
-            };
-            int u0 = 0;
-#pragma unroll
-            for (; u0 + 3 < EPT; u0 += 4) {
-                float xk[4], xr[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) fin(u0 + u, xk[u], xr[u]);
-                int qi[4], isum[4]; float d16[4], s16[4];
-                quant_blocks<4>(xk, qi, d16, s16, isum);
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const int i = tid + (u0 + u) * NT; qvec_store(qk, nb, i >> 5, i & 31, qi[u], d16[u], s16[u], isum[u]); }
-                quant_blocks<4>(xr, qi, d16, s16, isum);
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const int i = tid + (u0 + u) * NT; qvec_store(qr, nb, i >> 5, i & 31, qi[u], d16[u], s16[u], isum[u]); }
-            }
-#pragma unroll
-            for (; u0 < EPT; u0++) {
-                float xk, xr;
-                fin(u0, xk, xr);
-                const int i = tid + u0 * NT;
-                int qi, isum; float d16, s16;
-                quant_block32(xk, qi, d16, s16, isum);
-                qvec_store(qk, nb, i >> 5, i & 31, qi, d16, s16, isum);
-                quant_block32(xr, qi, d16, s16, isum);
-                qvec_store(qr, nb, i >> 5, i & 31, qi, d16, s16, isum);
-            }
-            // value-projection rows of this wave (K = F): up to 8 steps of 64 blocks in two batches
-            if (e_has) batch_issue<FMT, 2, 4>(wG[0], L.fv.qs, L.fv.qh, L.fv.sc, e_row0, D, nbF, 0, lane);
-            else batch_zero<FMT, 2, 4>(wG[0]);
-            if (e_has && nbF > 256) batch_issue<FMT, 2, 4>(wG[1], L.fv.qs, L.fv.qh, L.fv.sc, e_row0, D, nbF, 256, lane);
-            else batch_zero<FMT, 2, 4>(wG[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-#pragma unroll
-            for (int gi = 0; gi < 2; gi++) {
-                const int g = blk * gpb + gi;
-                if (gi < gpb && g < GK) {
-                    float res[4];
-                    rows_finish<FMT, 4, UD>(wFk[gi], L.fk.qs, L.fk.qh, L.fk.sc, g * 32 + wave * 4, F, nb, qk, lane, res);
-                    const float v = pick_lane<4>(res, lane);
-                    const float t = v > 0.0f ? v : 0.0f;
-                    if (lane < 4) l_out[gi * 32 + wave * 4 + lane] = t * t;
-                }
-            }
-            if (e_has) {
-                float res[2];
-                rows_finish<FMT, 2, UD>(wFr, L.fr.qs, L.fr.qh, L.fr.sc, e_row0, D, nb, qr, lane, res);
-                const float v = pick_lane<2>(res, lane);
-                if (lane < 2) tg_store(p.rr + e_row0 + lane, __float_as_uint(v), tagL + SLOT_KQ);
-            }
-            __syncthreads();
-            if (wave == 0) {   // quantise this workgroup's key groups (relu^2 outputs): half-wave = group
-                const int gi = lane >> 5;
-                const int g = blk * gpb + gi;
-                const bool valid = gi < gpb && g < GK;
-                const float v = valid ? l_out[gi * 32 + (lane & 31)] : 0.0f;
-                int qi, isum; float d16, s16;
-                quant_block32(v, qi, d16, s16, isum);
-                tq_store_block(p.kq, nbF, valid ? g : 0, lane & 31, qi, d16, s16, isum, tagL + SLOT_KQ, valid);
-            }
-        }
-        }
-
-        // =========================================== G ===========================================
-        {
-        const int tid = opq(tid0), lane = tid & 63;
-        stage_qvec<KQU, NT>(pl, p.kq, F, tagL + SLOT_KQ, l_kq, tid);
-        {
-            const u64 * ptr[1] = {p.rr + e_row0 + (lane < 2 ? lane : 0)};
-            const bool valid[1] = {e_has && lane < 2};
-            if (e_has) poll_ptrs<1>(pl, ptr, valid, tagL + SLOT_KQ, rrv);
-        }
-        __syncthreads();
-        issue_A(p.layers[li + 1 < p.n_layers ? li + 1 : li], li + 1 < p.n_layers ? sin_l + p.state_stride : sin_l, tid, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        if (e_has) {
-            const QVec lk = qvec_at(l_kq, F);
-            float acc[2] = {0.0f, 0.0f};
-            batch_consume<FMT, 2, 4>(wG[0], nbF, 0, lane, lk, acc);
-            if (nbF > 256) batch_consume<FMT, 2, 4>(wG[1], nbF, 256, lane, lk, acc);
-            float res[2];
-            res[0] = wave_sum_f(acc[0]); res[1] = wave_sum_f(acc[1]);
-            const float v = pick_lane<2>(res, lane);
-            if (lane < 2) {
-                const float gte = sigmoid_f(__uint_as_float(rrv[0])) * v;
-                xown = xown + gte;
-                tg_store(p.xffn + e_row0 + lane, __float_as_uint(xown), tagL + SLOT_XFFN);
-                p.x[e_row0 + lane] = xown;
-            }
-        }
+        for (int u = 0; u < V4; u++) {
+            const int i = tid * 4 + u * 4 * NT;
+            pa.lw[u] = *reinterpret_cast<const float4 *>(ln1_w + i); pa.lb[u] = *reinterpret_cast<const float4 *>(ln1_b + i);
+            pa.pv[u] = *reinterpret_cast<const float4 *>(sin_l + D + i); pa.mx[u] = *reinterpret_cast<const float4 *>(maa_x + i);
         }
     }
-    if (blk == 0 && tid == 0) p.ctl[0] = base + (unsigned) p.n_layers * 8u;
+    static __device__ __forceinline__ void issue_pf(PF & pf, const M6Arena & ar, const M6Layer & L, const float * sin_l, int tid) {
+        const float * ln2_w = ar.f(L.ln2_w), * ln2_b = ar.f(L.ln2_b), * fmaa_k = ar.f(L.fmaa_k), * fmaa_r = ar.f(L.fmaa_r);
+#pragma unroll
+        for (int u = 0; u < V4; u++) {
+            const int i = tid * 4 + u * 4 * NT;
+            pf.lw[u] = *reinterpret_cast<const float4 *>(ln2_w + i); pf.lb[u] = *reinterpret_cast<const float4 *>(ln2_b + i);
+            pf.pv[u] = *reinterpret_cast<const float4 *>(sin_l + i);
+            pf.mk[u] = *reinterpret_cast<const float4 *>(fmaa_k + i); pf.mr[u] = *reinterpret_cast<const float4 *>(fmaa_r + i);
+        }
+    }
+
+    // A: LN1 + token shift + maa_x mix + quantise, every workgroup redundantly (all 8 waves). Barriers: 6 + 1.
+    static __device__ __forceinline__ void prologue_A(const Lds & l, const PA & pa, float * sout_l, bool write_state, int tid) {
+        const float scale = ln_stats(l, tid);
+        const QVec lq = qvec_at(l.q1, D);
+#pragma unroll
+        for (int u = 0; u < V4; u++) {
+            const int i = tid * 4 + u * 4 * NT;
+            const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
+            const float xs[4] = {xc.x, xc.y, xc.z, xc.w};
+            const float lw[4] = {pa.lw[u].x, pa.lw[u].y, pa.lw[u].z, pa.lw[u].w}, lb[4] = {pa.lb[u].x, pa.lb[u].y, pa.lb[u].z, pa.lb[u].w};
+            const float pv[4] = {pa.pv[u].x, pa.pv[u].y, pa.pv[u].z, pa.pv[u].w}, mx[4] = {pa.mx[u].x, pa.mx[u].y, pa.mx[u].z, pa.mx[u].w};
+            float xn[4], sx[4], xxx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float y = xs[j] * scale;
+                const float yw = y * lw[j];
+                xn[j] = yw + lb[j];
+                sx[j] = pv[j] - xn[j];
+                const float sm = sx[j] * mx[j];
+                xxx[j] = sm + xn[j];
+            }
+            *reinterpret_cast<float4 *>(l.xn + i) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+            *reinterpret_cast<float4 *>(l.sx + i) = make_float4(sx[0], sx[1], sx[2], sx[3]);
+            if (write_state) *reinterpret_cast<float4 *>(sout_l + D + i) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+            unsigned packed; float d16, s16; int isum;
+            quant_vec4(xxx, packed, d16, s16, isum);
+            qvec_store4(lq, nb, i, packed, d16, s16, isum);
+        }
+        __syncthreads();
+    }
+
+    // F: LN2 + token shift + the two mixes + quantise (all 8 waves). Barriers: 6 + 1.
+    static __device__ __forceinline__ void prologue_F(const Lds & l, const PF & pf, float * sout_l, bool write_state, int tid) {
+        const float scale = ln_stats(l, tid);
+        const QVec qk = qvec_at(l.q1, D), qr = qvec_at(l.q2, D);
+#pragma unroll
+        for (int u = 0; u < V4; u++) {
+            const int i = tid * 4 + u * 4 * NT;
+            const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
+            const float xs[4] = {xc.x, xc.y, xc.z, xc.w};
+            const float lw[4] = {pf.lw[u].x, pf.lw[u].y, pf.lw[u].z, pf.lw[u].w}, lb[4] = {pf.lb[u].x, pf.lb[u].y, pf.lb[u].z, pf.lb[u].w};
+            const float pv[4] = {pf.pv[u].x, pf.pv[u].y, pf.pv[u].z, pf.pv[u].w};
+            const float mk[4] = {pf.mk[u].x, pf.mk[u].y, pf.mk[u].z, pf.mk[u].w}, mr[4] = {pf.mr[u].x, pf.mr[u].y, pf.mr[u].z, pf.mr[u].w};
+            float xn[4], xk[4], xr[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float y = xs[j] * scale;
+                const float yw = y * lw[j];
+                xn[j] = yw + lb[j];
+                const float sx = pv[j] - xn[j];
+                const float sk = sx * mk[j];
+                xk[j] = sk + xn[j];
+                const float sr = sx * mr[j];
+                xr[j] = sr + xn[j];
+            }
+            if (write_state) *reinterpret_cast<float4 *>(sout_l + i) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+            unsigned packed; float d16, s16; int isum;
+            quant_vec4(xk, packed, d16, s16, isum);
+            qvec_store4(qk, nb, i, packed, d16, s16, isum);
+            quant_vec4(xr, packed, d16, s16, isum);
+            qvec_store4(qr, nb, i, packed, d16, s16, isum);
+        }
+        __syncthreads();
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // comm wave
+    // -----------------------------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void comm_main(const M6P & p, const Lds & l, int lane0, unsigned base) {
+        const int blk = blockIdx.x;
+        const int F = p.F, DR = p.DR, R = p.R, H = p.H;
+        const int nbF = F / 32;
+        Poll pl{p.ctl, false};
+        const M6Arena ar{p.arena};
+        // which activation images this workgroup's workers read in C
+        const int blk_mat = (blk * RPB_C) / D;
+        const int blk_act = (0x4213 >> (4 * blk_mat)) & 0xF;   // r,k,v,g -> mix image (w,k,v,r,g order)
+        bool blk_xhas = false;                                 // some worker here owns a decay-W1 row
+        for (int wk = 0; wk < NWK; wk++) { const int g = wk * NBLK + blk - 5 * R; blk_xhas = blk_xhas || (g >= 0 && g < DR); }
+        const bool d_has = blk < H;
+        const int d_head = blk;
+        PA pa; PF pf;
+        issue_pa(pa, ar, p.layers[0], p.sin, lane0);
+
+        for (int li = 0; li < p.n_layers; li++) {
+            const M6Layer & L = p.layers[li];
+            const float * sin_l = p.sin + (long long) li * p.state_stride;
+            float * sout_l = p.sout + (long long) li * p.state_stride;
+            const unsigned tagL = base + (unsigned) li * 8u;
+            const int lane = opq(lane0) & 63;
+            const int tidst = lane0;
+            STAMP(0);
+
+            // ---- A ----
+            if (li == 0) {
+#pragma unroll 8
+                for (int u = 0; u < XU; u++) l.x[lane + u * 64] = p.x[lane + u * 64];
+            } else {
+                poll_units<XU, 64>(pl, p.xffn, D, tagL - 8u + SLOT_XFFN, lane, [&](int i, unsigned v) { l.x[i] = __uint_as_float(v); });
+            }
+            STAMP(1);
+            __syncthreads();
+            prologue_A(l, pa, sout_l, blk == 0, lane);
+            STAMP(2);
+            // ---- B ----
+            poll_units<5, 64>(pl, p.tl, 5 * R, tagL + SLOT_TL, lane, [&](int i, unsigned v) { l.tl[i] = __uint_as_float(v); });
+            STAMP(3);
+            __syncthreads();
+            // ---- C ----
+            stage_qvec<DU, 64>(pl, p.act5 + (long long) blk_act * p.act_stride, D, tagL + SLOT_ACT, l.act, lane);
+            if (blk_xhas) stage_qvec<DU, 64>(pl, p.act5, D, tagL + SLOT_ACT, l.actw, lane);
+            STAMP(4);
+            __syncthreads();
+            // ---- D: WKV head of this workgroup ----
+            if (d_has) {
+                const int c = d_head * S + lane;
+                float s[S];
+                const float * st = sin_l + 2 * D + (long long) d_head * S * S;
+#pragma unroll
+                for (int i = 0; i < S; i++) s[i] = st[i * S + lane];
+                RawBlk<FMT> w2[NBD];
+                const WPl dw2 = ar.w(L.dw2);
+#pragma unroll
+                for (int b = 0; b < NBD; b++) load_raw<FMT>(w2[b], dw2.qs, dw2.qh, dw2.sc, (long long) c * NBD + b);
+                const float td = ar.f(L.time_decay)[c], uu = ar.f(L.faaaa)[c], lnw = ar.f(L.lnx_w)[c], lnb = ar.f(L.lnx_b)[c];
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned dq[6];
+                {
+                    const u64 * ptr[6] = {p.rkvg + c, p.rkvg + D + c, p.rkvg + 2 * D + c, p.rkvg + 3 * D + c, p.dl + lane, p.dl + (NBD > 2 ? 64 + lane : lane)};
+                    const bool valid[6] = {true, true, true, true, true, NBD > 2};
+                    poll_ptrs<6>(pl, ptr, valid, tagL + SLOT_RKVG, dq);
+                }
+                // 1. quantise dl (DR = 32 NBD elements) into LDS: half-wave = block
+                const QVec ldl = qvec_at(l.dl, NBD * 32);
+#pragma unroll
+                for (int j = 0; j < (NBD * 32 + 63) / 64; j++) {
+                    const int e = j * 64 + lane;
+                    const float val = e < NBD * 32 ? __uint_as_float(dq[4 + j]) : 0.0f;
+                    int qi, isum; float d16, s16;
+                    quant_block32(val, qi, d16, s16, isum);
+                    if (e < NBD * 32) qvec_store(ldl, NBD, e >> 5, e & 31, qi, d16, s16, isum);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // 2. decay row of channel c (order of the 64-entry halving tree, zeros elsewhere)
+                float P[NBD];
+#pragma unroll
+                for (int b = 0; b < NBD; b++) {
+                    WBlk<FMT> w;
+                    unpack_raw<FMT>(w, w2[b]);
+                    const int4 alo = *reinterpret_cast<const int4 *>(ldl.q + b * 16);
+                    const int4 ahi = *reinterpret_cast<const int4 *>(ldl.q + NBD * 16 + b * 16);
+                    P[b] = blk_fma<FMT>(w, alo, ahi, ldl.d[b], ldl.s[b], ldl.isum[b], 0.0f);
+                }
+#pragma unroll
+                for (int o = NBD / 2; o > 0; o >>= 1)
+#pragma unroll
+                    for (int i = 0; i < o; i++) P[i] += P[i + o];
+                const float wdec = det_expf(-det_expf(P[0] + td));
+                // 3. WKV6: lane j owns value column j; r_i, k_i, u_i, w_i are broadcast from lane i
+                const int rr_i = (int) dq[0], kk_i = (int) dq[1], uu_i = __float_as_int(uu), ww_i = __float_as_int(wdec);
+                const float vj = __uint_as_float(dq[2]);
+                float o = 0.0f;
+                float * so = sout_l + 2 * D + (long long) d_head * S * S;
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    const float ki = __int_as_float(__builtin_amdgcn_readlane(kk_i, i));
+                    const float ui = __int_as_float(__builtin_amdgcn_readlane(uu_i, i));
+                    const float ri = __int_as_float(__builtin_amdgcn_readlane(rr_i, i));
+                    const float wi = __int_as_float(__builtin_amdgcn_readlane(ww_i, i));
+                    const float kv = vj * ki;
+                    const float prev = s[i];
+                    const float temp = kv * ui + prev;
+                    o += temp * ri;
+                    so[i * S + lane] = prev * wi + kv;
+                }
+                // 4. GroupNorm over the head, * ln_x, gate
+                const float mean = (float) (wave_sum_d((double) o) / (double) S);
+                const float dv = o - mean;
+                const float var = (float) (wave_sum_d((double) (dv * dv)) / (double) S);
+                const float scale = 1.0f / sqrtf(var + 64e-5f);
+                float y = dv * scale;
+                y = y * lnw;
+                y = y + lnb;
+                y *= __uint_as_float(dq[3]);
+                int qi, isum; float d16, s16;
+                quant_block32(y, qi, d16, s16, isum);
+                tq_store_block(p.yq, nb, 2 * d_head + (lane >> 5), lane & 31, qi, d16, s16, isum, tagL + SLOT_YQ);
+            }
+            STAMP(5);
+            // ---- E ----
+            issue_pf(pf, ar, L, sin_l, lane0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_qvec<DU, 64>(pl, p.yq, D, tagL + SLOT_YQ, l.yq, lane);
+            STAMP(6);
+            __syncthreads();
+            // ---- F ----
+            poll_units<XU, 64>(pl, p.xatt, D, tagL + SLOT_XATT, lane, [&](int i, unsigned v) { l.x[i] = __uint_as_float(v); });
+            STAMP(7);
+            __syncthreads();
+            prologue_F(l, pf, sout_l, blk == 0, lane);
+            STAMP(8);
+            __syncthreads();   // workers' key rows are in l.out
+            STAMP(9);
+            {
+                // quantise this workgroup's key groups (relu^2 outputs): half-wave = group
+#pragma unroll
+                for (int g2 = 0; g2 < (GPB + 1) / 2; g2++) {
+                    const int gi = g2 * 2 + (lane >> 5);
+                    const int g = blk * GPB + gi;
+                    const bool valid = gi < GPB && g < nbF;
+                    const float v = valid ? l.out[gi * 32 + (lane & 31)] : 0.0f;
+                    int qi, isum; float d16, s16;
+                    quant_block32(v, qi, d16, s16, isum);
+                    tq_store_block(p.kq, nbF, valid ? g : 0, lane & 31, qi, d16, s16, isum, tagL + SLOT_KQ, valid);
+                }
+            }
+            STAMP(10);
+            // ---- G ----
+            {
+                const int nl = li + 1 < p.n_layers ? li + 1 : li;
+                issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, lane0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stage_qvec<KQU, 64>(pl, p.kq, F, tagL + SLOT_KQ, l.kq, lane);
+            poll_units<1, 64>(pl, p.rr + (long long) blk * RPB_E, RPB_E, tagL + SLOT_KQ, lane, [&](int i, unsigned v) { l.rr[i] = __uint_as_float(v); });
+            STAMP(11);
+            __syncthreads();
+            STAMP(12);
+        }
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // worker waves
+    // -----------------------------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void worker_main(const M6P & p, const Lds & l, int tid0, int wave) {
+        const int blk = blockIdx.x;
+        const int wk = wave - 1;
+        const int gwk = wk * NBLK + blk;
+        const int F = p.F, DR = p.DR, R = p.R;
+        const int nbF = F / 32;
+        const unsigned base = p.ctl[0];
+        const M6Arena ar{p.arena};
+        // small jobs
+        const int a_row = gwk; const bool a_has = a_row < 5 * R;                      // W1 row
+        const int x_row = gwk - 5 * R; const bool x_has = x_row >= 0 && x_row < DR;   // decay-W1 row
+        const int b_chunk = NWK * NBLK - 1 - gwk; const bool b_has = b_chunk < 5 * (D / 64);
+        const int b_f = b_has ? b_chunk / (D / 64) : 0;
+        const int b_d0 = (b_has ? b_chunk % (D / 64) : 0) * 64;
+        // C rows
+        const int c_mat = (blk * RPB_C) / D, c_base = (blk * RPB_C) % D;
+        // E / G / F-receptance rows
+        const int e_base = blk * RPB_E;
+        // F key rows
+        const int k_base = blk * GPB * 32;
+
+        float xown[NSE];
+#pragma unroll
+        for (int si = 0; si < NSE; si++) { const int j = wk + si * NWK; xown[si] = j < RPB_E ? p.x[e_base + j] : 0.0f; }
+
+        PA pa; PF pf;
+        Batch<FMT, 1, UD> wA, wCx;
+        float wB[64]; float wBmaa;
+        Batch<FMT, 2, UD> wC[NSC];
+        Batch<FMT, 1, UD> wE[NSE], wFr[NSE];
+        Batch<FMT, 2, UD> wFk[NSK];
+        Batch<FMT, 1, 4> wG[NSE][2];
+
+        auto issue_A = [&](const M6Layer & L, const float * sin_l, int tid, int lane) {
+            issue_pa(pa, ar, L, sin_l, tid);
+            batch_issue_opt<FMT, 1, UD>(a_has, wA, ar.w(L.w1), a_row, 5 * R, nb, 0, lane);
+        };
+        issue_A(p.layers[0], p.sin, tid0, tid0 & 63);
+
+        for (int li = 0; li < p.n_layers; li++) {
+            const float * sin_l = p.sin + (long long) li * p.state_stride;
+            float * sout_l = p.sout + (long long) li * p.state_stride;
+            const unsigned tagL = base + (unsigned) li * 8u;
+            const int tidst = tid0;
+            STAMP(0);
+
+            // =========================================== A ===========================================
+            {
+                const int tid = opq(tid0), lane = tid & 63;
+                const M6Layer & L = p.layers[opq_s(li)];
+                const WPl w_w1 = ar.w(L.w1);
+                {   // (workers without a chunk read one float of chunk 0: no traffic, no branch)
+                    const int b_d = b_has ? b_d0 + lane : 0;
+                    const float * col = ar.f(L.w2t) + (long long) b_f * R * D + b_d;
+                    const int rr = b_has ? R : 1;
+#pragma unroll
+                    for (int m = 0; m < 64; m++) wB[m] = col[(long long) (m < rr ? m : rr - 1) * D];
+                    wBmaa = ar.f(L.maa[b_f])[b_d];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(1);
+                __syncthreads();                       // x staged
+                STAMP(2);
+                prologue_A(l, pa, sout_l, blk == 0, tid);
+                STAMP(3);
+                if (a_has) {
+                    float res[1];
+                    rows_finish<FMT, 1, UD>(wA, w_w1.qs, w_w1.qh, w_w1.sc, a_row, 5 * R, nb, qvec_at(l.q1, D), lane, res);
+                    if (lane == 0) tg_store(p.tl + a_row, __float_as_uint(det_tanhf(res[0])), tagL + SLOT_TL);
+                }
+            }
+            // =========================================== B ===========================================
+            {
+                const int tid = opq(tid0), lane = tid & 63;
+                const M6Layer & L = p.layers[opq_s(li)];
+                const WPl w_c = ar.w(L.rkvg[c_mat]), w_dw1 = ar.w(L.dw1);
+#pragma unroll
+                for (int si = 0; si < NSC; si++) {
+                    const int s = wk + si * NWK;
+                    batch_issue_opt<FMT, 2, UD>(s < RPB_C / 2, wC[si], w_c, c_base + 2 * s, D, nb, 0, lane);
+                }
+                batch_issue_opt<FMT, 1, UD>(x_has, wCx, w_dw1, x_row, DR, nb, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(4);
+                __syncthreads();                       // tl staged
+                STAMP(5);
+                if (b_has) {
+                    const int b_d = b_d0 + lane;
+                    const float * tlf = l.tl + b_f * R;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int m = 0; m < 64; m++) if (m < R) acc += wB[m] * tlf[m];
+                    const float mm = (acc + wBmaa) * l.sx[b_d];
+                    const float o = mm + l.xn[b_d];
+                    int qi, isum; float d16, s16;
+                    quant_block32(o, qi, d16, s16, isum);
+                    tq_store_block(p.act5 + (long long) b_f * p.act_stride, nb, b_d >> 5, lane & 31, qi, d16, s16, isum, tagL + SLOT_ACT);
+                }
+            }
+            // =========================================== C ===========================================
+            {
+                const int tid = opq(tid0), lane = tid & 63;
+                const M6Layer & L = p.layers[opq_s(li)];
+                const WPl w_wo = ar.w(L.wo), w_c = ar.w(L.rkvg[c_mat]), w_dw1 = ar.w(L.dw1);
+                STAMP(6);
+                __syncthreads();                       // activation image(s) staged
+                STAMP(7);
+                if (x_has) {   // the decay row first: every head waits for all of dl
+                    float res[1];
+                    rows_finish<FMT, 1, UD>(wCx, w_dw1.qs, w_dw1.qh, w_dw1.sc, x_row, DR, nb, qvec_at(l.actw, D), lane, res);
+                    if (lane == 0) tg_store(p.dl + x_row, __float_as_uint(det_tanhf(res[0])), tagL + SLOT_RKVG);
+                }
+                const QVec la = qvec_at(l.act, D);
+#pragma unroll
+                for (int si = 0; si < NSC; si++) {
+                    const int s = wk + si * NWK;
+                    if (s < RPB_C / 2) {
+                        float res[2];
+                        rows_finish<FMT, 2, UD>(wC[si], w_c.qs, w_c.qh, w_c.sc, c_base + 2 * s, D, nb, la, lane, res);
+                        float v = pick_lane<2>(res, lane);
+                        if (c_mat == 3) v = v / (1.0f + det_expf(-v));
+                        if (lane < 2) tg_store(p.rkvg + (long long) c_mat * D + c_base + 2 * s + lane, __float_as_uint(v), tagL + SLOT_RKVG);
+                    }
+                }
+                // the output-projection rows go in flight now: the workers idle through the WKV phase anyway
+#pragma unroll
+                for (int si = 0; si < NSE; si++) {
+                    const int j = wk + si * NWK;
+                    batch_issue_opt<FMT, 1, UD>(j < RPB_E, wE[si], w_wo, e_base + j, D, nb, 0, lane);
+                }
+            }
+            // =========================================== E (workers have no part in D) ===========================================
+            {
+                const int tid = opq(tid0), lane = tid & 63;
+                const M6Layer & L = p.layers[opq_s(li)];
+                const WPl w_fk = ar.w(L.fk), w_fr = ar.w(L.fr), w_wo = ar.w(L.wo);
+#pragma unroll
+                for (int si = 0; si < NSK; si++) {
+                    const int s = wk + si * NWK;
+                    batch_issue_opt<FMT, 2, UD>(s < GPB * 16 && k_base + 2 * s < F, wFk[si], w_fk, k_base + 2 * s, F, nb, 0, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(8);
+                __syncthreads();                       // yq staged
+                STAMP(9);
+                const QVec la = qvec_at(l.yq, D);
+#pragma unroll
+                for (int si = 0; si < NSE; si++) {
+                    const int j = wk + si * NWK;
+                    if (j < RPB_E) {
+                        float res[1];
+                        rows_finish<FMT, 1, UD>(wE[si], w_wo.qs, w_wo.qh, w_wo.sc, e_base + j, D, nb, la, lane, res);
+                        xown[si] = xown[si] + res[0];
+                        if (lane == 0) tg_store(p.xatt + e_base + j, __float_as_uint(xown[si]), tagL + SLOT_XATT);
+                    }
+                }
+                // the channel-mixing prologue's parameters: they land while the comm wave waits for x_att
+                issue_pf(pf, ar, L, sin_l, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // =========================================== F ===========================================
+            {
+                const int tid = opq(tid0), lane = tid & 63;
+                const M6Layer & L = p.layers[opq_s(li)];
+                const WPl w_fk = ar.w(L.fk), w_fr = ar.w(L.fr), w_fv = ar.w(L.fv);
+                STAMP(10);
+                __syncthreads();                       // x_att staged
+                STAMP(11);
+                prologue_F(l, pf, sout_l, blk == 0, tid);
+                STAMP(12);
+                // receptance rows go in flight under the key rows
+#pragma unroll
+                for (int si = 0; si < NSE; si++) {
+                    const int j = wk + si * NWK;
+                    batch_issue_opt<FMT, 1, UD>(j < RPB_E, wFr[si], w_fr, e_base + j, D, nb, 0, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const QVec qk = qvec_at(l.q1, D), qr = qvec_at(l.q2, D);
+#pragma unroll
+                for (int si = 0; si < NSK; si++) {
+                    const int s = wk + si * NWK;
+                    if (s < GPB * 16 && k_base + 2 * s < F) {
+                        float res[2];
+                        rows_finish<FMT, 2, UD>(wFk[si], w_fk.qs, w_fk.qh, w_fk.sc, k_base + 2 * s, F, nb, qk, lane, res);
+                        const float v = pick_lane<2>(res, lane);
+                        const float t = v > 0.0f ? v : 0.0f;
+                        if (lane < 2) l.out[2 * s + lane] = t * t;
+                    }
+                }
+                // first half of the value-projection rows (K = F) goes in flight under the receptance rows
+#pragma unroll
+                for (int si = 0; si < NSE; si++) {
+                    const int j = wk + si * NWK;
+                    batch_issue_opt<FMT, 1, 4>(j < RPB_E, wG[si][0], w_fv, e_base + j, D, nbF, 0, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int si = 0; si < NSE; si++) {
+                    const int j = wk + si * NWK;
+                    if (j < RPB_E) {
+                        float res[1];
+                        rows_finish<FMT, 1, UD>(wFr[si], w_fr.qs, w_fr.qh, w_fr.sc, e_base + j, D, nb, qr, lane, res);
+                        if (lane == 0) tg_store(p.rr + e_base + j, __float_as_uint(res[0]), tagL + SLOT_KQ);
+                    }
+                }
+                STAMP(13);
+                __syncthreads();                       // key rows in l.out -> comm quantises them
+#pragma unroll
+                for (int si = 0; si < NSE; si++) {
+                    const int j = wk + si * NWK;
+                    batch_issue_opt<FMT, 1, 4>(j < RPB_E && nbF > 256, wG[si][1], w_fv, e_base + j, D, nbF, 256, lane);
+                }
+            }
+            // =========================================== G ===========================================
+            {
+                const int tid = opq(tid0), lane = tid & 63;
+                const M6Layer & L = p.layers[opq_s(li)];
+                {
+                    const int nl = li + 1 < p.n_layers ? li + 1 : li;
+                    issue_A(p.layers[nl], p.sin + (long long) nl * p.state_stride, tid, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(14);
+                __syncthreads();                       // kq and rr staged
+                STAMP(15);
+                const QVec lk = qvec_at(l.kq, F);
+#pragma unroll
+                for (int si = 0; si < NSE; si++) {
+                    const int j = wk + si * NWK;
+                    if (j < RPB_E) {
+                        float acc[1] = {0.0f};
+                        batch_consume<FMT, 1, 4>(wG[si][0], nbF, 0, lane, lk, acc);
+                        if (nbF > 256) batch_consume<FMT, 1, 4>(wG[si][1], nbF, 256, lane, lk, acc);
+                        const float v = wave_sum_f(acc[0]);
+                        const float gte = sigmoid_f(l.rr[j]) * v;
+                        xown[si] = xown[si] + gte;
+                        if (lane == 0) { tg_store(p.xffn + e_base + j, __float_as_uint(xown[si]), tagL + SLOT_XFFN); p.x[e_base + j] = xown[si]; }
+                    }
+                }
+                STAMP(16);
+            }
+        }
+    }
+};
+
+template <int FMT, int EPT, int KQU, int NBD, int GPB>
+__global__ __launch_bounds__(512) void k6_mega(M6P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef K6<FMT, EPT, KQU, NBD, GPB> K;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // wave-uniform: roles, row bases and predicates stay scalar
+    const M6Lds lo = m6_lds(K::D, p.F);
+    typename K::Lds l;
+    l.x = reinterpret_cast<float *>(smem + lo.x); l.xn = reinterpret_cast<float *>(smem + lo.xn); l.sx = reinterpret_cast<float *>(smem + lo.sx);
+    l.q1 = smem + lo.q1; l.q2 = smem + lo.q2; l.act = smem + lo.act; l.actw = smem + lo.actw; l.yq = smem + lo.yq; l.kq = smem + lo.kq;
+    l.tl = reinterpret_cast<float *>(smem + lo.tl); l.red = reinterpret_cast<double *>(smem + lo.red);
+    l.out = reinterpret_cast<float *>(smem + lo.out); l.rr = reinterpret_cast<float *>(smem + lo.rr); l.dl = smem + lo.dl;
+    const unsigned base = p.ctl[0];
+    if (wave == 0) K::comm_main(p, l, tid0, base);
+    else K::worker_main(p, l, tid0, wave);
+    if (blockIdx.x == 0 && tid0 == 0) p.ctl[0] = base + (unsigned) p.n_layers * 8u;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -627,16 +812,17 @@ struct MegaV6 {
     void * xch = nullptr;
     unsigned * ctl = nullptr;
     M6P proto{};
+    long long * trace = nullptr;
     int variant = -1, n_blocks = 0;
     size_t lds = 0;
     uint64_t bytes = 0;   // algorithmic bytes of one launch: every layer tensor once + the recurrent state read and written
 };
 
 typedef void (*MegaKernel)(M6P);
-struct MegaVariant { int fmt, ept, kqu, nbd; MegaKernel fn; };
+struct MegaVariant { int fmt, ept, kqu, nbd, gpb; MegaKernel fn; };
 static const MegaVariant g_variants[] = {
-    {T_Q4_0, 8, 9, 4, k6_mega<T_Q4_0, 8, 9, 4>},
-    {T_Q4_0, 4, 5, 2, k6_mega<T_Q4_0, 4, 5, 2>},
+    {T_Q4_0, 8, 70, 4, 2, k6_mega<T_Q4_0, 8, 70, 4, 2>},   // D 4096, F <= 14336, decay rank 128
+    {T_Q4_0, 4, 35, 2, 1, k6_mega<T_Q4_0, 4, 35, 2, 1>},   // D 2048, F <= 7168,  decay rank 64
 };
 
 static int mega_variant(const Model & m, int n_cu) {
@@ -646,8 +832,8 @@ static int mega_variant(const Model & m, int n_cu) {
     const LayerW & L0 = m.layers[m.layer_begin];
     if (!L0.ffn_key || !L0.att_time_decay_w1 || !L0.att_time_maa_w1) return -1;
     const int64_t F = L0.ffn_key->ne[1], DR = L0.att_time_decay_w1->ne[1], R5 = L0.att_time_maa_w1->ne[1], R = R5 / 5;
-    const int64_t NB = n_cu, W = NB * 8;
-    if (H > NB || DR > NB || F % 32 != 0 || F / 32 > 2 * NB || 5 * (D / 64) > W || D / 2 > W || R > 64 || R5 > 1280 || R5 > W) return -1;
+    const int64_t NB = 256, NW = NB * 7;   // the kernel is laid out for exactly 256 workgroups (one per CU of an MI355X)
+    if (n_cu != NB || H > NB || F % 32 != 0 || 5 * (D / 64) + R5 + DR > NW || R > 64 || R5 > 320) return -1;
     for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
         const LayerW & L = m.layers[i];
         const DevTensor * mats[] = {L.att_receptance, L.att_key, L.att_value, L.att_gate, L.att_output, L.att_time_maa_w1,
@@ -657,7 +843,7 @@ static int mega_variant(const Model & m, int n_cu) {
     }
     for (size_t v = 0; v < sizeof(g_variants) / sizeof(g_variants[0]); v++) {
         const MegaVariant & mv = g_variants[v];
-        if (mv.fmt == fmt && D == mv.ept * 512 && 10 * (F / 32) <= (int64_t) mv.kqu * 512 && DR == mv.nbd * 32) return (int) v;
+        if (mv.fmt == fmt && D == mv.ept * 512 && 10 * (F / 32) <= (int64_t) mv.kqu * 64 && DR == mv.nbd * 32 && (F / 32 + NB - 1) / NB == mv.gpb) return (int) v;
     }
     return -1;
 }
@@ -688,7 +874,15 @@ void * mega_v6_create(const Model & m) {
     }
     (void) hipFuncSetAttribute((const void *) g_variants[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) mg->lds);
     std::vector<M6Layer> hl;
-    auto f = [](const DevTensor * t) { return (const float *) t->data; };
+    const unsigned char * abase = (const unsigned char *) m.arena;
+    bool in_arena = true;
+    auto off = [&](const void * ptr) -> long long {
+        const long long o = (const unsigned char *) ptr - abase;
+        if (!ptr || o < 0 || (uint64_t) o >= m.arena_bytes) in_arena = false;
+        return o;
+    };
+    auto f = [&](const DevTensor * t) { return off(t->data); };
+    auto pl3 = [&](const DevTensor * t) { M6Off o; o.qs = off(t->qs); o.qh = t->qh ? off(t->qh) : 0; o.sc = off(t->sc); return o; };
     uint64_t bytes = 0;
     for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
         const LayerW & L = m.layers[i];
@@ -698,10 +892,10 @@ void * mega_v6_create(const Model & m) {
         d.w2t = f(L.att_time_maa_w2); d.time_decay = f(L.att_time_decay); d.faaaa = f(L.att_time_faaaa);
         d.lnx_w = f(L.att_ln_x_w); d.lnx_b = f(L.att_ln_x_b); d.ln2_w = f(L.ln2_w); d.ln2_b = f(L.ln2_b);
         d.fmaa_k = f(L.ffn_time_maa_k); d.fmaa_r = f(L.ffn_time_maa_r);
-        d.w1 = planes(L.att_time_maa_w1);
-        d.rkvg[0] = planes(L.att_receptance); d.rkvg[1] = planes(L.att_key); d.rkvg[2] = planes(L.att_value); d.rkvg[3] = planes(L.att_gate);
-        d.dw1 = planes(L.att_time_decay_w1); d.dw2 = planes(L.att_time_decay_w2); d.wo = planes(L.att_output);
-        d.fk = planes(L.ffn_key); d.fr = planes(L.ffn_receptance); d.fv = planes(L.ffn_value);
+        d.w1 = pl3(L.att_time_maa_w1);
+        d.rkvg[0] = pl3(L.att_receptance); d.rkvg[1] = pl3(L.att_key); d.rkvg[2] = pl3(L.att_value); d.rkvg[3] = pl3(L.att_gate);
+        d.dw1 = pl3(L.att_time_decay_w1); d.dw2 = pl3(L.att_time_decay_w2); d.wo = pl3(L.att_output);
+        d.fk = pl3(L.ffn_key); d.fr = pl3(L.ffn_receptance); d.fv = pl3(L.ffn_value);
         hl.push_back(d);
         const DevTensor * all[] = {L.ln1_w, L.ln1_b, L.att_time_maa_x, L.att_time_maa_w, L.att_time_maa_k, L.att_time_maa_v, L.att_time_maa_r, L.att_time_maa_g,
                                    L.att_time_maa_w1, L.att_time_maa_w2, L.att_time_decay, L.att_time_faaaa, L.att_time_decay_w1, L.att_time_decay_w2,
@@ -711,9 +905,14 @@ void * mega_v6_create(const Model & m) {
         bytes += 2 * (uint64_t) m.state_per_layer() * sizeof(float);
     }
     mg->bytes = bytes;
+    if (!in_arena) { delete mg; return nullptr; }
     const int64_t nbD = D / 32, nbF = F / 32;
-    const int64_t act_stride = (10 * nbD + 31) / 32 * 32;
-    const int64_t units = 1280 + 5 * act_stride + 4 * D + 256 + act_stride + D + (10 * nbF + 31) / 32 * 32 + D + D;
+    const int64_t PAD = 512;   // polls read whole 64-unit rounds: keep every buffer readable past its end
+    auto up = [](int64_t v) { return (v + 63) / 64 * 64; };
+    const int64_t act_stride = up(10 * nbD);
+    const int64_t sizes[9] = {up(1280) + PAD, 5 * act_stride + PAD, 4 * D + PAD, 256 + PAD, act_stride + PAD, D + PAD, up(10 * nbF) + PAD, D + PAD, D + PAD};
+    int64_t units = 0;
+    for (int64_t z : sizes) units += z;
     bool ok = hipMalloc((void **) &mg->d_layers, hl.size() * sizeof(M6Layer)) == hipSuccess
            && hipMemcpy(mg->d_layers, hl.data(), hl.size() * sizeof(M6Layer), hipMemcpyHostToDevice) == hipSuccess
            && hipMalloc(&mg->xch, (size_t) units * 8) == hipSuccess && hipMemset(mg->xch, 0, (size_t) units * 8) == hipSuccess
@@ -723,21 +922,26 @@ void * mega_v6_create(const Model & m) {
     if (!ok) { mega_v6_destroy(mg); return nullptr; }
     M6P & q = mg->proto;
     q.layers = mg->d_layers; q.n_layers = (int) hl.size();
+    q.arena = abase;
     q.state_stride = m.state_per_layer();
     u64 * u = (u64 *) mg->xch;
-    q.tl = u; u += 1280;
-    q.act5 = u; u += 5 * act_stride; q.act_stride = act_stride;
-    q.rkvg = u; u += 4 * D;
-    q.dl = u; u += 256;
-    q.yq = u; u += act_stride;
-    q.xatt = u; u += D;
-    q.kq = u; u += (10 * nbF + 31) / 32 * 32;
-    q.rr = u; u += D;
-    q.xffn = u; u += D;
+    u64 ** slots[9] = {&q.tl, &q.act5, &q.rkvg, &q.dl, &q.yq, &q.xatt, &q.kq, &q.rr, &q.xffn};
+    for (int i = 0; i < 9; i++) { *slots[i] = u; u += sizes[i]; }
+    q.act_stride = act_stride;
     q.ctl = mg->ctl;
     q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;
     q.gpb = (int) ((nbF + NB - 1) / NB);
     return mg;
+}
+
+// debug: cycle stamps of one layer (16 per wave) for the next launches; out must hold n_blocks * 8 * 32 values
+bool mega_v6_trace(void * h, int layer, long long * out, bool fetch) {
+    MegaV6 * mg = (MegaV6 *) h;
+    const size_t n = (size_t) mg->n_blocks * 8 * 32;
+    if (!mg->trace) { if (hipMalloc((void **) &mg->trace, n * 8) != hipSuccess) return false; (void) hipMemset(mg->trace, 0, n * 8); }
+    mg->proto.trace = mg->trace; mg->proto.trace_layer = layer;
+    if (fetch) return hipMemcpy(out, mg->trace, n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    return true;
 }
 
 uint64_t mega_v6_bytes(void * h) { return ((MegaV6 *) h)->bytes; }

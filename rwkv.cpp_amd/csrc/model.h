@@ -150,6 +150,7 @@ void     mega_v6_destroy(void * h);
 void     mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf);
 bool     mega_v6_aborted(void * h);
 uint64_t mega_v6_bytes(void * h);
+bool     mega_v6_trace(void * h, int layer, long long * out, bool fetch);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
 bool forward_decode(rwkv_context * ctx, bool want_logits);
 // grows the per-context activation scratch to hold T tokens
