@@ -25,7 +25,8 @@
 
 namespace rwkvmi {
 
-typedef unsigned long long u64;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef volatile __attribute__((address_space(1))) v4u gv4u;
 
 // Per-layer table in HBM: byte offsets from the parameter arena. A pointer READ FROM MEMORY is generic to the compiler and
 // generic (FLAT) loads also count on the LDS counter -- every LDS wait would then wait for the weight prefetch in flight;
@@ -33,7 +34,7 @@ typedef unsigned long long u64;
 // scalar loads where they are used, not held across the layer.
 struct M6Off { long long qs, qh, sc; };
 struct M6Layer {
-    long long ln1_w, ln1_b, maa_x, maa[5], w2t, time_decay, faaaa, lnx_w, lnx_b, ln2_w, ln2_b, fmaa_k, fmaa_r;
+    long long ln1_w, ln1_b, maa_x, maa[5], w2b /* floats into M6P::w2b */, time_decay, faaaa, lnx_w, lnx_b, ln2_w, ln2_b, fmaa_k, fmaa_r;
     M6Off w1, rkvg[4], dw1, dw2, wo, fk, fr, fv;
 };
 struct M6Arena {
@@ -47,9 +48,11 @@ struct M6Arena {
 struct M6P {
     const M6Layer * layers; int n_layers;
     const unsigned char * arena;
+    const float * w2b;                               // W2 of every layer in the chunk-blocked layout (see k_block_w2)
     float * x;                                       // plain residual stream: input of the first layer, output of the last
     const float * sin; float * sout; long long state_stride;
-    u64 *tl, *act5, *rkvg, *dl, *yq, *xatt, *kq, *rr, *xffn;   // tagged exchange buffers
+    void * xch; unsigned xch_bytes;                   // the exchange arena: every tagged buffer lives in it ...
+    int tl, act5, rkvg, dl, yq, xatt, kq, rr, xffn;   // ... at these unit (16-byte) offsets
     long long act_stride;                            // units between the five mix images
     unsigned * ctl;                                  // [0] tag generation, [1] abort
     int F, DR, R, H, gpb;
@@ -60,94 +63,106 @@ struct M6P {
 // tagged exchange
 // ---------------------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void tg_store(u64 * p, unsigned payload, unsigned tag) {
-    __hip_atomic_store(p, ((u64) tag << 32) | (u64) payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// A unit is 16 bytes {p0, p1, p2, (aux16 << 16) | tag16}, written with ONE 16-byte store and read with ONE 16-byte load
+// (sc0 sc1: past the non-coherent caches). 16-byte aligned vector accesses are single-copy on this memory system
+// (tools/tear16.hip: 3e8 concurrent reads against 5e7 updates from other XCDs, no torn unit), so a unit whose tag matches
+// carries its whole payload. The tag is a 16-bit rolling generation; the stale content of a unit is always the previous
+// generation of the same buffer.
+// Accesses go through one raw buffer descriptor over the exchange arena with the sc1 (agent scope) cache policy only:
+// past the per-XCD L2 for foreign lines, but not the system-scope path a volatile access would take (measured ~2x slower).
+typedef __amdgpu_buffer_rsrc_t xrsrc;
+__device__ __forceinline__ xrsrc make_xrsrc(void * base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int) bytes, 0x00020000); }
+__device__ __forceinline__ void tg_store(xrsrc xr, int unit, unsigned a, unsigned b, unsigned c, unsigned aux16, unsigned tag) {
+    const v4u v = {a, b, c, (aux16 << 16) | (tag & 0xFFFFu)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, xr, unit * 16, 0, 16);
 }
-__device__ __forceinline__ u64 tg_load(const u64 * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ v4u tg_load(xrsrc xr, int unit) { return __builtin_amdgcn_raw_buffer_load_b128(xr, unit * 16, 0, 16); }
+__device__ __forceinline__ bool tg_ok(const v4u & v, unsigned tag) { return (v.w & 0xFFFFu) == (tag & 0xFFFFu); }
 
 struct Poll { unsigned * ctl; bool dead; };
+
+__device__ __forceinline__ bool poll_backoff(Poll & pl, unsigned spin) {
+    if ((spin & 63u) == 63u) {
+        if (__hip_atomic_load(pl.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) pl.dead = true;
+        else if (spin > 3000000u) { __hip_atomic_store(pl.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pl.dead = true; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+    return pl.dead;
+}
 
 // Core: N units per lane given by address; all loads of an attempt are issued together; an attempt succeeds for the wave
 // when every lane saw the expected tag on all of its valid units (invalid slots carry a harmless duplicate address).
 template <int N>
-__device__ __forceinline__ void poll_ptrs(Poll & pl, const u64 * const (&ptr)[N], const bool (&valid)[N], unsigned tag, unsigned (&out)[N]) {
-    u64 v[N];
+__device__ __forceinline__ void poll_ptrs(Poll & pl, xrsrc xr, const int (&ptr)[N], const bool (&valid)[N], unsigned tag, v4u (&out)[N]) {
     for (unsigned spin = 0;; spin++) {
+        asm volatile("" ::: "memory");   // the loads below are not volatile (that would make them system scope): keep them in the loop
 #pragma unroll
-        for (int u = 0; u < N; u++) v[u] = tg_load(ptr[u]);
+        for (int u = 0; u < N; u++) out[u] = tg_load(xr, ptr[u]);
         bool ok = true;
 #pragma unroll
-        for (int u = 0; u < N; u++) ok = ok && (!valid[u] || (unsigned) (v[u] >> 32) == tag);
+        for (int u = 0; u < N; u++) ok = ok && (!valid[u] || tg_ok(out[u], tag));
         if (__all(ok) || pl.dead) break;
-        if ((spin & 63u) == 63u) {
-            if (__hip_atomic_load(pl.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) pl.dead = true;
-            else if (spin > 3000000u) { __hip_atomic_store(pl.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pl.dead = true; }
-        }
-        __builtin_amdgcn_s_sleep(1);
+        if (poll_backoff(pl, spin)) break;
     }
-#pragma unroll
-    for (int u = 0; u < N; u++) out[u] = (unsigned) v[u];
 }
 
-// Threads tid, tid + NT, ... own units of a contiguous range; sink(i, payload) runs once per unit.
+// Lanes tid, tid + NT, ... own units of a contiguous range; sink(i, unit) runs once per unit.
 // The buffer is padded to MAXU * NT units, so every slot is loaded unclamped (base + immediate offset addressing, no
-// per-slot address registers); slots past n are simply not checked. Long ranges are polled in rounds of at most 24
-// loads per lane (48 result registers): the first round absorbs the wait, the others normally pass at once.
-template <int MAXU, int NT, int U0, int UN, typename Sink>
-__device__ __forceinline__ void poll_round(Poll & pl, const u64 * mine, int n, unsigned tag, int tid, Sink && sink) {
-    u64 v[UN];
+// per-slot address registers); slots past n are simply not checked.
+template <int MAXU, int NT, typename Sink>
+__device__ __forceinline__ void poll_units(Poll & pl, xrsrc xr, int src, int n, unsigned tag, int tid, Sink && sink) {
+    static_assert(MAXU <= 28, "poll_units: range too long for one round");
+    const int mine = src + tid;
+    v4u v[MAXU];
     for (unsigned spin = 0;; spin++) {
+        asm volatile("" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < UN; u++) v[u] = tg_load(mine + (U0 + u) * NT);
+        for (int u = 0; u < MAXU; u++) v[u] = tg_load(xr, mine + u * NT);
         bool ok = true;
 #pragma unroll
-        for (int u = 0; u < UN; u++) ok = ok && (tid + (U0 + u) * NT >= n || (unsigned) (v[u] >> 32) == tag);
+        for (int u = 0; u < MAXU; u++) ok = ok && (tid + u * NT >= n || tg_ok(v[u], tag));
         if (__all(ok) || pl.dead) break;
-        if ((spin & 63u) == 63u) {
-            if (__hip_atomic_load(pl.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) pl.dead = true;
-            else if (spin > 3000000u) { __hip_atomic_store(pl.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pl.dead = true; }
-        }
-        __builtin_amdgcn_s_sleep(1);
+        if (poll_backoff(pl, spin)) break;
     }
 #pragma unroll
-    for (int u = 0; u < UN; u++) if (tid + (U0 + u) * NT < n) sink(tid + (U0 + u) * NT, (unsigned) v[u]);
+    for (int u = 0; u < MAXU; u++) if (tid + u * NT < n) sink(tid + u * NT, v[u]);
 }
 
-template <int MAXU, int NT, typename Sink>
-__device__ __forceinline__ void poll_units(Poll & pl, const u64 * src, int n, unsigned tag, int tid, Sink && sink) {
-    constexpr int CH = 24;
-    const u64 * mine = src + tid;
-    poll_round<MAXU, NT, 0, (MAXU < CH ? MAXU : CH)>(pl, mine, n, tag, tid, sink);
-    if constexpr (MAXU > CH) poll_round<MAXU, NT, CH, (MAXU - CH < CH ? MAXU - CH : CH)>(pl, mine, n, tag, tid, sink);
-    if constexpr (MAXU > 2 * CH) poll_round<MAXU, NT, 2 * CH, (MAXU - 2 * CH < CH ? MAXU - 2 * CH : CH)>(pl, mine, n, tag, tid, sink);
-    static_assert(MAXU <= 3 * CH, "poll_units: range too long");
-}
-
-// A quantised vector of K elements travels as 10 units per 32-element block: units [0, 8 nb) are the dwords of the lohi
-// q image, [8 nb, 9 nb) the fp16 pair {d, s}, [9 nb, 10 nb) the integer sum.
+// A quantised vector of K elements travels as 3 units per 32-element block b (dwords q0..q7 of the block, elements 4j..4j+3
+// in dword j):  unit 3b = {q0, q1, q2},  3b+1 = {q3, q4, q5},  3b+2 = {q6, q7, fp16 pair {d, s}} with the integer sum in aux16.
 __device__ __forceinline__ unsigned f16_bits(float v) { return (unsigned) __half_as_ushort(__float2half_rn(v)); }
 
-// One block from the 32 lanes of a half-wave (lane e holds element e): 4 lanes pack a dword, the quad leader stores it.
-__device__ __forceinline__ void tq_store_block(u64 * base, int nb, int blk, int e, int qi, float d16, float s16, int isum, unsigned tag, bool valid = true) {
+// One block from the 32 lanes of a half-wave (lane e holds element e): quads pack dwords, lanes 0..2 of the half-wave gather
+// three each and store one unit each.
+__device__ __forceinline__ void tq_store_block(xrsrc xr, int base, int blk, int e, int qi, float d16, float s16, int isum, unsigned tag, bool valid = true) {
     int w = (qi & 0xFF) << (8 * (e & 3));
     w |= lane_xor1_i(w);
-    w |= lane_xor2_i(w);
-    if (!valid) return;
-    if ((e & 3) == 0) tg_store(base + (e < 16 ? 0 : 4 * nb) + blk * 4 + ((e & 15) >> 2), (unsigned) w, tag);
-    if (e == 0) {
-        tg_store(base + 8 * nb + blk, f16_bits(d16) | (f16_bits(s16) << 16), tag);
-        tg_store(base + 9 * nb + blk, (unsigned) isum, tag);
-    }
+    w |= lane_xor2_i(w);                       // every lane of quad j holds dword j
+    const int half0 = (int) (threadIdx.x & 32);
+    const int k = e < 3 ? e : 0;               // unit of this lane
+    const int g0 = __shfl(w, half0 + 4 * (3 * k), WAVE);
+    const int g1 = __shfl(w, half0 + 4 * (3 * k + 1), WAVE);
+    const int g2 = __shfl(w, half0 + 4 * ((3 * k + 2) & 7), WAVE);
+    if (!valid || e >= 3) return;
+    if (e < 2) tg_store(xr, base + 3 * blk + e, (unsigned) g0, (unsigned) g1, (unsigned) g2, 0u, tag);
+    else tg_store(xr, base + 3 * blk + 2, (unsigned) g0, (unsigned) g1, f16_bits(d16) | (f16_bits(s16) << 16), (unsigned) isum & 0xFFFFu, tag);
 }
 
 template <int MAXU, int NT>
-__device__ __forceinline__ void stage_qvec(Poll & pl, const u64 * src, int K, unsigned tag, unsigned char * l, int tid) {
+__device__ __forceinline__ void stage_qvec(Poll & pl, xrsrc xr, int src, int K, unsigned tag, unsigned char * l, int tid) {
     const int nb = K / 32;
     const QVec q = qvec_at(l, K);
-    poll_units<MAXU, NT>(pl, src, 10 * nb, tag, tid, [&](int i, unsigned v) {
-        if (i < 8 * nb) reinterpret_cast<unsigned *>(l)[i] = v;
-        else if (i < 9 * nb) { q.d[i - 8 * nb] = h2f_bits((uint16_t) (v & 0xFFFFu)); q.s[i - 8 * nb] = h2f_bits((uint16_t) (v >> 16)); }
-        else q.isum[i - 9 * nb] = (int) v;
+    unsigned * lo = reinterpret_cast<unsigned *>(l);
+    unsigned * hi = reinterpret_cast<unsigned *>(l + nb * 16);
+    poll_units<MAXU, NT>(pl, xr, src, 3 * nb, tag, tid, [&](int i, const v4u & v) {
+        const int b = i / 3, k = i - 3 * b;
+        if (k == 0) { lo[b * 4 + 0] = v.x; lo[b * 4 + 1] = v.y; lo[b * 4 + 2] = v.z; }
+        else if (k == 1) { lo[b * 4 + 3] = v.x; hi[b * 4 + 0] = v.y; hi[b * 4 + 1] = v.z; }
+        else {
+            hi[b * 4 + 2] = v.x; hi[b * 4 + 3] = v.y;
+            q.d[b] = h2f_bits((uint16_t) (v.z & 0xFFFFu)); q.s[b] = h2f_bits((uint16_t) (v.z >> 16));
+            q.isum[b] = (int) (short) (v.w >> 16);
+        }
     });
 }
 
@@ -262,8 +277,20 @@ struct K6 {
     static constexpr int RPB_E = D / NBLK;               // output / receptance / value rows per workgroup
     static constexpr int NSE = (RPB_E + NWK - 1) / NWK;
     static constexpr int NSK = (GPB * 16 + NWK - 1) / NWK;
-    static constexpr int XU = D / 64;                    // poll slots per lane for an f32 D-vector
-    static constexpr int DU = (10 * nb + 63) / 64;       // ... for a quantised D-vector
+    static constexpr int XU = (NBLK * NWK + 63) / 64;    // poll slots per lane for x / rr (one unit per worker: its 2-3 rows)
+    static constexpr int DU = (3 * nb + 63) / 64;        // ... for a quantised D-vector
+    static_assert(NSE <= 3, "a worker's rows of x must fit one unit");
+    // rows of the residual stream owned by worker wk of a workgroup: consecutive, the first RPB_E % NWK workers one more
+    static __device__ __forceinline__ int e_cnt(int wk) { return RPB_E / NWK + (wk < RPB_E % NWK ? 1 : 0); }
+    static __device__ __forceinline__ int e_start(int wk) { return wk * (RPB_E / NWK) + (wk < RPB_E % NWK ? wk : RPB_E % NWK); }
+    // sink of an x-like vector: unit i = (workgroup, worker) -> its rows of dst
+    static __device__ __forceinline__ void x_sink(float * dst, int i, const v4u & v) {
+        const int b = i / NWK, wk = i - b * NWK;
+        const int st = b * RPB_E + e_start(wk), n = e_cnt(wk);
+        dst[st] = __uint_as_float(v.x);
+        if (n > 1) dst[st + 1] = __uint_as_float(v.y);
+        if (n > 2) dst[st + 2] = __uint_as_float(v.z);
+    }
 
     struct Lds {
         float *x, *xn, *sx, *tl, *out, *rr;
@@ -380,6 +407,7 @@ struct K6 {
         const int nbF = F / 32;
         Poll pl{p.ctl, false};
         const M6Arena ar{p.arena};
+        const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         // which activation images this workgroup's workers read in C
         const int blk_mat = (blk * RPB_C) / D;
         const int blk_act = (0x4213 >> (4 * blk_mat)) & 0xF;   // r,k,v,g -> mix image (w,k,v,r,g order)
@@ -387,6 +415,11 @@ struct K6 {
         for (int wk = 0; wk < NWK; wk++) { const int g = wk * NBLK + blk - 5 * R; blk_xhas = blk_xhas || (g >= 0 && g < DR); }
         const bool d_has = blk < H;
         const int d_head = blk;
+        // B: 64-element chunks of the five mixes; chunk c < NBLK on workgroup c, the rest on the LAST workgroups (the first
+        // ones run the WKV heads)
+        constexpr int NCH = 5 * (D / 64);
+        const int b_extra = NCH - NBLK;   // chunks beyond one per workgroup (host guarantees <= NBLK)
+        const int b_chunk2 = (b_extra > 0 && blk >= NBLK - b_extra) ? NBLK + (blk - (NBLK - b_extra)) : -1;
         PA pa; PF pf;
         issue_pa(pa, ar, p.layers[0], p.sin, lane0);
 
@@ -402,21 +435,54 @@ struct K6 {
             // ---- A ----
             if (li == 0) {
 #pragma unroll 8
-                for (int u = 0; u < XU; u++) l.x[lane + u * 64] = p.x[lane + u * 64];
+                for (int u = 0; u < D / 64; u++) l.x[lane + u * 64] = p.x[lane + u * 64];
             } else {
-                poll_units<XU, 64>(pl, p.xffn, D, tagL - 8u + SLOT_XFFN, lane, [&](int i, unsigned v) { l.x[i] = __uint_as_float(v); });
+                poll_units<XU, 64>(pl, xr, p.xffn, NBLK * NWK, tagL - 8u + SLOT_XFFN, lane, [&](int i, const v4u & v) { x_sink(l.x, i, v); });
             }
+            // W2 of this workgroup's chunk(s): chunk-blocked copy, lane d reads float4 {m .. m+3}; in flight across the prologue
+            float4 wB4[2][16]; float wBmaa[2];
+            int bf[2], bd[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int ch = q == 0 ? (blk < NCH ? blk : 0) : (b_chunk2 >= 0 ? b_chunk2 : 0);
+                bf[q] = ch / (D / 64);
+                bd[q] = (ch % (D / 64)) * 64 + lane;
+                const float4 * cb = reinterpret_cast<const float4 *>(p.w2b + L.w2b + (long long) ch * R * 64);
+#pragma unroll
+                for (int m4 = 0; m4 < 16; m4++) wB4[q][m4] = cb[(m4 < R / 4 ? m4 : R / 4 - 1) * 64 + lane];
+                wBmaa[q] = ar.f(L.maa[bf[q]])[bd[q]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             STAMP(1);
             __syncthreads();
             prologue_A(l, pa, sout_l, blk == 0, lane);
             STAMP(2);
-            // ---- B ----
-            poll_units<5, 64>(pl, p.tl, 5 * R, tagL + SLOT_TL, lane, [&](int i, unsigned v) { l.tl[i] = __uint_as_float(v); });
-            STAMP(3);
-            __syncthreads();
+            // ---- B: the data-dependent mixes of this workgroup's chunk(s) (rwkv_graph.inc:313-346) ----
+            {
+                // (the W2 columns of this workgroup's chunk(s) were put in flight before the prologue)
+                __builtin_amdgcn_sched_barrier(0);
+                poll_units<5, 64>(pl, xr, p.tl, 5 * R, tagL + SLOT_TL, lane, [&](int i, const v4u & v) { l.tl[i] = __uint_as_float(v.x); });
+                __builtin_amdgcn_wave_barrier();
+                STAMP(3);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const bool has = q == 0 ? blk < NCH : b_chunk2 >= 0;
+                    if (has) {
+                        const float * tlf = l.tl + bf[q] * R;
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int m = 0; m < 64; m++) if (m < R) acc += (&wB4[q][m >> 2].x)[m & 3] * tlf[m];
+                        const float mm = (acc + wBmaa[q]) * l.sx[bd[q]];
+                        const float o = mm + l.xn[bd[q]];
+                        int qi, isum; float d16, s16;
+                        quant_block32(o, qi, d16, s16, isum);
+                        tq_store_block(xr, p.act5 + bf[q] * (int) p.act_stride, bd[q] >> 5, lane & 31, qi, d16, s16, isum, tagL + SLOT_ACT);
+                    }
+                }
+            }
             // ---- C ----
-            stage_qvec<DU, 64>(pl, p.act5 + (long long) blk_act * p.act_stride, D, tagL + SLOT_ACT, l.act, lane);
-            if (blk_xhas) stage_qvec<DU, 64>(pl, p.act5, D, tagL + SLOT_ACT, l.actw, lane);
+            stage_qvec<DU, 64>(pl, xr, p.act5 + blk_act * (int) p.act_stride, D, tagL + SLOT_ACT, l.act, lane);
+            if (blk_xhas) stage_qvec<DU, 64>(pl, xr, p.act5, D, tagL + SLOT_ACT, l.actw, lane);
             STAMP(4);
             __syncthreads();
             // ---- D: WKV head of this workgroup ----
@@ -434,9 +500,15 @@ struct K6 {
                 __builtin_amdgcn_sched_barrier(0);
                 unsigned dq[6];
                 {
-                    const u64 * ptr[6] = {p.rkvg + c, p.rkvg + D + c, p.rkvg + 2 * D + c, p.rkvg + 3 * D + c, p.dl + lane, p.dl + (NBD > 2 ? 64 + lane : lane)};
+                    // r,k,v,g of channel c: one unit per 2-row set; dl: one unit per value
+                    const int ptr[6] = {p.rkvg + (c >> 1), p.rkvg + ((D + c) >> 1), p.rkvg + ((2 * D + c) >> 1), p.rkvg + ((3 * D + c) >> 1),
+                                          p.dl + lane, p.dl + (NBD > 2 ? 64 + lane : lane)};
                     const bool valid[6] = {true, true, true, true, true, NBD > 2};
-                    poll_ptrs<6>(pl, ptr, valid, tagL + SLOT_RKVG, dq);
+                    v4u dv[6];
+                    poll_ptrs<6>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) dq[q] = (c & 1) ? dv[q].y : dv[q].x;
+                    dq[4] = dv[4].x; dq[5] = dv[5].x;
                 }
                 // 1. quantise dl (DR = 32 NBD elements) into LDS: half-wave = block
                 const QVec ldl = qvec_at(l.dl, NBD * 32);
@@ -492,17 +564,17 @@ struct K6 {
                 y *= __uint_as_float(dq[3]);
                 int qi, isum; float d16, s16;
                 quant_block32(y, qi, d16, s16, isum);
-                tq_store_block(p.yq, nb, 2 * d_head + (lane >> 5), lane & 31, qi, d16, s16, isum, tagL + SLOT_YQ);
+                tq_store_block(xr, p.yq, 2 * d_head + (lane >> 5), lane & 31, qi, d16, s16, isum, tagL + SLOT_YQ);
             }
             STAMP(5);
             // ---- E ----
             issue_pf(pf, ar, L, sin_l, lane0);
             __builtin_amdgcn_sched_barrier(0);
-            stage_qvec<DU, 64>(pl, p.yq, D, tagL + SLOT_YQ, l.yq, lane);
+            stage_qvec<DU, 64>(pl, xr, p.yq, D, tagL + SLOT_YQ, l.yq, lane);
             STAMP(6);
             __syncthreads();
             // ---- F ----
-            poll_units<XU, 64>(pl, p.xatt, D, tagL + SLOT_XATT, lane, [&](int i, unsigned v) { l.x[i] = __uint_as_float(v); });
+            poll_units<XU, 64>(pl, xr, p.xatt, NBLK * NWK, tagL + SLOT_XATT, lane, [&](int i, const v4u & v) { x_sink(l.x, i, v); });
             STAMP(7);
             __syncthreads();
             prologue_F(l, pf, sout_l, blk == 0, lane);
@@ -519,7 +591,7 @@ struct K6 {
                     const float v = valid ? l.out[gi * 32 + (lane & 31)] : 0.0f;
                     int qi, isum; float d16, s16;
                     quant_block32(v, qi, d16, s16, isum);
-                    tq_store_block(p.kq, nbF, valid ? g : 0, lane & 31, qi, d16, s16, isum, tagL + SLOT_KQ, valid);
+                    tq_store_block(xr, p.kq, valid ? g : 0, lane & 31, qi, d16, s16, isum, tagL + SLOT_KQ, valid);
                 }
             }
             STAMP(10);
@@ -529,8 +601,8 @@ struct K6 {
                 issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, lane0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            stage_qvec<KQU, 64>(pl, p.kq, F, tagL + SLOT_KQ, l.kq, lane);
-            poll_units<1, 64>(pl, p.rr + (long long) blk * RPB_E, RPB_E, tagL + SLOT_KQ, lane, [&](int i, unsigned v) { l.rr[i] = __uint_as_float(v); });
+            stage_qvec<KQU, 64>(pl, xr, p.kq, F, tagL + SLOT_KQ, l.kq, lane);
+            poll_units<1, 64>(pl, xr, p.rr + blk * NWK, NWK, tagL + SLOT_KQ, lane, [&](int i, const v4u & v) { x_sink(l.rr, i, v); });
             STAMP(11);
             __syncthreads();
             STAMP(12);
@@ -548,26 +620,24 @@ struct K6 {
         const int nbF = F / 32;
         const unsigned base = p.ctl[0];
         const M6Arena ar{p.arena};
+        const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         // small jobs
         const int a_row = gwk; const bool a_has = a_row < 5 * R;                      // W1 row
         const int x_row = gwk - 5 * R; const bool x_has = x_row >= 0 && x_row < DR;   // decay-W1 row
-        const int b_chunk = NWK * NBLK - 1 - gwk; const bool b_has = b_chunk < 5 * (D / 64);
-        const int b_f = b_has ? b_chunk / (D / 64) : 0;
-        const int b_d0 = (b_has ? b_chunk % (D / 64) : 0) * 64;
         // C rows
         const int c_mat = (blk * RPB_C) / D, c_base = (blk * RPB_C) % D;
         // E / G / F-receptance rows
         const int e_base = blk * RPB_E;
+        const int e_st = e_start(wk), e_n = e_cnt(wk);
         // F key rows
         const int k_base = blk * GPB * 32;
 
         float xown[NSE];
 #pragma unroll
-        for (int si = 0; si < NSE; si++) { const int j = wk + si * NWK; xown[si] = j < RPB_E ? p.x[e_base + j] : 0.0f; }
+        for (int si = 0; si < NSE; si++) { const int j = e_st + si; xown[si] = si < e_n ? p.x[e_base + j] : 0.0f; }
 
         PA pa; PF pf;
         Batch<FMT, 1, UD> wA, wCx;
-        float wB[64]; float wBmaa;
         Batch<FMT, 2, UD> wC[NSC];
         Batch<FMT, 1, UD> wE[NSE], wFr[NSE];
         Batch<FMT, 2, UD> wFk[NSK];
@@ -591,14 +661,6 @@ struct K6 {
                 const int tid = opq(tid0), lane = tid & 63;
                 const M6Layer & L = p.layers[opq_s(li)];
                 const WPl w_w1 = ar.w(L.w1);
-                {   // (workers without a chunk read one float of chunk 0: no traffic, no branch)
-                    const int b_d = b_has ? b_d0 + lane : 0;
-                    const float * col = ar.f(L.w2t) + (long long) b_f * R * D + b_d;
-                    const int rr = b_has ? R : 1;
-#pragma unroll
-                    for (int m = 0; m < 64; m++) wB[m] = col[(long long) (m < rr ? m : rr - 1) * D];
-                    wBmaa = ar.f(L.maa[b_f])[b_d];
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 STAMP(1);
                 __syncthreads();                       // x staged
@@ -608,13 +670,10 @@ struct K6 {
                 if (a_has) {
                     float res[1];
                     rows_finish<FMT, 1, UD>(wA, w_w1.qs, w_w1.qh, w_w1.sc, a_row, 5 * R, nb, qvec_at(l.q1, D), lane, res);
-                    if (lane == 0) tg_store(p.tl + a_row, __float_as_uint(det_tanhf(res[0])), tagL + SLOT_TL);
+                    if (lane == 0) tg_store(xr, p.tl + a_row, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
                 }
-            }
-            // =========================================== B ===========================================
-            {
-                const int tid = opq(tid0), lane = tid & 63;
-                const M6Layer & L = p.layers[opq_s(li)];
+                STAMP(4);
+                // r/k/v/g rows (+ the decay row) stream while the comm waves run the mixes
                 const WPl w_c = ar.w(L.rkvg[c_mat]), w_dw1 = ar.w(L.dw1);
 #pragma unroll
                 for (int si = 0; si < NSC; si++) {
@@ -622,22 +681,7 @@ struct K6 {
                     batch_issue_opt<FMT, 2, UD>(s < RPB_C / 2, wC[si], w_c, c_base + 2 * s, D, nb, 0, lane);
                 }
                 batch_issue_opt<FMT, 1, UD>(x_has, wCx, w_dw1, x_row, DR, nb, 0, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                STAMP(4);
-                __syncthreads();                       // tl staged
                 STAMP(5);
-                if (b_has) {
-                    const int b_d = b_d0 + lane;
-                    const float * tlf = l.tl + b_f * R;
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int m = 0; m < 64; m++) if (m < R) acc += wB[m] * tlf[m];
-                    const float mm = (acc + wBmaa) * l.sx[b_d];
-                    const float o = mm + l.xn[b_d];
-                    int qi, isum; float d16, s16;
-                    quant_block32(o, qi, d16, s16, isum);
-                    tq_store_block(p.act5 + (long long) b_f * p.act_stride, nb, b_d >> 5, lane & 31, qi, d16, s16, isum, tagL + SLOT_ACT);
-                }
             }
             // =========================================== C ===========================================
             {
@@ -650,7 +694,7 @@ struct K6 {
                 if (x_has) {   // the decay row first: every head waits for all of dl
                     float res[1];
                     rows_finish<FMT, 1, UD>(wCx, w_dw1.qs, w_dw1.qh, w_dw1.sc, x_row, DR, nb, qvec_at(l.actw, D), lane, res);
-                    if (lane == 0) tg_store(p.dl + x_row, __float_as_uint(det_tanhf(res[0])), tagL + SLOT_RKVG);
+                    if (lane == 0) tg_store(xr, p.dl + x_row, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
                 }
                 const QVec la = qvec_at(l.act, D);
 #pragma unroll
@@ -659,43 +703,44 @@ struct K6 {
                     if (s < RPB_C / 2) {
                         float res[2];
                         rows_finish<FMT, 2, UD>(wC[si], w_c.qs, w_c.qh, w_c.sc, c_base + 2 * s, D, nb, la, lane, res);
-                        float v = pick_lane<2>(res, lane);
+                        float v = pick_lane<2>(res, lane);          // lane r finishes row r ...
                         if (c_mat == 3) v = v / (1.0f + det_expf(-v));
-                        if (lane < 2) tg_store(p.rkvg + (long long) c_mat * D + c_base + 2 * s + lane, __float_as_uint(v), tagL + SLOT_RKVG);
+                        const int v1 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true);   // ... lane 0 collects row 1 (row_shl:1)
+                        if (lane == 0) tg_store(xr, p.rkvg + ((c_mat * D + c_base + 2 * s) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
                     }
                 }
-                // the output-projection rows go in flight now: the workers idle through the WKV phase anyway
+                // output-projection rows, then the key rows, go in flight now: the workers idle through the WKV phase
+                const WPl w_fk = ar.w(L.fk);
 #pragma unroll
                 for (int si = 0; si < NSE; si++) {
-                    const int j = wk + si * NWK;
-                    batch_issue_opt<FMT, 1, UD>(j < RPB_E, wE[si], w_wo, e_base + j, D, nb, 0, lane);
+                    const int j = e_st + si;
+                    batch_issue_opt<FMT, 1, UD>(si < e_n, wE[si], w_wo, e_base + j, D, nb, 0, lane);
+                }
+#pragma unroll
+                for (int si = 0; si < NSK; si++) {
+                    const int s = wk + si * NWK;
+                    batch_issue_opt<FMT, 2, UD>(s < GPB * 16 && k_base + 2 * s < F, wFk[si], w_fk, k_base + 2 * s, F, nb, 0, lane);
                 }
             }
             // =========================================== E (workers have no part in D) ===========================================
             {
                 const int tid = opq(tid0), lane = tid & 63;
                 const M6Layer & L = p.layers[opq_s(li)];
-                const WPl w_fk = ar.w(L.fk), w_fr = ar.w(L.fr), w_wo = ar.w(L.wo);
-#pragma unroll
-                for (int si = 0; si < NSK; si++) {
-                    const int s = wk + si * NWK;
-                    batch_issue_opt<FMT, 2, UD>(s < GPB * 16 && k_base + 2 * s < F, wFk[si], w_fk, k_base + 2 * s, F, nb, 0, lane);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                const WPl w_wo = ar.w(L.wo);
                 STAMP(8);
                 __syncthreads();                       // yq staged
                 STAMP(9);
                 const QVec la = qvec_at(l.yq, D);
 #pragma unroll
                 for (int si = 0; si < NSE; si++) {
-                    const int j = wk + si * NWK;
-                    if (j < RPB_E) {
+                    const int j = e_st + si;
+                    if (si < e_n) {
                         float res[1];
                         rows_finish<FMT, 1, UD>(wE[si], w_wo.qs, w_wo.qh, w_wo.sc, e_base + j, D, nb, la, lane, res);
                         xown[si] = xown[si] + res[0];
-                        if (lane == 0) tg_store(p.xatt + e_base + j, __float_as_uint(xown[si]), tagL + SLOT_XATT);
                     }
                 }
+                if (lane == 0) tg_store(xr, p.xatt + blk * NWK + wk, __float_as_uint(xown[0]), __float_as_uint(xown[NSE > 1 ? 1 : 0]), __float_as_uint(xown[NSE > 2 ? 2 : 0]), 0u, tagL + SLOT_XATT);
                 // the channel-mixing prologue's parameters: they land while the comm wave waits for x_att
                 issue_pf(pf, ar, L, sin_l, tid);
                 __builtin_amdgcn_sched_barrier(0);
@@ -713,8 +758,8 @@ struct K6 {
                 // receptance rows go in flight under the key rows
 #pragma unroll
                 for (int si = 0; si < NSE; si++) {
-                    const int j = wk + si * NWK;
-                    batch_issue_opt<FMT, 1, UD>(j < RPB_E, wFr[si], w_fr, e_base + j, D, nb, 0, lane);
+                    const int j = e_st + si;
+                    batch_issue_opt<FMT, 1, UD>(si < e_n, wFr[si], w_fr, e_base + j, D, nb, 0, lane);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const QVec qk = qvec_at(l.q1, D), qr = qvec_at(l.q2, D);
@@ -729,57 +774,56 @@ struct K6 {
                         if (lane < 2) l.out[2 * s + lane] = t * t;
                     }
                 }
-                // first half of the value-projection rows (K = F) goes in flight under the receptance rows
+                float rrow[NSE];
+#pragma unroll
+                for (int si = 0; si < NSE; si++) rrow[si] = 0.0f;
 #pragma unroll
                 for (int si = 0; si < NSE; si++) {
-                    const int j = wk + si * NWK;
-                    batch_issue_opt<FMT, 1, 4>(j < RPB_E, wG[si][0], w_fv, e_base + j, D, nbF, 0, lane);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int si = 0; si < NSE; si++) {
-                    const int j = wk + si * NWK;
-                    if (j < RPB_E) {
+                    const int j = e_st + si;
+                    if (si < e_n) {
                         float res[1];
                         rows_finish<FMT, 1, UD>(wFr[si], w_fr.qs, w_fr.qh, w_fr.sc, e_base + j, D, nb, qr, lane, res);
-                        if (lane == 0) tg_store(p.rr + e_base + j, __float_as_uint(res[0]), tagL + SLOT_KQ);
+                        rrow[si] = res[0];
                     }
                 }
+                if (lane == 0) tg_store(xr, p.rr + blk * NWK + wk, __float_as_uint(rrow[0]), __float_as_uint(rrow[NSE > 1 ? 1 : 0]), __float_as_uint(rrow[NSE > 2 ? 2 : 0]), 0u, tagL + SLOT_KQ);
                 STAMP(13);
                 __syncthreads();                       // key rows in l.out -> comm quantises them
+                // the value-projection rows (K = F) stream while the comm waves quantise and hand over k
 #pragma unroll
                 for (int si = 0; si < NSE; si++) {
-                    const int j = wk + si * NWK;
-                    batch_issue_opt<FMT, 1, 4>(j < RPB_E && nbF > 256, wG[si][1], w_fv, e_base + j, D, nbF, 256, lane);
+                    const int j = e_st + si;
+                    batch_issue_opt<FMT, 1, 4>(si < e_n, wG[si][0], w_fv, e_base + j, D, nbF, 0, lane);
+                    batch_issue_opt<FMT, 1, 4>(si < e_n && nbF > 256, wG[si][1], w_fv, e_base + j, D, nbF, 256, lane);
                 }
             }
             // =========================================== G ===========================================
             {
                 const int tid = opq(tid0), lane = tid & 63;
                 const M6Layer & L = p.layers[opq_s(li)];
-                {
-                    const int nl = li + 1 < p.n_layers ? li + 1 : li;
-                    issue_A(p.layers[nl], p.sin + (long long) nl * p.state_stride, tid, lane);
-                }
-                __builtin_amdgcn_sched_barrier(0);
                 STAMP(14);
                 __syncthreads();                       // kq and rr staged
                 STAMP(15);
                 const QVec lk = qvec_at(l.kq, F);
 #pragma unroll
                 for (int si = 0; si < NSE; si++) {
-                    const int j = wk + si * NWK;
-                    if (j < RPB_E) {
+                    const int j = e_st + si;
+                    if (si < e_n) {
                         float acc[1] = {0.0f};
                         batch_consume<FMT, 1, 4>(wG[si][0], nbF, 0, lane, lk, acc);
                         if (nbF > 256) batch_consume<FMT, 1, 4>(wG[si][1], nbF, 256, lane, lk, acc);
                         const float v = wave_sum_f(acc[0]);
                         const float gte = sigmoid_f(l.rr[j]) * v;
                         xown[si] = xown[si] + gte;
-                        if (lane == 0) { tg_store(p.xffn + e_base + j, __float_as_uint(xown[si]), tagL + SLOT_XFFN); p.x[e_base + j] = xown[si]; }
+                        if (lane == 0) p.x[e_base + j] = xown[si];
                     }
                 }
+                if (lane == 0) tg_store(xr, p.xffn + blk * NWK + wk, __float_as_uint(xown[0]), __float_as_uint(xown[NSE > 1 ? 1 : 0]), __float_as_uint(xown[NSE > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
                 STAMP(16);
+                {
+                    const int nl = li + 1 < p.n_layers ? li + 1 : li;
+                    issue_A(p.layers[nl], p.sin + (long long) nl * p.state_stride, tid, lane);
+                }
             }
         }
     }
@@ -807,7 +851,18 @@ __global__ __launch_bounds__(512) void k6_mega(M6P p) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 
+// dst[(((f * D/64 + chunk) * R/4 + m/4) * 64 + lane) * 4 + m%4] = src[(f * R + m) * D + chunk * 64 + lane]   (src = W2 as [5][R][D])
+__global__ void k_block_w2(const float * __restrict__ src, float * __restrict__ dst, int D, int R) {
+    const long long n = 5ll * R * D;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const int d = (int) (i % D); const long long fm = i / D; const int m = (int) (fm % R), f = (int) (fm / R);
+        const long long o = ((((long long) f * (D / 64) + d / 64) * (R / 4) + m / 4) * 64 + d % 64) * 4 + m % 4;
+        dst[o] = src[i];
+    }
+}
+
 struct MegaV6 {
+    float * w2b = nullptr;
     M6Layer * d_layers = nullptr;
     void * xch = nullptr;
     unsigned * ctl = nullptr;
@@ -821,8 +876,8 @@ struct MegaV6 {
 typedef void (*MegaKernel)(M6P);
 struct MegaVariant { int fmt, ept, kqu, nbd, gpb; MegaKernel fn; };
 static const MegaVariant g_variants[] = {
-    {T_Q4_0, 8, 70, 4, 2, k6_mega<T_Q4_0, 8, 70, 4, 2>},   // D 4096, F <= 14336, decay rank 128
-    {T_Q4_0, 4, 35, 2, 1, k6_mega<T_Q4_0, 4, 35, 2, 1>},   // D 2048, F <= 7168,  decay rank 64
+    {T_Q4_0, 8, 21, 4, 2, k6_mega<T_Q4_0, 8, 21, 4, 2>},   // D 4096, F <= 14336, decay rank 128
+    {T_Q4_0, 4, 11, 2, 1, k6_mega<T_Q4_0, 4, 11, 2, 1>},   // D 2048, F <= 7168,  decay rank 64
 };
 
 static int mega_variant(const Model & m, int n_cu) {
@@ -843,7 +898,7 @@ static int mega_variant(const Model & m, int n_cu) {
     }
     for (size_t v = 0; v < sizeof(g_variants) / sizeof(g_variants[0]); v++) {
         const MegaVariant & mv = g_variants[v];
-        if (mv.fmt == fmt && D == mv.ept * 512 && 10 * (F / 32) <= (int64_t) mv.kqu * 64 && DR == mv.nbd * 32 && (F / 32 + NB - 1) / NB == mv.gpb) return (int) v;
+        if (mv.fmt == fmt && D == mv.ept * 512 && 3 * (F / 32) <= (int64_t) mv.kqu * 64 && DR == mv.nbd * 32 && (F / 32 + NB - 1) / NB == mv.gpb) return (int) v;
     }
     return -1;
 }
@@ -852,6 +907,7 @@ void mega_v6_destroy(void * h) {
     MegaV6 * mg = (MegaV6 *) h;
     if (!mg) return;
     if (mg->d_layers) (void) hipFree(mg->d_layers);
+    if (mg->w2b) (void) hipFree(mg->w2b);
     if (mg->xch) (void) hipFree(mg->xch);
     if (mg->ctl) (void) hipFree(mg->ctl);
     delete mg;
@@ -873,6 +929,8 @@ void * mega_v6_create(const Model & m) {
         delete mg; return nullptr;
     }
     (void) hipFuncSetAttribute((const void *) g_variants[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) mg->lds);
+    const size_t w2_layer = (size_t) 5 * R * D;
+    if (R % 4 != 0 || hipMalloc((void **) &mg->w2b, w2_layer * (m.layer_end - m.layer_begin) * sizeof(float)) != hipSuccess) { delete mg; return nullptr; }
     std::vector<M6Layer> hl;
     const unsigned char * abase = (const unsigned char *) m.arena;
     bool in_arena = true;
@@ -889,13 +947,14 @@ void * mega_v6_create(const Model & m) {
         M6Layer d{};
         d.ln1_w = f(L.ln1_w); d.ln1_b = f(L.ln1_b); d.maa_x = f(L.att_time_maa_x);
         d.maa[0] = f(L.att_time_maa_w); d.maa[1] = f(L.att_time_maa_k); d.maa[2] = f(L.att_time_maa_v); d.maa[3] = f(L.att_time_maa_r); d.maa[4] = f(L.att_time_maa_g);
-        d.w2t = f(L.att_time_maa_w2); d.time_decay = f(L.att_time_decay); d.faaaa = f(L.att_time_faaaa);
+        d.w2b = (long long) hl.size() * 5 * R * D; d.time_decay = f(L.att_time_decay); d.faaaa = f(L.att_time_faaaa);
         d.lnx_w = f(L.att_ln_x_w); d.lnx_b = f(L.att_ln_x_b); d.ln2_w = f(L.ln2_w); d.ln2_b = f(L.ln2_b);
         d.fmaa_k = f(L.ffn_time_maa_k); d.fmaa_r = f(L.ffn_time_maa_r);
         d.w1 = pl3(L.att_time_maa_w1);
         d.rkvg[0] = pl3(L.att_receptance); d.rkvg[1] = pl3(L.att_key); d.rkvg[2] = pl3(L.att_value); d.rkvg[3] = pl3(L.att_gate);
         d.dw1 = pl3(L.att_time_decay_w1); d.dw2 = pl3(L.att_time_decay_w2); d.wo = pl3(L.att_output);
         d.fk = pl3(L.ffn_key); d.fr = pl3(L.ffn_receptance); d.fv = pl3(L.ffn_value);
+        hipLaunchKernelGGL(k_block_w2, dim3(512), dim3(256), 0, 0, (const float *) L.att_time_maa_w2->data, mg->w2b + hl.size() * w2_layer, (int) D, (int) R);
         hl.push_back(d);
         const DevTensor * all[] = {L.ln1_w, L.ln1_b, L.att_time_maa_x, L.att_time_maa_w, L.att_time_maa_k, L.att_time_maa_v, L.att_time_maa_r, L.att_time_maa_g,
                                    L.att_time_maa_w1, L.att_time_maa_w2, L.att_time_decay, L.att_time_faaaa, L.att_time_decay_w1, L.att_time_decay_w2,
@@ -907,26 +966,28 @@ void * mega_v6_create(const Model & m) {
     mg->bytes = bytes;
     if (!in_arena) { delete mg; return nullptr; }
     const int64_t nbD = D / 32, nbF = F / 32;
-    const int64_t PAD = 512;   // polls read whole 64-unit rounds: keep every buffer readable past its end
+    const int64_t PAD = 2048;   // polls read whole 64-lane rounds: keep every buffer readable past its end
     auto up = [](int64_t v) { return (v + 63) / 64 * 64; };
-    const int64_t act_stride = up(10 * nbD);
-    const int64_t sizes[9] = {up(1280) + PAD, 5 * act_stride + PAD, 4 * D + PAD, 256 + PAD, act_stride + PAD, D + PAD, up(10 * nbF) + PAD, D + PAD, D + PAD};
+    const int64_t act_stride = up(3 * nbD), xunits = up(256 * 7);
+    const int64_t sizes[9] = {up(1280) + PAD, 5 * act_stride + PAD, 2 * D + PAD, 256 + PAD, act_stride + PAD, xunits + PAD, up(3 * nbF) + PAD, xunits + PAD, xunits + PAD};
     int64_t units = 0;
     for (int64_t z : sizes) units += z;
     bool ok = hipMalloc((void **) &mg->d_layers, hl.size() * sizeof(M6Layer)) == hipSuccess
            && hipMemcpy(mg->d_layers, hl.data(), hl.size() * sizeof(M6Layer), hipMemcpyHostToDevice) == hipSuccess
-           && hipMalloc(&mg->xch, (size_t) units * 8) == hipSuccess && hipMemset(mg->xch, 0, (size_t) units * 8) == hipSuccess
+           && hipMalloc(&mg->xch, (size_t) units * 16) == hipSuccess && hipMemset(mg->xch, 0, (size_t) units * 16) == hipSuccess
            && hipMalloc((void **) &mg->ctl, 256) == hipSuccess;
     const unsigned init[2] = {8u, 0u};
     ok = ok && hipMemcpy(mg->ctl, init, sizeof(init), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { mega_v6_destroy(mg); return nullptr; }
     M6P & q = mg->proto;
     q.layers = mg->d_layers; q.n_layers = (int) hl.size();
-    q.arena = abase;
+    q.arena = abase; q.w2b = mg->w2b;
+    if (hipDeviceSynchronize() != hipSuccess) { mega_v6_destroy(mg); return nullptr; }
     q.state_stride = m.state_per_layer();
-    u64 * u = (u64 *) mg->xch;
-    u64 ** slots[9] = {&q.tl, &q.act5, &q.rkvg, &q.dl, &q.yq, &q.xatt, &q.kq, &q.rr, &q.xffn};
-    for (int i = 0; i < 9; i++) { *slots[i] = u; u += sizes[i]; }
+    q.xch = mg->xch; q.xch_bytes = (unsigned) (units * 16);
+    int u = 0;
+    int * slots[9] = {&q.tl, &q.act5, &q.rkvg, &q.dl, &q.yq, &q.xatt, &q.kq, &q.rr, &q.xffn};
+    for (int i = 0; i < 9; i++) { *slots[i] = u; u += (int) sizes[i]; }
     q.act_stride = act_stride;
     q.ctl = mg->ctl;
     q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;

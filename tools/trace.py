@@ -11,12 +11,12 @@ NB=256
 out=np.zeros(NB*8*32,dtype=np.int64)
 assert L.rwkv_mi_debug_mega_trace(m._ctx.ptr, 5, 5, 3, out.ctypes.data)
 t=out.reshape(NB,8,32)
-cn=['A.poll','A.bar+prol','B.poll','C.poll(+bar)','D','E.poll','F.poll(+bar)','F.prol','F.bar','F.quant','G.poll','G.bar']
+cn=['A.poll','A.bar+prol','B.load+poll','B.comp+C.poll','D','E.poll','F.poll(+bar)','F.prol','F.bar','F.quant','G.poll','G.bar']
 c=np.diff(t[:,0,:13],axis=1).astype(float)
 print('COMM wave: mean / min / max cycles')
 for i,n in enumerate(cn): print('%-14s %8.0f %8.0f %8.0f'%(n,c[:,i].mean(),c[:,i].min(),c[:,i].max()))
 print('comm layer total', (t[:,0,12]-t[:,0,0]).mean())
-wn=['A.issue','A.barwait','A.prol','A.w1+B.issue','B.barwait','B.comp+C.issue','C.barwait','C.comp+E.issue','E.barwait','E.comp+pf','F.barwait','F.prol','F.rows','F.bar+G.issue','G.barwait','G.comp']
+wn=['-','A.barwait','A.prol','A.w1','C.issue','-','C.barwait','C.comp+issueEF','E.barwait','E.comp+pf','F.barwait','F.prol','F.rows','F.bar+G1.issue','G.barwait','G.comp']
 w=np.diff(t[:,1:,:17],axis=2).astype(float)
 print('WORKER waves: mean / min / max cycles')
 for i,n in enumerate(wn): print('%-16s %8.0f %8.0f %8.0f'%(n,w[:,:,i].mean(),w[:,:,i].min(),w[:,:,i].max()))
