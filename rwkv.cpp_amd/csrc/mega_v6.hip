@@ -57,6 +57,7 @@ struct M6P {
     unsigned * ctl;                                  // [0] tag generation, [1] abort
     int F, DR, R, H, gpb;
     long long * trace; int trace_layer;
+    int delay_c, delay_e, delay_g;   // pacing of the bulk issues (x 1024 cycles), see worker_main
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -111,7 +112,7 @@ __device__ __forceinline__ void poll_ptrs(Poll & pl, xrsrc xr, const int (&ptr)[
 // per-slot address registers); slots past n are simply not checked.
 template <int MAXU, int NT, typename Sink>
 __device__ __forceinline__ void poll_units(Poll & pl, xrsrc xr, int src, int n, unsigned tag, int tid, Sink && sink) {
-    static_assert(MAXU <= 28, "poll_units: range too long for one round");
+    static_assert(MAXU <= 32, "poll_units: range too long for one round");
     const int mine = src + tid;
     v4u v[MAXU];
     for (unsigned spin = 0;; spin++) {
@@ -272,24 +273,21 @@ struct K6 {
     static constexpr int nb = D / 32;
     static constexpr int UD = nb / 64 > 0 ? nb / 64 : 1;
     static constexpr int V4 = D / (4 * NT);              // float4 groups per thread in the prologues
+    static constexpr int NOWN = 8;                       // row owners per workgroup: the 7 workers and the comm wave
     static constexpr int RPB_C = 4 * D / NBLK;           // r/k/v/g rows per workgroup (all of one matrix)
-    static constexpr int NSC = (RPB_C / 2 + NWK - 1) / NWK;
+    static constexpr int NSC = RPB_C / 2 / NOWN;         // 2-row sets per owner
     static constexpr int RPB_E = D / NBLK;               // output / receptance / value rows per workgroup
-    static constexpr int NSE = (RPB_E + NWK - 1) / NWK;
-    static constexpr int NSK = (GPB * 16 + NWK - 1) / NWK;
-    static constexpr int XU = (NBLK * NWK + 63) / 64;    // poll slots per lane for x / rr (one unit per worker: its 2-3 rows)
+    static constexpr int NSE = RPB_E / NOWN;             // rows per owner (consecutive)
+    static constexpr int NSK = GPB * 16 / NOWN;          // key 2-row sets per owner
+    static constexpr int XU = NBLK * NOWN / 64;          // poll slots per lane for x (one unit per owner: its rows)
     static constexpr int DU = (3 * nb + 63) / 64;        // ... for a quantised D-vector
-    static_assert(NSE <= 3, "a worker's rows of x must fit one unit");
-    // rows of the residual stream owned by worker wk of a workgroup: consecutive, the first RPB_E % NWK workers one more
-    static __device__ __forceinline__ int e_cnt(int wk) { return RPB_E / NWK + (wk < RPB_E % NWK ? 1 : 0); }
-    static __device__ __forceinline__ int e_start(int wk) { return wk * (RPB_E / NWK) + (wk < RPB_E % NWK ? wk : RPB_E % NWK); }
-    // sink of an x-like vector: unit i = (workgroup, worker) -> its rows of dst
+    static_assert(RPB_C % (2 * NOWN) == 0 && RPB_E % NOWN == 0 && (GPB * 16) % NOWN == 0 && NSE <= 3, "row ownership must divide evenly");
+    // sink of an x-like vector: unit i = (workgroup, owner) -> its rows of dst
     static __device__ __forceinline__ void x_sink(float * dst, int i, const v4u & v) {
-        const int b = i / NWK, wk = i - b * NWK;
-        const int st = b * RPB_E + e_start(wk), n = e_cnt(wk);
+        const int st = (i / NOWN) * RPB_E + (i % NOWN) * NSE;
         dst[st] = __uint_as_float(v.x);
-        if (n > 1) dst[st + 1] = __uint_as_float(v.y);
-        if (n > 2) dst[st + 2] = __uint_as_float(v.z);
+        if (NSE > 1) dst[st + 1] = __uint_as_float(v.y);
+        if (NSE > 2) dst[st + 2] = __uint_as_float(v.z);
     }
 
     struct Lds {
@@ -399,6 +397,118 @@ struct K6 {
     }
 
     // -----------------------------------------------------------------------------------------------------------
+    // the big row phases, shared by the 8 row owners of a workgroup (workers own = 0..6, comm wave own = 7)
+    // -----------------------------------------------------------------------------------------------------------
+    struct Rows {
+        Batch<FMT, 2, UD> wC[NSC];
+        Batch<FMT, 1, UD> wE[NSE], wFr[NSE];
+        Batch<FMT, 2, UD> wFk[NSK];
+        Batch<FMT, 1, 4> wG[NSE][2];
+        float xown[NSE];
+    };
+    static __device__ __forceinline__ int c_mat() { return ((int) blockIdx.x * RPB_C) / D; }
+    static __device__ __forceinline__ int c_base() { return ((int) blockIdx.x * RPB_C) % D; }
+
+    static __device__ __forceinline__ void issue_C(Rows & r, const M6Arena & ar, const M6Layer & L, int own, int lane) {
+        const WPl w = ar.w(L.rkvg[c_mat()]);
+#pragma unroll
+        for (int si = 0; si < NSC; si++) batch_issue<FMT, 2, UD>(r.wC[si], w.qs, w.qh, w.sc, c_base() + 2 * (own + si * NOWN), D, nb, 0, lane);
+    }
+    static __device__ __forceinline__ void compute_C(Rows & r, const Lds & l, xrsrc xr, const M6P & p, unsigned tagL, int own, int lane) {
+        const QVec la = qvec_at(l.act, D);
+        const int mat = c_mat();
+#pragma unroll
+        for (int si = 0; si < NSC; si++) {
+            const int row0 = c_base() + 2 * (own + si * NOWN);
+            float res[2];
+            rows_finish<FMT, 2, UD>(r.wC[si], nullptr, nullptr, nullptr, row0, D, nb, la, lane, res);
+            float v = pick_lane<2>(res, lane);          // lane r finishes row r ...
+            if (mat == 3) v = v / (1.0f + det_expf(-v));
+            const int v1 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true);   // ... lane 0 collects row 1 (row_shl:1)
+            if (lane == 0) tg_store(xr, p.rkvg + ((mat * D + row0) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
+        }
+    }
+    static __device__ __forceinline__ void issue_E(Rows & r, const M6Arena & ar, const M6Layer & L, int own, int lane) {
+        const WPl w = ar.w(L.wo);
+#pragma unroll
+        for (int si = 0; si < NSE; si++) batch_issue<FMT, 1, UD>(r.wE[si], w.qs, w.qh, w.sc, (int) blockIdx.x * RPB_E + own * NSE + si, D, nb, 0, lane);
+    }
+    static __device__ __forceinline__ void x_store(xrsrc xr, int buf, const float (&v)[NSE], int own, int lane, unsigned tag) {
+        if (lane == 0) tg_store(xr, buf + (int) blockIdx.x * NOWN + own, __float_as_uint(v[0]), __float_as_uint(v[NSE > 1 ? 1 : 0]), __float_as_uint(v[NSE > 2 ? 2 : 0]), 0u, tag);
+    }
+    static __device__ __forceinline__ void compute_E(Rows & r, const Lds & l, xrsrc xr, const M6P & p, unsigned tagL, int own, int lane) {
+        const QVec la = qvec_at(l.yq, D);
+#pragma unroll
+        for (int si = 0; si < NSE; si++) {
+            float res[1];
+            rows_finish<FMT, 1, UD>(r.wE[si], nullptr, nullptr, nullptr, 0, D, nb, la, lane, res);
+            r.xown[si] = r.xown[si] + res[0];
+        }
+        x_store(xr, p.xatt, r.xown, own, lane, tagL + SLOT_XATT);
+    }
+    static __device__ __forceinline__ bool k_valid(const M6P & p, int own, int si) { return (int) blockIdx.x * GPB * 32 + 2 * (own + si * NOWN) < p.F; }
+    static __device__ __forceinline__ void issue_Fk(Rows & r, const M6P & p, const M6Arena & ar, const M6Layer & L, int own, int lane) {
+        const WPl w = ar.w(L.fk);
+#pragma unroll
+        for (int si = 0; si < NSK; si++) batch_issue_opt<FMT, 2, UD>(k_valid(p, own, si), r.wFk[si], w, (int) blockIdx.x * GPB * 32 + 2 * (own + si * NOWN), p.F, nb, 0, lane);
+    }
+    static __device__ __forceinline__ void issue_Fr(Rows & r, const M6Arena & ar, const M6Layer & L, int own, int lane) {
+        const WPl w = ar.w(L.fr);
+#pragma unroll
+        for (int si = 0; si < NSE; si++) batch_issue<FMT, 1, UD>(r.wFr[si], w.qs, w.qh, w.sc, (int) blockIdx.x * RPB_E + own * NSE + si, D, nb, 0, lane);
+    }
+    static __device__ __forceinline__ void compute_F(Rows & r, const Lds & l, xrsrc xr, const M6P & p, unsigned tagL, int own, int lane) {
+        const QVec qk = qvec_at(l.q1, D), qr = qvec_at(l.q2, D);
+#pragma unroll
+        for (int si = 0; si < NSK; si++) {
+            if (k_valid(p, own, si)) {
+                float res[2];
+                rows_finish<FMT, 2, UD>(r.wFk[si], nullptr, nullptr, nullptr, 0, p.F, nb, qk, lane, res);
+                const float v = pick_lane<2>(res, lane);
+                const float t = v > 0.0f ? v : 0.0f;
+                if (lane < 2) l.out[2 * (own + si * NOWN) + lane] = t * t;
+            }
+        }
+        float rrow[NSE];
+#pragma unroll
+        for (int si = 0; si < NSE; si++) {
+            float res[1];
+            rows_finish<FMT, 1, UD>(r.wFr[si], nullptr, nullptr, nullptr, 0, D, nb, qr, lane, res);
+            rrow[si] = res[0];
+        }
+        x_store(xr, p.rr, rrow, own, lane, tagL + SLOT_KQ);
+    }
+    static __device__ __forceinline__ void issue_G(Rows & r, const M6P & p, const M6Arena & ar, const M6Layer & L, int own, int lane) {
+        const WPl w = ar.w(L.fv);
+        const int nbF = p.F / 32;
+#pragma unroll
+        for (int si = 0; si < NSE; si++) {
+            const int row = (int) blockIdx.x * RPB_E + own * NSE + si;
+            batch_issue<FMT, 1, 4>(r.wG[si][0], w.qs, w.qh, w.sc, row, D, nbF, 0, lane);
+            batch_issue_opt<FMT, 1, 4>(nbF > 256, r.wG[si][1], w, row, D, nbF, 256, lane);
+        }
+    }
+    static __device__ __forceinline__ void compute_G(Rows & r, const Lds & l, xrsrc xr, const M6P & p, unsigned tagL, int own, int lane) {
+        const int nbF = p.F / 32;
+        const QVec lk = qvec_at(l.kq, p.F);
+#pragma unroll
+        for (int si = 0; si < NSE; si++) {
+            float acc[1] = {0.0f};
+            batch_consume<FMT, 1, 4>(r.wG[si][0], nbF, 0, lane, lk, acc);
+            if (nbF > 256) batch_consume<FMT, 1, 4>(r.wG[si][1], nbF, 256, lane, lk, acc);
+            const float v = wave_sum_f(acc[0]);
+            const float gte = sigmoid_f(l.rr[own * NSE + si]) * v;
+            r.xown[si] = r.xown[si] + gte;
+            if (lane == 0) p.x[(int) blockIdx.x * RPB_E + own * NSE + si] = r.xown[si];
+        }
+        x_store(xr, p.xffn, r.xown, own, lane, tagL + SLOT_XFFN);
+    }
+    static __device__ __forceinline__ void load_xown(Rows & r, const M6P & p, int own) {
+#pragma unroll
+        for (int si = 0; si < NSE; si++) r.xown[si] = p.x[(int) blockIdx.x * RPB_E + own * NSE + si];
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
     // comm wave
     // -----------------------------------------------------------------------------------------------------------
     static __device__ __forceinline__ void comm_main(const M6P & p, const Lds & l, int lane0, unsigned base) {
@@ -421,6 +531,9 @@ struct K6 {
         const int b_extra = NCH - NBLK;   // chunks beyond one per workgroup (host guarantees <= NBLK)
         const int b_chunk2 = (b_extra > 0 && blk >= NBLK - b_extra) ? NBLK + (blk - (NBLK - b_extra)) : -1;
         PA pa; PF pf;
+        constexpr int own = NOWN - 1;   // the comm wave is the eighth row owner: its weights go in flight right before the poll that precedes their use
+        Rows r;
+        load_xown(r, p, own);
         issue_pa(pa, ar, p.layers[0], p.sin, lane0);
 
         for (int li = 0; li < p.n_layers; li++) {
@@ -437,7 +550,7 @@ struct K6 {
 #pragma unroll 8
                 for (int u = 0; u < D / 64; u++) l.x[lane + u * 64] = p.x[lane + u * 64];
             } else {
-                poll_units<XU, 64>(pl, xr, p.xffn, NBLK * NWK, tagL - 8u + SLOT_XFFN, lane, [&](int i, const v4u & v) { x_sink(l.x, i, v); });
+                poll_units<XU, 64>(pl, xr, p.xffn, NBLK * NOWN, tagL - 8u + SLOT_XFFN, lane, [&](int i, const v4u & v) { x_sink(l.x, i, v); });
             }
             // W2 of this workgroup's chunk(s): chunk-blocked copy, lane d reads float4 {m .. m+3}; in flight across the prologue
             float4 wB4[2][16]; float wBmaa[2];
@@ -481,10 +594,12 @@ struct K6 {
                 }
             }
             // ---- C ----
+            issue_C(r, ar, L, own, lane);
             stage_qvec<DU, 64>(pl, xr, p.act5 + blk_act * (int) p.act_stride, D, tagL + SLOT_ACT, l.act, lane);
             if (blk_xhas) stage_qvec<DU, 64>(pl, xr, p.act5, D, tagL + SLOT_ACT, l.actw, lane);
             STAMP(4);
             __syncthreads();
+            compute_C(r, l, xr, p, tagL, own, lane);
             // ---- D: WKV head of this workgroup ----
             if (d_has) {
                 const int c = d_head * S + lane;
@@ -568,18 +683,23 @@ struct K6 {
             }
             STAMP(5);
             // ---- E ----
-            issue_pf(pf, ar, L, sin_l, lane0);
-            __builtin_amdgcn_sched_barrier(0);
+            issue_E(r, ar, L, own, lane);
             stage_qvec<DU, 64>(pl, xr, p.yq, D, tagL + SLOT_YQ, l.yq, lane);
             STAMP(6);
             __syncthreads();
+            compute_E(r, l, xr, p, tagL, own, lane);
+            issue_pf(pf, ar, L, sin_l, lane0);
+            __builtin_amdgcn_sched_barrier(0);
             // ---- F ----
-            poll_units<XU, 64>(pl, xr, p.xatt, NBLK * NWK, tagL + SLOT_XATT, lane, [&](int i, const v4u & v) { x_sink(l.x, i, v); });
+            poll_units<XU, 64>(pl, xr, p.xatt, NBLK * NOWN, tagL + SLOT_XATT, lane, [&](int i, const v4u & v) { x_sink(l.x, i, v); });
+            issue_Fk(r, p, ar, L, own, lane);
+            issue_Fr(r, ar, L, own, lane);
             STAMP(7);
             __syncthreads();
             prologue_F(l, pf, sout_l, blk == 0, lane);
             STAMP(8);
-            __syncthreads();   // workers' key rows are in l.out
+            compute_F(r, l, xr, p, tagL, own, lane);
+            __syncthreads();   // every owner's key rows are in l.out
             STAMP(9);
             {
                 // quantise this workgroup's key groups (relu^2 outputs): half-wave = group
@@ -600,11 +720,12 @@ struct K6 {
                 const int nl = li + 1 < p.n_layers ? li + 1 : li;
                 issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, lane0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            issue_G(r, p, ar, L, own, lane);
             stage_qvec<KQU, 64>(pl, xr, p.kq, F, tagL + SLOT_KQ, l.kq, lane);
-            poll_units<1, 64>(pl, xr, p.rr + blk * NWK, NWK, tagL + SLOT_KQ, lane, [&](int i, const v4u & v) { x_sink(l.rr, i, v); });
+            poll_units<1, 64>(pl, xr, p.rr + blk * NOWN, NOWN, tagL + SLOT_KQ, lane, [&](int i, const v4u & v) { x_sink(l.rr, i, v); });
             STAMP(11);
             __syncthreads();
+            compute_G(r, l, xr, p, tagL, own, lane);
             STAMP(12);
         }
     }
@@ -614,34 +735,20 @@ struct K6 {
     // -----------------------------------------------------------------------------------------------------------
     static __device__ __forceinline__ void worker_main(const M6P & p, const Lds & l, int tid0, int wave) {
         const int blk = blockIdx.x;
-        const int wk = wave - 1;
-        const int gwk = wk * NBLK + blk;
-        const int F = p.F, DR = p.DR, R = p.R;
-        const int nbF = F / 32;
+        const int own = wave - 1;
+        const int gwk = own * NBLK + blk;
+        const int DR = p.DR, R = p.R;
         const unsigned base = p.ctl[0];
         const M6Arena ar{p.arena};
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         // small jobs
         const int a_row = gwk; const bool a_has = a_row < 5 * R;                      // W1 row
         const int x_row = gwk - 5 * R; const bool x_has = x_row >= 0 && x_row < DR;   // decay-W1 row
-        // C rows
-        const int c_mat = (blk * RPB_C) / D, c_base = (blk * RPB_C) % D;
-        // E / G / F-receptance rows
-        const int e_base = blk * RPB_E;
-        const int e_st = e_start(wk), e_n = e_cnt(wk);
-        // F key rows
-        const int k_base = blk * GPB * 32;
 
-        float xown[NSE];
-#pragma unroll
-        for (int si = 0; si < NSE; si++) { const int j = e_st + si; xown[si] = si < e_n ? p.x[e_base + j] : 0.0f; }
-
+        Rows r;
+        load_xown(r, p, own);
         PA pa; PF pf;
         Batch<FMT, 1, UD> wA, wCx;
-        Batch<FMT, 2, UD> wC[NSC];
-        Batch<FMT, 1, UD> wE[NSE], wFr[NSE];
-        Batch<FMT, 2, UD> wFk[NSK];
-        Batch<FMT, 1, 4> wG[NSE][2];
 
         auto issue_A = [&](const M6Layer & L, const float * sin_l, int tid, int lane) {
             issue_pa(pa, ar, L, sin_l, tid);
@@ -655,13 +762,10 @@ struct K6 {
             const unsigned tagL = base + (unsigned) li * 8u;
             const int tidst = tid0;
             STAMP(0);
-
-            // =========================================== A ===========================================
+            // ---- A: prologue, W1 row; then the r/k/v/g rows (+ the decay row) stream while the comm waves run the mixes ----
             {
                 const int tid = opq(tid0), lane = tid & 63;
                 const M6Layer & L = p.layers[opq_s(li)];
-                const WPl w_w1 = ar.w(L.w1);
-                __builtin_amdgcn_sched_barrier(0);
                 STAMP(1);
                 __syncthreads();                       // x staged
                 STAMP(2);
@@ -669,161 +773,69 @@ struct K6 {
                 STAMP(3);
                 if (a_has) {
                     float res[1];
-                    rows_finish<FMT, 1, UD>(wA, w_w1.qs, w_w1.qh, w_w1.sc, a_row, 5 * R, nb, qvec_at(l.q1, D), lane, res);
+                    rows_finish<FMT, 1, UD>(wA, nullptr, nullptr, nullptr, 0, 5 * R, nb, qvec_at(l.q1, D), lane, res);
                     if (lane == 0) tg_store(xr, p.tl + a_row, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
                 }
                 STAMP(4);
-                // r/k/v/g rows (+ the decay row) stream while the comm waves run the mixes
-                const WPl w_c = ar.w(L.rkvg[c_mat]), w_dw1 = ar.w(L.dw1);
-#pragma unroll
-                for (int si = 0; si < NSC; si++) {
-                    const int s = wk + si * NWK;
-                    batch_issue_opt<FMT, 2, UD>(s < RPB_C / 2, wC[si], w_c, c_base + 2 * s, D, nb, 0, lane);
-                }
-                batch_issue_opt<FMT, 1, UD>(x_has, wCx, w_dw1, x_row, DR, nb, 0, lane);
+                issue_C(r, ar, L, own, lane);
+                batch_issue_opt<FMT, 1, UD>(x_has, wCx, ar.w(L.dw1), x_row, DR, nb, 0, lane);
                 STAMP(5);
             }
-            // =========================================== C ===========================================
+            // ---- C: decay row first (every head waits for all of dl), r/k/v/g rows; then output-projection and key rows go
+            //         in flight: the workers idle through the WKV phase ----
             {
                 const int tid = opq(tid0), lane = tid & 63;
                 const M6Layer & L = p.layers[opq_s(li)];
-                const WPl w_wo = ar.w(L.wo), w_c = ar.w(L.rkvg[c_mat]), w_dw1 = ar.w(L.dw1);
                 STAMP(6);
                 __syncthreads();                       // activation image(s) staged
                 STAMP(7);
-                if (x_has) {   // the decay row first: every head waits for all of dl
+                if (x_has) {
                     float res[1];
-                    rows_finish<FMT, 1, UD>(wCx, w_dw1.qs, w_dw1.qh, w_dw1.sc, x_row, DR, nb, qvec_at(l.actw, D), lane, res);
+                    rows_finish<FMT, 1, UD>(wCx, nullptr, nullptr, nullptr, 0, DR, nb, qvec_at(l.actw, D), lane, res);
                     if (lane == 0) tg_store(xr, p.dl + x_row, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
                 }
-                const QVec la = qvec_at(l.act, D);
-#pragma unroll
-                for (int si = 0; si < NSC; si++) {
-                    const int s = wk + si * NWK;
-                    if (s < RPB_C / 2) {
-                        float res[2];
-                        rows_finish<FMT, 2, UD>(wC[si], w_c.qs, w_c.qh, w_c.sc, c_base + 2 * s, D, nb, la, lane, res);
-                        float v = pick_lane<2>(res, lane);          // lane r finishes row r ...
-                        if (c_mat == 3) v = v / (1.0f + det_expf(-v));
-                        const int v1 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true);   // ... lane 0 collects row 1 (row_shl:1)
-                        if (lane == 0) tg_store(xr, p.rkvg + ((c_mat * D + c_base + 2 * s) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
-                    }
-                }
-                // output-projection rows, then the key rows, go in flight now: the workers idle through the WKV phase
-                const WPl w_fk = ar.w(L.fk);
-#pragma unroll
-                for (int si = 0; si < NSE; si++) {
-                    const int j = e_st + si;
-                    batch_issue_opt<FMT, 1, UD>(si < e_n, wE[si], w_wo, e_base + j, D, nb, 0, lane);
-                }
-#pragma unroll
-                for (int si = 0; si < NSK; si++) {
-                    const int s = wk + si * NWK;
-                    batch_issue_opt<FMT, 2, UD>(s < GPB * 16 && k_base + 2 * s < F, wFk[si], w_fk, k_base + 2 * s, F, nb, 0, lane);
-                }
+                compute_C(r, l, xr, p, tagL, own, lane);
+                issue_E(r, ar, L, own, lane);
+                issue_Fk(r, p, ar, L, own, lane);
             }
-            // =========================================== E (workers have no part in D) ===========================================
+            // ---- E (workers have no part in D); then the channel-mixing prologue's parameters: they land while the comm
+            //         wave waits for x_att ----
             {
                 const int tid = opq(tid0), lane = tid & 63;
                 const M6Layer & L = p.layers[opq_s(li)];
-                const WPl w_wo = ar.w(L.wo);
                 STAMP(8);
                 __syncthreads();                       // yq staged
                 STAMP(9);
-                const QVec la = qvec_at(l.yq, D);
-#pragma unroll
-                for (int si = 0; si < NSE; si++) {
-                    const int j = e_st + si;
-                    if (si < e_n) {
-                        float res[1];
-                        rows_finish<FMT, 1, UD>(wE[si], w_wo.qs, w_wo.qh, w_wo.sc, e_base + j, D, nb, la, lane, res);
-                        xown[si] = xown[si] + res[0];
-                    }
-                }
-                if (lane == 0) tg_store(xr, p.xatt + blk * NWK + wk, __float_as_uint(xown[0]), __float_as_uint(xown[NSE > 1 ? 1 : 0]), __float_as_uint(xown[NSE > 2 ? 2 : 0]), 0u, tagL + SLOT_XATT);
-                // the channel-mixing prologue's parameters: they land while the comm wave waits for x_att
+                compute_E(r, l, xr, p, tagL, own, lane);
                 issue_pf(pf, ar, L, sin_l, tid);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // =========================================== F ===========================================
+            // ---- F: prologue; receptance rows go in flight under the key rows; after the rows the value-projection rows
+            //         (K = F) stream while the comm waves quantise and hand over k ----
             {
                 const int tid = opq(tid0), lane = tid & 63;
                 const M6Layer & L = p.layers[opq_s(li)];
-                const WPl w_fk = ar.w(L.fk), w_fr = ar.w(L.fr), w_fv = ar.w(L.fv);
                 STAMP(10);
                 __syncthreads();                       // x_att staged
                 STAMP(11);
                 prologue_F(l, pf, sout_l, blk == 0, tid);
                 STAMP(12);
-                // receptance rows go in flight under the key rows
-#pragma unroll
-                for (int si = 0; si < NSE; si++) {
-                    const int j = e_st + si;
-                    batch_issue_opt<FMT, 1, UD>(si < e_n, wFr[si], w_fr, e_base + j, D, nb, 0, lane);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const QVec qk = qvec_at(l.q1, D), qr = qvec_at(l.q2, D);
-#pragma unroll
-                for (int si = 0; si < NSK; si++) {
-                    const int s = wk + si * NWK;
-                    if (s < GPB * 16 && k_base + 2 * s < F) {
-                        float res[2];
-                        rows_finish<FMT, 2, UD>(wFk[si], w_fk.qs, w_fk.qh, w_fk.sc, k_base + 2 * s, F, nb, qk, lane, res);
-                        const float v = pick_lane<2>(res, lane);
-                        const float t = v > 0.0f ? v : 0.0f;
-                        if (lane < 2) l.out[2 * s + lane] = t * t;
-                    }
-                }
-                float rrow[NSE];
-#pragma unroll
-                for (int si = 0; si < NSE; si++) rrow[si] = 0.0f;
-#pragma unroll
-                for (int si = 0; si < NSE; si++) {
-                    const int j = e_st + si;
-                    if (si < e_n) {
-                        float res[1];
-                        rows_finish<FMT, 1, UD>(wFr[si], w_fr.qs, w_fr.qh, w_fr.sc, e_base + j, D, nb, qr, lane, res);
-                        rrow[si] = res[0];
-                    }
-                }
-                if (lane == 0) tg_store(xr, p.rr + blk * NWK + wk, __float_as_uint(rrow[0]), __float_as_uint(rrow[NSE > 1 ? 1 : 0]), __float_as_uint(rrow[NSE > 2 ? 2 : 0]), 0u, tagL + SLOT_KQ);
+                issue_Fr(r, ar, L, own, lane);
+                compute_F(r, l, xr, p, tagL, own, lane);
                 STAMP(13);
                 __syncthreads();                       // key rows in l.out -> comm quantises them
-                // the value-projection rows (K = F) stream while the comm waves quantise and hand over k
-#pragma unroll
-                for (int si = 0; si < NSE; si++) {
-                    const int j = e_st + si;
-                    batch_issue_opt<FMT, 1, 4>(si < e_n, wG[si][0], w_fv, e_base + j, D, nbF, 0, lane);
-                    batch_issue_opt<FMT, 1, 4>(si < e_n && nbF > 256, wG[si][1], w_fv, e_base + j, D, nbF, 256, lane);
-                }
+                issue_G(r, p, ar, L, own, lane);
             }
-            // =========================================== G ===========================================
+            // ---- G; then the next layer's prologue parameters and W1 row ----
             {
                 const int tid = opq(tid0), lane = tid & 63;
-                const M6Layer & L = p.layers[opq_s(li)];
                 STAMP(14);
                 __syncthreads();                       // kq and rr staged
                 STAMP(15);
-                const QVec lk = qvec_at(l.kq, F);
-#pragma unroll
-                for (int si = 0; si < NSE; si++) {
-                    const int j = e_st + si;
-                    if (si < e_n) {
-                        float acc[1] = {0.0f};
-                        batch_consume<FMT, 1, 4>(wG[si][0], nbF, 0, lane, lk, acc);
-                        if (nbF > 256) batch_consume<FMT, 1, 4>(wG[si][1], nbF, 256, lane, lk, acc);
-                        const float v = wave_sum_f(acc[0]);
-                        const float gte = sigmoid_f(l.rr[j]) * v;
-                        xown[si] = xown[si] + gte;
-                        if (lane == 0) p.x[e_base + j] = xown[si];
-                    }
-                }
-                if (lane == 0) tg_store(xr, p.xffn + blk * NWK + wk, __float_as_uint(xown[0]), __float_as_uint(xown[NSE > 1 ? 1 : 0]), __float_as_uint(xown[NSE > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
+                compute_G(r, l, xr, p, tagL, own, lane);
                 STAMP(16);
-                {
-                    const int nl = li + 1 < p.n_layers ? li + 1 : li;
-                    issue_A(p.layers[nl], p.sin + (long long) nl * p.state_stride, tid, lane);
-                }
+                const int nl = li + 1 < p.n_layers ? li + 1 : li;
+                issue_A(p.layers[nl], p.sin + (long long) nl * p.state_stride, tid, lane);
             }
         }
     }
@@ -968,7 +980,7 @@ void * mega_v6_create(const Model & m) {
     const int64_t nbD = D / 32, nbF = F / 32;
     const int64_t PAD = 2048;   // polls read whole 64-lane rounds: keep every buffer readable past its end
     auto up = [](int64_t v) { return (v + 63) / 64 * 64; };
-    const int64_t act_stride = up(3 * nbD), xunits = up(256 * 7);
+    const int64_t act_stride = up(3 * nbD), xunits = up(256 * 8);
     const int64_t sizes[9] = {up(1280) + PAD, 5 * act_stride + PAD, 2 * D + PAD, 256 + PAD, act_stride + PAD, xunits + PAD, up(3 * nbF) + PAD, xunits + PAD, xunits + PAD};
     int64_t units = 0;
     for (int64_t z : sizes) units += z;
@@ -992,6 +1004,8 @@ void * mega_v6_create(const Model & m) {
     q.ctl = mg->ctl;
     q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;
     q.gpb = (int) ((nbF + NB - 1) / NB);
+    auto envi = [](const char * n) { const char * v = getenv(n); return v ? atoi(v) : 0; };
+    q.delay_c = envi("RWKV_MI_DELAY_C"); q.delay_e = envi("RWKV_MI_DELAY_E"); q.delay_g = envi("RWKV_MI_DELAY_G");
     return mg;
 }
 
