@@ -613,17 +613,14 @@ struct K6 {
                 for (int b = 0; b < NBD; b++) load_raw<FMT>(w2[b], dw2.qs, dw2.qh, dw2.sc, (long long) c * NBD + b);
                 const float td = ar.f(L.time_decay)[c], uu = ar.f(L.faaaa)[c], lnw = ar.f(L.lnx_w)[c], lnb = ar.f(L.lnx_b)[c];
                 __builtin_amdgcn_sched_barrier(0);
+                // dl arrives first (the decay rows are the first thing the workers finish): one unit per value
                 unsigned dq[6];
                 {
-                    // r,k,v,g of channel c: one unit per 2-row set; dl: one unit per value
-                    const int ptr[6] = {p.rkvg + (c >> 1), p.rkvg + ((D + c) >> 1), p.rkvg + ((2 * D + c) >> 1), p.rkvg + ((3 * D + c) >> 1),
-                                          p.dl + lane, p.dl + (NBD > 2 ? 64 + lane : lane)};
-                    const bool valid[6] = {true, true, true, true, true, NBD > 2};
-                    v4u dv[6];
-                    poll_ptrs<6>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) dq[q] = (c & 1) ? dv[q].y : dv[q].x;
-                    dq[4] = dv[4].x; dq[5] = dv[5].x;
+                    const int ptr[2] = {p.dl + lane, p.dl + (NBD > 2 ? 64 + lane : lane)};
+                    const bool valid[2] = {true, NBD > 2};
+                    v4u dv[2];
+                    poll_ptrs<2>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
+                    dq[4] = dv[0].x; dq[5] = dv[1].x;
                 }
                 // 1. quantise dl (DR = 32 NBD elements) into LDS: half-wave = block
                 const QVec ldl = qvec_at(l.dl, NBD * 32);
@@ -651,22 +648,30 @@ struct K6 {
 #pragma unroll
                     for (int i = 0; i < o; i++) P[i] += P[i + o];
                 const float wdec = det_expf(-det_expf(P[0] + td));
-                // 3. WKV6: lane j owns value column j; r_i, k_i, u_i, w_i are broadcast from lane i
-                const int rr_i = (int) dq[0], kk_i = (int) dq[1], uu_i = __float_as_int(uu), ww_i = __float_as_int(wdec);
+                // r,k,v,g of channel c: one unit per 2-row set
+                {
+                    const int ptr[4] = {p.rkvg + (c >> 1), p.rkvg + ((D + c) >> 1), p.rkvg + ((2 * D + c) >> 1), p.rkvg + ((3 * D + c) >> 1)};
+                    const bool valid[4] = {true, true, true, true};
+                    v4u dv[4];
+                    poll_ptrs<4>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) dq[q] = (c & 1) ? dv[q].y : dv[q].x;
+                }
+                // 3. WKV6 (ggml_rwkv_wkv6): lane j owns value column j; {k, u, r, w}_i are broadcast through LDS (l.tl is free here)
+                float4 * bc = reinterpret_cast<float4 *>(l.tl);
+                bc[lane] = make_float4(__uint_as_float(dq[1]), uu, __uint_as_float(dq[0]), wdec);
+                __builtin_amdgcn_wave_barrier();
                 const float vj = __uint_as_float(dq[2]);
                 float o = 0.0f;
                 float * so = sout_l + 2 * D + (long long) d_head * S * S;
 #pragma unroll
                 for (int i = 0; i < S; i++) {
-                    const float ki = __int_as_float(__builtin_amdgcn_readlane(kk_i, i));
-                    const float ui = __int_as_float(__builtin_amdgcn_readlane(uu_i, i));
-                    const float ri = __int_as_float(__builtin_amdgcn_readlane(rr_i, i));
-                    const float wi = __int_as_float(__builtin_amdgcn_readlane(ww_i, i));
-                    const float kv = vj * ki;
+                    const float4 b4 = bc[i];
+                    const float kv = vj * b4.x;
                     const float prev = s[i];
-                    const float temp = kv * ui + prev;
-                    o += temp * ri;
-                    so[i * S + lane] = prev * wi + kv;
+                    const float temp = kv * b4.y + prev;
+                    o += temp * b4.z;
+                    so[i * S + lane] = prev * b4.w + kv;
                 }
                 // 4. GroupNorm over the head, * ln_x, gate
                 const float mean = (float) (wave_sum_d((double) o) / (double) S);
