@@ -51,6 +51,11 @@ RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled)
  * at context creation from the model geometry, the weight format and the environment (RWKV_MI_NO_FUSED / RWKV_MI_NO_MEGA). */
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx);
 
+/* Diagnostic for decode path 2: runs `n` eager single-token steps of `token` and returns the shader-clock stamps the
+ * persistent kernel took in layer `layer`: out[(workgroup * 8 + wave) * 32 + k], 256 workgroups, k < 17 (wave 0: the
+ * polling wave's phases, waves 1..7: the row workers' phases; tools/trace.py prints them). false if path 2 is not active. */
+RWKV_API bool rwkv_mi_trace_phases(struct rwkv_context * ctx, uint32_t token, int layer, int n, long long * out);
+
 /* ---- layer pipeline: one process per GPU, each owning layers [layer_begin, layer_end) and their slice of the state ----
  * (supersedes the reference's n_gpu_layers CPU/GPU split, rwkv_model_loading.inc:129-142). The hand-off of the residual
  * stream between stages is the caller's job (RCCL send/recv over xGMI, see rwkv.cpp_amd/pipeline.py). */

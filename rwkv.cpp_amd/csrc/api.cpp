@@ -384,7 +384,7 @@ RWKV_API bool rwkv_mi_logits_store(struct rwkv_context * ctx, float * logits_out
 // device pointer of the context's logits buffer (valid after a last-stage step / any eval that produced logits)
 RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx) { return ctx->d_logits; }
 
-RWKV_API bool rwkv_mi_debug_mega_trace(struct rwkv_context * ctx, uint32_t token, int layer, int n, long long * out) {
+RWKV_API bool rwkv_mi_trace_phases(struct rwkv_context * ctx, uint32_t token, int layer, int n, long long * out) {
     if (!ctx->mega) return false;
     const bool g = ctx->use_graph; ctx->use_graph = false;
     bool ok = mega_v6_trace(ctx->mega, layer, out, false);

@@ -1,22 +1,23 @@
 // mega_v6.hip -- the RWKV-6 single-token (decode) step over ALL layers of a stage as ONE persistent launch.
 //
 // Why: at batch 1 every phase of a layer (fused_v6.hip's seven launches) is an all-to-all dependency, and a launch boundary
-// costs ~5 us of ramp + drain during which no weight bytes move; measured, the seven-launch path spends more time in those
-// gaps than in streaming (profiles/). Here one workgroup per CU stays resident for the whole token and
-//   * every wave owns a FIXED slice of every matrix (rows), so the weights of phase P+1 are loaded into registers while
-//     phase P is still waiting for its inputs: weights do not depend on activations, only the order of use does;
-//   * phases are chained by DATAFLOW, not by barriers: every value that crosses workgroups is an 8-byte {payload, tag}
-//     unit written with one agent-scope atomic store and polled with agent-scope atomic loads until the tag of the
-//     expected (token, layer, phase) shows up. No fence, no counter, no s_waitcnt vmcnt(0) on the producer side, so the
-//     weight stream of the next phase stays in flight across the hand-over.
-// Per wave the vector-memory queue returns in order, which fixes the schedule inside a phase:
-//   poll the phase's inputs -> issue the NEXT phase's weight loads -> compute with this phase's weights (landed while the
-//   wave was polling) -> tagged stores -> next phase's poll (returns once the weights in front of it have landed).
+// costs ~5 us of ramp + drain during which no weight bytes move (profiles/). Here one workgroup per CU
+// stays resident for the whole token:
+//   * every wave owns a FIXED slice of every matrix (rows), so the weights of the next phase are put in flight into
+//     registers as soon as the current phase's rows are done -- weights do not depend on activations, only the order of
+//     use does -- and stream while the activations are handed over;
+//   * phases are chained by DATAFLOW, not by barriers: every value that crosses workgroups is a 16-byte {payload, tag}
+//     unit written with one store and polled until the tag of the expected (token, layer, phase) shows up. No fence, no
+//     counter, no wait for outstanding loads on the producer side.
+// Vector-memory results return in order per wave, so a wave that polls cannot have a weight prefetch in flight: inside a
+// workgroup wave 0 (the "comm" wave) does all the polling into LDS and the other seven never wait on anything but the
+// workgroup barrier and their own loads. A grid-wide barrier costs 3.2-3.9 us on this part, a tagged hand-over of a
+// 4096-float vector to all 256 workgroups 3.5 us, of a small vector 1.5-2.2 us (tools/barrier_bench.hip, xchg_bench.hip).
 //
 // Arithmetic, reduction orders and epilogues are those of fused_v6.hip / kernels.hip: the results are
 // bit-identical to the seven-launch path and to the CPU oracle; only the distribution of rows over waves differs.
 //
-// Residency: the grid is one workgroup per CU (512 threads, ~100 KB LDS) and all of them must be resident at once, i.e. the
+// Residency: the grid is one workgroup per CU (512 threads, ~105 KB LDS) and all of them must be resident at once, i.e. the
 // device must not be shared with another process' persistent kernels. Polls are bounded: on timeout the abort word is set,
 // every workgroup drains without waiting, and the host reports the step as failed (it never hangs the device).
 #include "fused_blocks.h"
@@ -57,7 +58,6 @@ struct M6P {
     unsigned * ctl;                                  // [0] tag generation, [1] abort
     int F, DR, R, H, gpb;
     long long * trace; int trace_layer;
-    int delay_c, delay_e, delay_g;   // pacing of the bulk issues (x 1024 cycles), see worker_main
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -165,20 +165,6 @@ __device__ __forceinline__ void stage_qvec(Poll & pl, xrsrc xr, int src, int K, 
             q.isum[b] = (int) (short) (v.w >> 16);
         }
     });
-}
-
-// Waves without work in a phase define their staging registers too (zeros): a conditional issue alone would keep the
-// previous iteration's values live around the whole layer loop and push the kernel into scratch.
-template <int FMT, int R, int U>
-__device__ __forceinline__ void batch_zero(Batch<FMT, R, U> & bt) {
-#pragma unroll
-    for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-#pragma unroll
-            for (int k = 0; k < QF<FMT>::QS / 16; k++) bt.raw[u][r].q[k] = make_int4(0, 0, 0, 0);
-            bt.raw[u][r].qh = 0; bt.raw[u][r].sc = 0;
-        }
 }
 
 // Opaque copy: derived per-lane offsets (poll addresses, row offsets) are recomputed where they are used instead of
@@ -893,8 +879,10 @@ struct MegaV6 {
 typedef void (*MegaKernel)(M6P);
 struct MegaVariant { int fmt, ept, kqu, nbd, gpb; MegaKernel fn; };
 static const MegaVariant g_variants[] = {
-    {T_Q4_0, 8, 21, 4, 2, k6_mega<T_Q4_0, 8, 21, 4, 2>},   // D 4096, F <= 14336, decay rank 128
-    {T_Q4_0, 4, 11, 2, 1, k6_mega<T_Q4_0, 4, 11, 2, 1>},   // D 2048, F <= 7168,  decay rank 64
+#define MEGA_VARIANTS(FMT) \
+    {FMT, 8, 21, 4, 2, k6_mega<FMT, 8, 21, 4, 2>},   /* D 4096, F <= 14336, decay rank 128 */ \
+    {FMT, 4, 11, 2, 1, k6_mega<FMT, 4, 11, 2, 1>}    /* D 2048, F <= 7168,  decay rank 64  */
+    MEGA_VARIANTS(T_Q4_0), MEGA_VARIANTS(T_Q4_1), MEGA_VARIANTS(T_Q5_0), MEGA_VARIANTS(T_Q5_1), MEGA_VARIANTS(T_Q8_0),
 };
 
 static int mega_variant(const Model & m, int n_cu) {
@@ -1009,8 +997,6 @@ void * mega_v6_create(const Model & m) {
     q.ctl = mg->ctl;
     q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;
     q.gpb = (int) ((nbF + NB - 1) / NB);
-    auto envi = [](const char * n) { const char * v = getenv(n); return v ? atoi(v) : 0; };
-    q.delay_c = envi("RWKV_MI_DELAY_C"); q.delay_e = envi("RWKV_MI_DELAY_E"); q.delay_g = envi("RWKV_MI_DELAY_G");
     return mg;
 }
 

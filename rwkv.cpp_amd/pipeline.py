@@ -12,6 +12,7 @@ The orchestration below is executor-agnostic: `LibStageExecutor` drives librwkv.
 tests/test_pipeline_cpu.py plugs in the CPU oracle to check partitioning and protocol with gloo.
 """
 import ctypes
+import os
 import time
 from typing import List, Optional, Sequence, Tuple
 
@@ -245,6 +246,10 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
     costs, head, emb = stage_costs(spec, args.dtype)
     ranges = partition_layers(costs, world, head_cost=head, embed_cost=emb)
     lb, le = ranges[rank]
+    if torch.cuda.device_count() < world:
+        # several ranks share one GPU (smoke runs only): the persistent decode kernel needs the device to itself
+        # (all of its workgroups resident at once), so fall back to the per-layer launches
+        os.environ["RWKV_MI_NO_MEGA"] = "1"
     ex = LibStageExecutor(lib, path, lb, le, spec.n_layer)
     first = [(1103515245 * (j + 1)) % spec.n_vocab for j in range(world)]
 

@@ -13,11 +13,12 @@ pytestmark = pytest.mark.gpu
 TOKENS = [1, 2, 3, 400, 5, 77, 300, 9, 11, 12]
 
 
-@pytest.mark.parametrize("name", ["mega-v6-2048", "mega-v6-4096"])
-def test_mega_matches_oracle(tmp_path, name):
+@pytest.mark.parametrize("name,fmt", [("mega-v6-2048", "Q4_0"), ("mega-v6-4096", "Q4_0"), ("mega-v6-2048", "Q4_1"), ("mega-v6-2048", "Q5_0"),
+                                      ("mega-v6-4096", "Q5_1"), ("mega-v6-4096", "Q8_0")])
+def test_mega_matches_oracle(tmp_path, name, fmt):
     library()
     p = str(tmp_path / "m.bin")
-    synth.write_model(p, synth.CONFIGS[name], "Q4_0", seed=11)
+    synth.write_model(p, synth.CONFIGS[name], fmt, seed=11)
     om = O.OracleModel(p)
     m = model(p)
     assert m.decode_path() == 2, "persistent kernel not selected for a geometry it is built for"
@@ -59,3 +60,35 @@ def test_mega_equals_fused_path(tmp_path):
     assert np.array_equal(la, lb) and np.array_equal(sa, sb)
     m.free()
     f.free()
+
+
+def test_mega_stages_reproduce_full_model(tmp_path):
+    """Layer ranges (pipeline stages) through the persistent kernel: residual stream handed over in plain device memory."""
+    import ctypes
+    import torch
+    from rwkv_cpp_amd import pipeline
+    lib = library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS["mega-v6-2048"]
+    synth.write_model(p, spec, "Q4_0", seed=21)
+    full = model(p)
+    full.state_load(None)
+    exp, _ = full.decode_greedy(9, 5)
+    stages = [pipeline.LibStageExecutor(lib, p, b, e, spec.n_layer) for b, e in [(0, 1), (1, 3)]]
+    handles = [s.new_stream() for s in stages]
+    assert all(lib.library.rwkv_mi_decode_path(h) == 2 for h in handles)
+    tok = torch.tensor([9], dtype=torch.int32, device="cuda")
+    nxt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    xs = [torch.zeros(stages[0].handoff_len, dtype=torch.float32, device="cuda") for _ in range(3)]
+    got = []
+    for _ in range(5):
+        for i, s in enumerate(stages):
+            s.step(handles[i], tok, xs[i], xs[i + 1], nxt)
+            torch.cuda.synchronize()
+        got.append(int(nxt.item()))
+        tok.copy_(nxt)
+        torch.cuda.synchronize()
+    assert got == list(exp)
+    for s in stages:
+        s.close()
+    full.free()

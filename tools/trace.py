@@ -6,10 +6,10 @@ lib=library()
 p='/tmp/synthetic-rwkv6-7b-Q4_0-seed42.bin'
 if not os.path.exists(p): synth.write_model(p, synth.CONFIGS['rwkv6-7b'], 'Q4_0', seed=42)
 m=model(p); m.state_load(None)
-L=lib.library; L.rwkv_mi_debug_mega_trace.argtypes=[ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]; L.rwkv_mi_debug_mega_trace.restype=ctypes.c_bool
+L=lib.library; L.rwkv_mi_trace_phases.argtypes=[ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]; L.rwkv_mi_trace_phases.restype=ctypes.c_bool
 NB=256
 out=np.zeros(NB*8*32,dtype=np.int64)
-assert L.rwkv_mi_debug_mega_trace(m._ctx.ptr, 5, 5, 3, out.ctypes.data)
+assert L.rwkv_mi_trace_phases(m._ctx.ptr, 5, 5, 3, out.ctypes.data)
 t=out.reshape(NB,8,32)
 cn=['A.poll','A.bar+prol','B.load+poll','B.comp+C.poll','D','E.poll','F.poll(+bar)','F.prol','F.bar','F.quant','G.poll','G.bar']
 c=np.diff(t[:,0,:13],axis=1).astype(float)
