@@ -25,6 +25,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
 
 
+def pmc_traffic(path_id, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written
+    by tools/pmc_summary.py): the counters need their own profiler runs, so bench.py can only quote them, and only for the
+    workload and kernel they were taken on."""
+    f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(f):
+        return None, None
+    try:
+        d = json.load(open(f))
+    except Exception:
+        return None, None
+    e = d.get(f"{args.config}:{args.dtype}:path{path_id}")
+    if not e:
+        return None, None
+    return e.get("hbm_bytes_per_launch"), e.get("source")
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,10 +166,15 @@ def main():
             "load_seconds": load_s,
         }
         if not args.no_profile:
+            path_id = model.decode_path()
             p = model.profile_decode(first, min(args.steps, 32))
             ach = p["bytes"] / max(p["kernel_ms"], 1e-9) / 1e6
-            result["roofline"] = {"bound": "hbm", "kernel": f"quantised single-token projection kernels ({args.dtype}): k6_rkvgw, k6_proj_res, k6_ffn_kr", "achieved": ach,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            kname = {2: "k6_mega (persistent decode kernel: all layers of the stage in one launch)",
+                     1: "quantised single-token projection kernels: k6_rkvgw, k6_proj_res, k6_ffn_kr",
+                     0: "k_mvq_t1 (quantised single-token projection)"}[path_id] + f" [{args.dtype}]"
+            traffic, traffic_src = pmc_traffic(path_id, args)
+            result["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                   "launches": p["launches"], "avg_launch_us": p["kernel_ms"] * 1e3 / p["launches"],
                                   "avg_bytes_per_launch": p["bytes"] / p["launches"]}
         model.free()

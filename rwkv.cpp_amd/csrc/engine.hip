@@ -25,6 +25,41 @@ void ctx_fail(struct ::rwkv_context * ctx, int flags, const char * file, int lin
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// The persistent kernel is bound by cross-XCD hand-over latency, the seven-launch path by launch boundaries; which one wins
+// depends on the device (measured: 2.1 ms vs 2.6 ms per token on most MI355X boxes, 3.4 ms vs 2.6 ms on some). A few
+// eager tokens on zeroed state settle it per context at creation; the state is (re)initialised by every caller afterwards.
+static void calibrate_decode_path(rwkv_context * ctx) {
+    if (!ctx->mega || !ctx->fused_v6) return;
+    const char * e = getenv("RWKV_MI_NO_AUTOTUNE");
+    if (e && e[0] == '1') return;
+    Model & m = *ctx->model;
+    uint32_t * tok = nullptr;
+    if (hipMalloc((void **) &tok, 256) != hipSuccess) return;
+    const size_t sbytes = (size_t) m.state_len() * sizeof(float);
+    bool ok = hipMemsetAsync(tok, 0, 256, ctx->stream) == hipSuccess;
+    for (int i = 0; i < 2; i++) ok = ok && hipMemsetAsync(ctx->state[i], 0, sbytes, ctx->stream) == hipSuccess;
+    uint32_t * saved_tokens = ctx->d_tokens;
+    ctx->d_tokens = tok;
+    void * mega = ctx->mega;
+    auto run = [&](bool use_mega, int n) { ctx->mega = use_mega ? mega : nullptr; for (int i = 0; i < n && ok; i++) ok = forward(ctx, 1, false); ctx->mega = mega; };
+    auto timed = [&](bool use_mega) -> float {
+        run(use_mega, 2);
+        ok = ok && hipEventRecord(ctx->ev0, ctx->stream) == hipSuccess;
+        run(use_mega, 6);
+        ok = ok && hipEventRecord(ctx->ev1, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+        float ms = 0.0f;
+        ok = ok && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess;
+        return ms;
+    };
+    const float t_mega = timed(true), t_fused = timed(false);
+    (void) hipStreamSynchronize(ctx->stream);
+    ctx->d_tokens = saved_tokens;
+    ctx->cur = 0;
+    ctx->last_error = 0;
+    (void) hipFree(tok);
+    if (!ok || mega_v6_aborted(mega) || t_fused < 0.97f * t_mega) { mega_v6_destroy(mega); ctx->mega = nullptr; }
+}
+
 rwkv_context * create_context(Model * m, uint32_t n_threads) {
     std::unique_ptr<rwkv_context> ctx(new (std::nothrow) rwkv_context());
     RW_CHECK(RWKV_ERROR_CTX | RWKV_ERROR_ALLOC, nullptr, ctx != nullptr, "Failed to allocate rwkv_context");
@@ -53,6 +88,7 @@ rwkv_context * create_context(Model * m, uint32_t n_threads) {
         ctx->fused_v6 = true;
         const char * nm = getenv("RWKV_MI_NO_MEGA");
         if (!(nm && nm[0] == '1')) ctx->mega = mega_v6_create(*m);
+        calibrate_decode_path(ctx.get());
     }
     return ctx.release();
 }

@@ -10,6 +10,9 @@ from gpu_lib import library, model, synth
 
 pytestmark = pytest.mark.gpu
 
+# contexts normally time both single-token paths at creation and keep the faster one; these tests are about the persistent kernel
+os.environ["RWKV_MI_NO_AUTOTUNE"] = "1"
+
 TOKENS = [1, 2, 3, 400, 5, 77, 300, 9, 11, 12]
 
 
