@@ -27,3 +27,4 @@ m.state_load(None)
 m.decode_greedy(5, 8)
 toks, ms = m.decode_greedy(5, 64)
 print("rwkv_mi_decode_greedy (state resident): %.1f tokens/s" % (64 / (ms * 1e-3)))
+m.free()
