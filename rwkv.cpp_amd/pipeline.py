@@ -246,9 +246,11 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
     costs, head, emb = stage_costs(spec, args.dtype)
     ranges = partition_layers(costs, world, head_cost=head, embed_cost=emb)
     lb, le = ranges[rank]
-    if torch.cuda.device_count() < world:
-        # several ranks share one GPU (smoke runs only): the persistent decode kernel needs the device to itself
-        # (all of its workgroups resident at once), so fall back to the per-layer launches
+    if world > 1:
+        # The persistent decode kernel needs every CU of the device at once. In the pipeline RCCL's send / recv kernels sit
+        # resident on a CU while they wait for the peer, so a stage could not become resident until the peer moved on (stalls,
+        # and with several ranks on one GPU in smoke runs, a deadlock). Not validated on a multi-GPU node yet: stages use the
+        # seven-launch path.
         os.environ["RWKV_MI_NO_MEGA"] = "1"
     ex = LibStageExecutor(lib, path, lb, le, spec.n_layer)
     first = [(1103515245 * (j + 1)) % spec.n_vocab for j in range(world)]
