@@ -52,7 +52,7 @@ RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled)
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx);
 
 /* Diagnostic for decode path 2: runs `n` eager single-token steps of `token` and returns the shader-clock stamps the
- * persistent kernel took in layer `layer`: out[(workgroup * 8 + wave) * 32 + k], 256 workgroups, k < 17 (wave 0: the
+ * persistent kernel took in layer `layer`: out[(workgroup * 8 + wave) * 32 + k], 256 workgroups, k < 30 (k < 17 shader-clock stamps, 17..29 stamps of the 100 MHz real-time counter; wave 0: the
  * polling wave's phases, waves 1..7: the row workers' phases; tools/trace.py prints them). false if path 2 is not active. */
 RWKV_API bool rwkv_mi_trace_phases(struct rwkv_context * ctx, uint32_t token, int layer, int n, long long * out);
 

@@ -250,6 +250,8 @@ __device__ __forceinline__ void qvec_store4(const QVec & v, int nb, int i, unsig
     if (e == 0) { v.d[blk] = d16; v.s[blk] = s16; v.isum[blk] = isum; }
 }
 
+// RSTAMP: the 100 MHz real-time counter, consistent across XCDs (hand-over latencies); STAMP: the shader clock (phase lengths)
+#define RSTAMP(K) do { if (p.trace && li == p.trace_layer && (tidst & 63) == 0) p.trace[((long long) blockIdx.x * 8 + (tidst >> 6)) * 32 + (K)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
 #define STAMP(K) do { if (p.trace && li == p.trace_layer && (tidst & 63) == 0) p.trace[((long long) blockIdx.x * 8 + (tidst >> 6)) * 32 + (K)] = (long long) __builtin_readcyclecounter(); } while (0)
 
 template <int FMT, int EPT, int KQU, int NBD, int GPB>
@@ -552,7 +554,7 @@ struct K6 {
                 wBmaa[q] = ar.f(L.maa[bf[q]])[bd[q]];
             }
             __builtin_amdgcn_sched_barrier(0);
-            STAMP(1);
+            STAMP(1); RSTAMP(17);
             __syncthreads();
             prologue_A(l, pa, sout_l, blk == 0, lane);
             STAMP(2);
@@ -562,7 +564,7 @@ struct K6 {
                 __builtin_amdgcn_sched_barrier(0);
                 poll_units<5, 64>(pl, xr, p.tl, 5 * R, tagL + SLOT_TL, lane, [&](int i, const v4u & v) { l.tl[i] = __uint_as_float(v.x); });
                 __builtin_amdgcn_wave_barrier();
-                STAMP(3);
+                STAMP(3); RSTAMP(18);
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const bool has = q == 0 ? blk < NCH : b_chunk2 >= 0;
@@ -579,13 +581,15 @@ struct K6 {
                     }
                 }
             }
+            RSTAMP(19);
             // ---- C ----
             issue_C(r, ar, L, own, lane);
             stage_qvec<DU, 64>(pl, xr, p.act5 + blk_act * (int) p.act_stride, D, tagL + SLOT_ACT, l.act, lane);
             if (blk_xhas) stage_qvec<DU, 64>(pl, xr, p.act5, D, tagL + SLOT_ACT, l.actw, lane);
-            STAMP(4);
+            STAMP(4); RSTAMP(20);
             __syncthreads();
             compute_C(r, l, xr, p, tagL, own, lane);
+            RSTAMP(21);
             // ---- D: WKV head of this workgroup ----
             if (d_has) {
                 const int c = d_head * S + lane;
@@ -672,20 +676,21 @@ struct K6 {
                 quant_block32(y, qi, d16, s16, isum);
                 tq_store_block(xr, p.yq, 2 * d_head + (lane >> 5), lane & 31, qi, d16, s16, isum, tagL + SLOT_YQ);
             }
-            STAMP(5);
+            STAMP(5); RSTAMP(22);
             // ---- E ----
             issue_E(r, ar, L, own, lane);
             stage_qvec<DU, 64>(pl, xr, p.yq, D, tagL + SLOT_YQ, l.yq, lane);
-            STAMP(6);
+            STAMP(6); RSTAMP(23);
             __syncthreads();
             compute_E(r, l, xr, p, tagL, own, lane);
+            RSTAMP(24);
             issue_pf(pf, ar, L, sin_l, lane0);
             __builtin_amdgcn_sched_barrier(0);
             // ---- F ----
             poll_units<XU, 64>(pl, xr, p.xatt, NBLK * NOWN, tagL + SLOT_XATT, lane, [&](int i, const v4u & v) { x_sink(l.x, i, v); });
             issue_Fk(r, p, ar, L, own, lane);
             issue_Fr(r, ar, L, own, lane);
-            STAMP(7);
+            STAMP(7); RSTAMP(25);
             __syncthreads();
             prologue_F(l, pf, sout_l, blk == 0, lane);
             STAMP(8);
@@ -705,7 +710,7 @@ struct K6 {
                     tq_store_block(xr, p.kq, valid ? g : 0, lane & 31, qi, d16, s16, isum, tagL + SLOT_KQ, valid);
                 }
             }
-            STAMP(10);
+            STAMP(10); RSTAMP(26);
             // ---- G ----
             {
                 const int nl = li + 1 < p.n_layers ? li + 1 : li;
@@ -714,9 +719,10 @@ struct K6 {
             issue_G(r, p, ar, L, own, lane);
             stage_qvec<KQU, 64>(pl, xr, p.kq, F, tagL + SLOT_KQ, l.kq, lane);
             poll_units<1, 64>(pl, xr, p.rr + blk * NOWN, NOWN, tagL + SLOT_KQ, lane, [&](int i, const v4u & v) { x_sink(l.rr, i, v); });
-            STAMP(11);
+            STAMP(11); RSTAMP(27);
             __syncthreads();
             compute_G(r, l, xr, p, tagL, own, lane);
+            RSTAMP(28);
             STAMP(12);
         }
     }
@@ -767,7 +773,7 @@ struct K6 {
                     rows_finish<FMT, 1, UD>(wA, nullptr, nullptr, nullptr, 0, 5 * R, nb, qvec_at(l.q1, D), lane, res);
                     if (lane == 0) tg_store(xr, p.tl + a_row, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
                 }
-                STAMP(4);
+                STAMP(4); RSTAMP(17);
                 issue_C(r, ar, L, own, lane);
                 batch_issue_opt<FMT, 1, UD>(x_has, wCx, ar.w(L.dw1), x_row, DR, nb, 0, lane);
                 STAMP(5);
@@ -786,6 +792,7 @@ struct K6 {
                     if (lane == 0) tg_store(xr, p.dl + x_row, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
                 }
                 compute_C(r, l, xr, p, tagL, own, lane);
+                RSTAMP(21);
                 issue_E(r, ar, L, own, lane);
                 issue_Fk(r, p, ar, L, own, lane);
             }
@@ -798,6 +805,7 @@ struct K6 {
                 __syncthreads();                       // yq staged
                 STAMP(9);
                 compute_E(r, l, xr, p, tagL, own, lane);
+                RSTAMP(24);
                 issue_pf(pf, ar, L, sin_l, tid);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -813,7 +821,7 @@ struct K6 {
                 STAMP(12);
                 issue_Fr(r, ar, L, own, lane);
                 compute_F(r, l, xr, p, tagL, own, lane);
-                STAMP(13);
+                STAMP(13); RSTAMP(29);
                 __syncthreads();                       // key rows in l.out -> comm quantises them
                 issue_G(r, p, ar, L, own, lane);
             }
@@ -824,7 +832,7 @@ struct K6 {
                 __syncthreads();                       // kq and rr staged
                 STAMP(15);
                 compute_G(r, l, xr, p, tagL, own, lane);
-                STAMP(16);
+                STAMP(16); RSTAMP(28);
                 const int nl = li + 1 < p.n_layers ? li + 1 : li;
                 issue_A(p.layers[nl], p.sin + (long long) nl * p.state_stride, tid, lane);
             }

@@ -21,4 +21,17 @@ w=np.diff(t[:,1:,:17],axis=2).astype(float)
 print('WORKER waves: mean / min / max cycles')
 for i,n in enumerate(wn): print('%-16s %8.0f %8.0f %8.0f'%(n,w[:,:,i].mean(),w[:,:,i].min(),w[:,:,i].max()))
 print('worker layer total', (t[:,1:,16]-t[:,1:,0]).mean())
+# hand-over latencies from the 100 MHz real-time counter (consistent across XCDs): ready = last producer stamp anywhere
+R=t.astype(float)
+def ho(name, prod, cons):
+    ready=max(R[:,w,k].max() for (w,k) in prod)
+    seen=R[:,0,cons]
+    print('%-22s last producer -> consumer staged: mean %.2f us  min %.2f  max %.2f   (producer spread %.2f us)'%(name,(seen.mean()-ready)/100,(seen.min()-ready)/100,(seen.max()-ready)/100,(ready-min(R[:,w,k].min() for (w,k) in prod))/100))
+W=range(1,8)
+ho('tl (A->B)', [(w,17) for w in W], 18)
+ho('act5 (B->C)', [(0,19)], 20)
+ho('yq (D->E)', [(0,22)], 23)
+ho('x_att (E->F)', [(0,24)]+[(w,24) for w in W], 25)
+ho('kq (F->G)', [(0,26)], 27)
+print('layer wall (xffn stored, max over all) - (x staged A, min): %.2f us'%((max(R[:,w,28].max() for w in range(8))-R[:,0,17].min())/100))
 sys.stdout.flush(); os._exit(0)
