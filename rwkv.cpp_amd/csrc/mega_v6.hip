@@ -405,15 +405,21 @@ struct K6 {
     static __device__ __forceinline__ void compute_C(Rows & r, const Lds & l, xrsrc xr, const M6P & p, unsigned tagL, int own, int lane) {
         const QVec la = qvec_at(l.act, D);
         const int mat = c_mat();
+        // all row sums first, then ONE epilogue with lane 2 si + r finishing row r of set si (the gate's silu is a double-
+        // precision exp: four of them back to back put the 64 gate workgroups behind everyone else)
+        float all[2 * NSC];
 #pragma unroll
         for (int si = 0; si < NSC; si++) {
-            const int row0 = c_base() + 2 * (own + si * NOWN);
             float res[2];
-            rows_finish<FMT, 2, UD>(r.wC[si], nullptr, nullptr, nullptr, row0, D, nb, la, lane, res);
-            float v = pick_lane<2>(res, lane);          // lane r finishes row r ...
-            if (mat == 3) v = v / (1.0f + det_expf(-v));
-            const int v1 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true);   // ... lane 0 collects row 1 (row_shl:1)
-            if (lane == 0) tg_store(xr, p.rkvg + ((mat * D + row0) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
+            rows_finish<FMT, 2, UD>(r.wC[si], nullptr, nullptr, nullptr, 0, D, nb, la, lane, res);
+            all[2 * si] = res[0]; all[2 * si + 1] = res[1];
+        }
+        float v = pick_lane<2 * NSC>(all, lane);
+        if (mat == 3) v = v / (1.0f + det_expf(-v));
+        const int v1 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true);   // lane 2 si collects row 1 (row_shl:1)
+        if (lane < 2 * NSC && (lane & 1) == 0) {
+            const int row0 = c_base() + 2 * (own + (lane >> 1) * NOWN);
+            tg_store(xr, p.rkvg + ((mat * D + row0) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
         }
     }
     static __device__ __forceinline__ void issue_E(Rows & r, const M6Arena & ar, const M6Layer & L, int own, int lane) {
@@ -513,11 +519,11 @@ struct K6 {
         for (int wk = 0; wk < NWK; wk++) { const int g = wk * NBLK + blk - 5 * R; blk_xhas = blk_xhas || (g >= 0 && g < DR); }
         const bool d_has = blk < H;
         const int d_head = blk;
-        // B: 64-element chunks of the five mixes; chunk c < NBLK on workgroup c, the rest on the LAST workgroups (the first
-        // ones run the WKV heads)
+        // B: 64-element chunks of the five mixes; chunk c < NBLK on workgroup c, the rest on workgroups NBLK/4.. (the first
+        // quarter runs the WKV heads, the last quarter the gate rows with their silu epilogue)
         constexpr int NCH = 5 * (D / 64);
         const int b_extra = NCH - NBLK;   // chunks beyond one per workgroup (host guarantees <= NBLK)
-        const int b_chunk2 = (b_extra > 0 && blk >= NBLK - b_extra) ? NBLK + (blk - (NBLK - b_extra)) : -1;
+        const int b_chunk2 = (b_extra > 0 && blk >= NBLK / 4 && blk < NBLK / 4 + b_extra) ? NBLK + (blk - NBLK / 4) : -1;
         PA pa; PF pf;
         constexpr int own = NOWN - 1;   // the comm wave is the eighth row owner: its weights go in flight right before the poll that precedes their use
         Rows r;
@@ -570,9 +576,15 @@ struct K6 {
                     const bool has = q == 0 ? blk < NCH : b_chunk2 >= 0;
                     if (has) {
                         const float * tlf = l.tl + bf[q] * R;
+                        // R is 32 or 64: two straight-line halves. (A per-term `if (m < R)` compiled into 64 basic blocks, each
+                        // waiting for its own LDS read: 4 us per chunk instead of 0.5.)
                         float acc = 0.0f;
 #pragma unroll
-                        for (int m = 0; m < 64; m++) if (m < R) acc += (&wB4[q][m >> 2].x)[m & 3] * tlf[m];
+                        for (int m = 0; m < 32; m++) acc += (&wB4[q][m >> 2].x)[m & 3] * tlf[m];
+                        if (R > 32) {
+#pragma unroll
+                            for (int m = 32; m < 64; m++) acc += (&wB4[q][m >> 2].x)[m & 3] * tlf[m];
+                        }
                         const float mm = (acc + wBmaa[q]) * l.sx[bd[q]];
                         const float o = mm + l.xn[bd[q]];
                         int qi, isum; float d16, s16;
@@ -901,7 +913,7 @@ static int mega_variant(const Model & m, int n_cu) {
     if (!L0.ffn_key || !L0.att_time_decay_w1 || !L0.att_time_maa_w1) return -1;
     const int64_t F = L0.ffn_key->ne[1], DR = L0.att_time_decay_w1->ne[1], R5 = L0.att_time_maa_w1->ne[1], R = R5 / 5;
     const int64_t NB = 256, NW = NB * 7;   // the kernel is laid out for exactly 256 workgroups (one per CU of an MI355X)
-    if (n_cu != NB || H > NB || F % 32 != 0 || 5 * (D / 64) + R5 + DR > NW || R > 64 || R5 > 320) return -1;
+    if (n_cu != NB || H > NB || F % 32 != 0 || 5 * (D / 64) + R5 + DR > NW || !(R == 32 || R == 64)) return -1;
     for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
         const LayerW & L = m.layers[i];
         const DevTensor * mats[] = {L.att_receptance, L.att_key, L.att_value, L.att_gate, L.att_output, L.att_time_maa_w1,

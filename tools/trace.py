@@ -33,5 +33,12 @@ ho('act5 (B->C)', [(0,19)], 20)
 ho('yq (D->E)', [(0,22)], 23)
 ho('x_att (E->F)', [(0,24)]+[(w,24) for w in W], 25)
 ho('kq (F->G)', [(0,26)], 27)
+# who is late? producer stamps relative to the earliest, by XCD (workgroup index mod 8) and the five latest workgroups
+for name,(ws,k) in (('tl stored',(W,17)),('act5 stored',([0],19)),('rkvg stored',(range(8),21)),('x_att stored',(range(8),24)),('kq stored',([0],26)),('x_ffn stored',(range(8),28))):
+    tt=np.stack([R[:,w,k] for w in ws],axis=1).max(axis=1)
+    rel=(tt-tt.min())/100
+    byx=[rel[x::8].mean() for x in range(8)]
+    late=np.argsort(-rel)[:5]
+    print('%-13s spread %.2f us; mean lateness by XCD %s; latest workgroups %s'%(name,rel.max(),' '.join('%.2f'%v for v in byx),' '.join('%d(%.2f)'%(b,rel[b]) for b in late)))
 print('layer wall (xffn stored, max over all) - (x staged A, min): %.2f us'%((max(R[:,w,28].max() for w in range(8))-R[:,0,17].min())/100))
 sys.stdout.flush(); os._exit(0)
