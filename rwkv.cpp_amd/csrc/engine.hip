@@ -26,7 +26,7 @@ void ctx_fail(struct ::rwkv_context * ctx, int flags, const char * file, int lin
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // The persistent kernel is bound by cross-XCD hand-over latency, the seven-launch path by launch boundaries; which one wins
-// depends on the device (measured: 2.1 ms vs 2.6 ms per token on most MI355X boxes, 3.4 ms vs 2.6 ms on some). A few
+// depends on the device (measured: 2.0 ms vs 2.6 ms per token on most MI355X boxes, 3.4 ms vs 2.9 ms on some). A few
 // eager tokens on zeroed state settle it per context at creation; the state is (re)initialised by every caller afterwards.
 static void calibrate_decode_path(rwkv_context * ctx) {
     if (!ctx->mega || !ctx->fused_v6) return;
