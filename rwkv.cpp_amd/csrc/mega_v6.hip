@@ -289,12 +289,26 @@ struct K6 {
 
     // LayerNorm statistics of the row in l.x (256 partials, threads 0..255); leaves x - mean in l.x
     static __device__ __forceinline__ float ln_stats(const Lds & l, int tid) {
+        // Thread t < 256 owns the partial over elements t, t + 256, ... (summed in that order). The D / 256 values are read
+        // into registers in one batch: as a rolled loop every iteration waited for its own LDS read (~130 cycles x 16 x 2).
+        constexpr int NP = D / 256;
         const bool pro = tid < 256;
+        float xv[NP];
+        if (pro) {
+#pragma unroll
+            for (int j = 0; j < NP; j++) xv[j] = l.x[tid + 256 * j];
+        }
         double sacc = 0.0;
-        if (pro) for (int i = tid; i < D; i += 256) sacc += (double) l.x[i];
+        if (pro) {
+#pragma unroll
+            for (int j = 0; j < NP; j++) sacc += (double) xv[j];
+        }
         const float mean = (float) (block_sum_d_8w(sacc, l.red) / (double) D);
         double s2 = 0.0;
-        if (pro) for (int i = tid; i < D; i += 256) { const float v = l.x[i] - mean; l.x[i] = v; s2 += (double) (v * v); }
+        if (pro) {
+#pragma unroll
+            for (int j = 0; j < NP; j++) { const float v = xv[j] - mean; l.x[tid + 256 * j] = v; s2 += (double) (v * v); }
+        }
         const float var = (float) (block_sum_d_8w(s2, l.red) / (double) D);
         return 1.0f / sqrtf(var + 1e-5f);
     }
