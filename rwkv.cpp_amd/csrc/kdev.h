@@ -93,21 +93,30 @@ __device__ __forceinline__ int half_sum_i(int v) {
 }
 
 // exp in double (ln2 hi/lo reduction, degree-13 Taylor, fma Horner), rounded once to float; same routine as the oracle's.
+// A double constant held in a scalar register pair, re-materialised (two s_mov) where it is used. Left to itself the
+// compiler hoists the sixteen constants of det_exp_d out of a kernel's main loop into vector registers and, under pressure,
+// spills them: a scratch reload in the middle of a dependent exp chain is a memory round trip.
+__device__ __forceinline__ double kconst(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int) (b & 0xFFFFFFFFll), hi = (int) (b >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double det_exp_d(double x) {
-    const double n = rint(x * 1.4426950408889634074);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;
-    p = fma(p, r, 2.08767569878681e-09);
-    p = fma(p, r, 2.505210838544172e-08);
-    p = fma(p, r, 2.755731922398589e-07);
-    p = fma(p, r, 2.7557319223985893e-06);
-    p = fma(p, r, 2.48015873015873e-05);
-    p = fma(p, r, 1.984126984126984e-04);
-    p = fma(p, r, 1.388888888888889e-03);
-    p = fma(p, r, 8.333333333333333e-03);
-    p = fma(p, r, 4.1666666666666664e-02);
-    p = fma(p, r, 1.6666666666666666e-01);
+    const double n = rint(x * kconst(1.4426950408889634074));
+    double r = fma(n, kconst(-6.93147180369123816490e-01), x);
+    r = fma(n, kconst(-1.90821492927058770002e-10), r);
+    double p = kconst(1.6059043836821613e-10);
+    p = fma(p, r, kconst(2.08767569878681e-09));
+    p = fma(p, r, kconst(2.505210838544172e-08));
+    p = fma(p, r, kconst(2.755731922398589e-07));
+    p = fma(p, r, kconst(2.7557319223985893e-06));
+    p = fma(p, r, kconst(2.48015873015873e-05));
+    p = fma(p, r, kconst(1.984126984126984e-04));
+    p = fma(p, r, kconst(1.388888888888889e-03));
+    p = fma(p, r, kconst(8.333333333333333e-03));
+    p = fma(p, r, kconst(4.1666666666666664e-02));
+    p = fma(p, r, kconst(1.6666666666666666e-01));
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);

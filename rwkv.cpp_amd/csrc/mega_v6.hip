@@ -619,10 +619,6 @@ struct K6 {
             // ---- D: WKV head of this workgroup ----
             if (d_has) {
                 const int c = d_head * S + lane;
-                float s[S];
-                const float * st = sin_l + 2 * D + (long long) d_head * S * S;
-#pragma unroll
-                for (int i = 0; i < S; i++) s[i] = st[i * S + lane];
                 RawBlk<FMT> w2[NBD];
                 const WPl dw2 = ar.w(L.dw2);
 #pragma unroll
@@ -664,6 +660,13 @@ struct K6 {
 #pragma unroll
                     for (int i = 0; i < o; i++) P[i] += P[i + o];
                 const float wdec = det_expf(-det_expf(P[0] + td));
+                // the head's state column goes in flight now, not before the decay: 64 more live registers pushed the
+                // double-precision exp's constants into scratch, and a scratch reload is a memory round trip on this chain
+                float s[S];
+                const float * st = sin_l + 2 * D + (long long) d_head * S * S;
+#pragma unroll
+                for (int i = 0; i < S; i++) s[i] = st[i * S + lane];
+                __builtin_amdgcn_sched_barrier(0);
                 // r,k,v,g of channel c: one unit per 2-row set
                 {
                     const int ptr[4] = {p.rkvg + (c >> 1), p.rkvg + ((D + c) >> 1), p.rkvg + ((2 * D + c) >> 1), p.rkvg + ((3 * D + c) >> 1)};
