@@ -213,10 +213,10 @@ __device__ __forceinline__ void fill_row(float * l_row, const float * __restrict
 // returns scale; afterwards xn_i = ((l_row[i] * scale) * w[i]) + b[i]   (same steps as block_layernorm in kernels.hip)
 __device__ __forceinline__ float block_ln_stats(float * l_row, int64_t D, double * red) {
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < D; i += 256) s += (double) l_row[i];
+    s = ln_partial_sum(l_row, D);
     const float mean = (float)(block_sum_d(s, red) / (double) D);
     double s2 = 0.0;
-    for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
+    s2 = ln_partial_var(l_row, D, mean);
     const float var = (float)(block_sum_d(s2, red) / (double) D);
     return 1.0f / sqrtf(var + 1e-5f);
 }

@@ -52,10 +52,10 @@ __global__ __launch_bounds__(1024) void k6_att_prep(P6A p) {
     if (pro) fill_row(l_row, p.x, D);
     __syncthreads();
     double sacc = 0.0;
-    if (pro) for (int64_t i = threadIdx.x; i < D; i += 256) sacc += (double) l_row[i];
+    if (pro) sacc = ln_partial_sum(l_row, D);
     const float mean = (float)(block_sum_d_8w(sacc, red) / (double) D);
     double s2 = 0.0;
-    if (pro) for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
+    if (pro) s2 = ln_partial_var(l_row, D, mean);
     const float var = (float)(block_sum_d_8w(s2, red) / (double) D);
     const float scale = 1.0f / sqrtf(var + 1e-5f);
     // elementwise + quantise: every thread, 4 independent element steps interleaved
@@ -344,10 +344,10 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
     if (pro) fill_row(l_row, p.x, D);
     __syncthreads();
     double sacc = 0.0;
-    if (pro) for (int64_t i = threadIdx.x; i < D; i += 256) sacc += (double) l_row[i];
+    if (pro) sacc = ln_partial_sum(l_row, D);
     const float mean = (float)(block_sum_d_8w(sacc, red) / (double) D);
     double s2 = 0.0;
-    if (pro) for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
+    if (pro) s2 = ln_partial_var(l_row, D, mean);
     const float var = (float)(block_sum_d_8w(s2, red) / (double) D);
     const float scale = 1.0f / sqrtf(var + 1e-5f);
     auto fin = [&](int64_t i, float lw, float lb, float pv, float mk, float mr, float & xk, float & xr) {

@@ -147,6 +147,36 @@ __device__ __forceinline__ float round_f16(float x) {
     return __half2float(__float2half_rn(x));
 }
 
+// LayerNorm partials of thread t < 256: elements t, t + 256, ... of a row in LDS, accumulated in that order (DESIGN.md
+// section 4). The LDS reads go out eight at a time: as a plain loop every iteration waits for its own read.
+__device__ __forceinline__ double ln_partial_sum(const float * l_row, int64_t D) {
+    double s = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 256 < D; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = l_row[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += (double) v[u];
+    }
+    for (; i < D; i += 256) s += (double) l_row[i];
+    return s;
+}
+// second pass: replaces x by x - mean and returns the partial of (x - mean)^2
+__device__ __forceinline__ double ln_partial_var(float * l_row, int64_t D, float mean) {
+    double s2 = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 256 < D; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = l_row[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const float d = v[u] - mean; l_row[i + u * 256] = d; s2 += (double) (d * d); }
+    }
+    for (; i < D; i += 256) { const float d = l_row[i] - mean; l_row[i] = d; s2 += (double) (d * d); }
+    return s2;
+}
+
 // Sum of one double per thread over a 256-thread workgroup, as a halving tree over the 256 partials
 // (p[i] += p[i+128]; p[i] += p[i+64]; then the 64-entry butterfly): the order the oracle's fold_d(.., 256) uses.
 __device__ __forceinline__ double block_sum_d(double v, double * red /* [257] */) {

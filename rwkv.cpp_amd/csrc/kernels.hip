@@ -342,10 +342,10 @@ __device__ __forceinline__ float emb_elem(const EmbView & e, int64_t row, int64_
 __device__ __forceinline__ void block_layernorm(float * l_row, int64_t D, const float * __restrict__ w, const float * __restrict__ b,
                                                 float eps, float * __restrict__ out, double * red) {
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < D; i += 256) s += (double) l_row[i];
+    s = ln_partial_sum(l_row, D);
     const float mean = (float)(block_sum_d(s, red) / (double) D);
     double s2 = 0.0;
-    for (int64_t i = threadIdx.x; i < D; i += 256) { const float v = l_row[i] - mean; l_row[i] = v; s2 += (double)(v * v); }
+    s2 = ln_partial_var(l_row, D, mean);
     const float var = (float)(block_sum_d(s2, red) / (double) D);
     const float scale = 1.0f / sqrtf(var + eps);
     int64_t i = threadIdx.x;
