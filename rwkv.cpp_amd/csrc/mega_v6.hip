@@ -673,7 +673,7 @@ struct K6 {
                     const bool valid[4] = {true, true, true, true};
                     v4u dv[4];
                     poll_ptrs<4>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
-#pragma unroll
+    #pragma unroll
                     for (int q = 0; q < 4; q++) dq[q] = (c & 1) ? dv[q].y : dv[q].x;
                 }
                 // 3. WKV6 (ggml_rwkv_wkv6): lane j owns value column j; {k, u, r, w}_i are broadcast through LDS (l.tl is free here)
@@ -746,6 +746,7 @@ struct K6 {
                 issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, lane0);
             }
             issue_G(r, p, ar, L, own, lane);
+            __syncthreads();   // releases the workers' value-projection stream
             stage_qvec<KQU, 64>(pl, xr, p.kq, F, tagL + SLOT_KQ, l.kq, lane);
             poll_units<1, 64>(pl, xr, p.rr + blk * NOWN, NOWN, tagL + SLOT_KQ, lane, [&](int i, const v4u & v) { x_sink(l.rr, i, v); });
             STAMP(11); RSTAMP(27);
@@ -852,6 +853,9 @@ struct K6 {
                 compute_F(r, l, xr, p, tagL, own, lane);
                 STAMP(13); RSTAMP(29);
                 __syncthreads();                       // key rows in l.out -> comm quantises them
+                // the stream below fills the CU's memory pipe for ~6 us: the comm wave's k stores and own loads go in first
+                // (second barrier; +4 % over issuing straight after the first one)
+                __syncthreads();
                 issue_G(r, p, ar, L, own, lane);
             }
             // ---- G; then the next layer's prologue parameters and W1 row ----
