@@ -585,6 +585,7 @@ struct K6 {
                 poll_units<5, 64>(pl, xr, p.tl, 5 * R, tagL + SLOT_TL, lane, [&](int i, const v4u & v) { l.tl[i] = __uint_as_float(v.x); });
                 __builtin_amdgcn_wave_barrier();
                 STAMP(3); RSTAMP(18);
+                __syncthreads();   // releases the workers' r/k/v/g stream
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const bool has = q == 0 ? blk < NCH : b_chunk2 >= 0;
@@ -804,6 +805,7 @@ struct K6 {
                     if (lane == 0) tg_store(xr, p.tl + a_row, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
                 }
                 STAMP(4); RSTAMP(17);
+                __syncthreads();   // the r/k/v/g stream starts once the comm wave has polled tl (+1.7 %: its polls are not behind the stream)
                 issue_C(r, ar, L, own, lane);
                 batch_issue_opt<FMT, 1, UD>(x_has, wCx, ar.w(L.dw1), x_row, DR, nb, 0, lane);
                 STAMP(5);
