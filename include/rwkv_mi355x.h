@@ -51,6 +51,11 @@ RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled)
  * at context creation from the model geometry, the weight format and the environment (RWKV_MI_NO_FUSED / RWKV_MI_NO_MEGA). */
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx);
 
+/* Waits for the context's stream and reports whether every persistent-kernel step so far completed (false: a poll timed out
+ * because not all workgroups could be resident -- the device is shared, or other kernels held CUs for seconds; results since
+ * then are invalid and the context should be re-created with RWKV_MI_NO_MEGA=1). Always true on paths 0 and 1. */
+RWKV_API bool rwkv_mi_decode_healthy(struct rwkv_context * ctx);
+
 /* Diagnostic for decode path 2: runs `n` eager single-token steps of `token` and returns the shader-clock stamps the
  * persistent kernel took in layer `layer`: out[(workgroup * 8 + wave) * 32 + k], 256 workgroups, k < 30 (k < 17 shader-clock stamps, 17..29 stamps of the 100 MHz real-time counter; wave 0: the
  * polling wave's phases, waves 1..7: the row workers' phases; tools/trace.py prints them). false if path 2 is not active. */

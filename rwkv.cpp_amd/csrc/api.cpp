@@ -307,6 +307,11 @@ RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major
 
 RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled) { ctx->use_graph = enabled; }
 
+RWKV_API bool rwkv_mi_decode_healthy(struct rwkv_context * ctx) {
+    if (hipSetDevice(ctx->model->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    return !(ctx->mega && mega_v6_aborted(ctx->mega));
+}
+
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx) { return ctx->mega ? 2 : (ctx->fused_v6 ? 1 : 0); }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -132,6 +132,9 @@ class LibStageExecutor(StageExecutor):
     def bytes_per_token(self) -> int:
         return int(self.L.rwkv_mi_bytes_per_token(self.ctx))
 
+    def healthy(self, handle) -> bool:
+        return bool(self.L.rwkv_mi_decode_healthy(handle))
+
     def close(self):
         for h in self._handles[1:]:
             self.L.rwkv_free(h)
@@ -246,13 +249,22 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
     costs, head, emb = stage_costs(spec, args.dtype)
     ranges = partition_layers(costs, world, head_cost=head, embed_cost=emb)
     lb, le = ranges[rank]
-    if world > 1:
-        # The persistent decode kernel needs every CU of the device at once. In the pipeline RCCL's send / recv kernels sit
-        # resident on a CU while they wait for the peer, so a stage could not become resident until the peer moved on (stalls,
-        # and with several ranks on one GPU in smoke runs, a deadlock). Not validated on a multi-GPU node yet: stages use the
-        # seven-launch path.
-        os.environ["RWKV_MI_NO_MEGA"] = "1"
-    ex = LibStageExecutor(lib, path, lb, le, spec.n_layer)
+    # Which single-token path the stages run is settled by measurement, like inside a context, but through the
+    # whole pipeline: the persistent decode kernel needs every CU of its device at once, RCCL's send / recv kernels hold CUs
+    # while they wait for a peer, and two persistent kernels on one GPU (ranks sharing a device in smoke runs) starve each
+    # other (measured: 39 instead of 5500 tokens/s on the small test model). Both variants are built, a few tokens go through
+    # each, every rank votes with the slowest rank's time, and the loser is freed.
+    try_mega = os.environ.get("RWKV_MI_PIPELINE_MEGA", "1") == "1"
+
+    def build(no_mega: bool):
+        if no_mega:
+            os.environ["RWKV_MI_NO_MEGA"] = "1"
+        else:
+            os.environ.pop("RWKV_MI_NO_MEGA", None)
+        e = LibStageExecutor(lib, path, lb, le, spec.n_layer)
+        return e, [e.new_stream() for _ in range(world)]
+
+    ex, handles = build(no_mega=True)
     first = [(1103515245 * (j + 1)) % spec.n_vocab for j in range(world)]
 
     def sync():
@@ -261,8 +273,35 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
         torch.cuda.synchronize()
 
     red_dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
-    handles = [ex.new_stream() for _ in range(world)]
     fb = dist.new_group(list(range(world)))   # own communicator (and stream) for the token feedback
+
+    def probe(e, hs):
+        for h in hs:
+            e.reset(h)
+        run_pipeline(e, dist, rank, world, first, 2, handles=hs, sync=sync, fb_group=fb)
+        _, el = run_pipeline(e, dist, rank, world, first, 6, handles=hs, sync=sync, fb_group=fb)
+        bad = 0.0 if all(e.healthy(h) for h in hs) else 1e9
+        t = torch.tensor([el + bad], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    path_used = "per-layer launches"
+    if try_mega:
+        ex2, handles2 = build(no_mega=False)
+        any_mega = torch.tensor([1.0 if any(lib.library.rwkv_mi_decode_path(h) == 2 for h in handles2) else 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(any_mega, op=dist.ReduceOp.MAX)
+        if float(any_mega.item()) > 0.5:
+            t_plain, t_mega = probe(ex, handles), probe(ex2, handles2)
+            if t_mega < 0.97 * t_plain:
+                ex.close()
+                ex, handles = ex2, handles2
+                path_used = "persistent kernel (%.2f vs %.2f ms per step in the probe)" % (t_mega / 6 * 1e3, t_plain / 6 * 1e3)
+            else:
+                ex2.close()
+                path_used = "per-layer launches (%.2f vs %.2f ms per step with the persistent kernel in the probe)" % (t_plain / 6 * 1e3, t_mega / 6 * 1e3)
+        else:
+            ex2.close()
+    os.environ.pop("RWKV_MI_NO_MEGA", None)
 
     def timed(streams, steps, warmup):
         hs = handles[:len(streams)]
@@ -286,7 +325,7 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
         "dtype": "int8 x int4 dot, f32 accumulate (Q4_0 weights, Q8_0 activations); f16 head", "data": "synthetic",
         "config": {"workload": f"{spec.name} {args.dtype} greedy decode, layer pipeline over RCCL send/recv, {world} independent decode "
                                f"streams in flight (one step = one token on every stream), state resident in HBM",
-                   "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": f"pp{world}", "stage_layers": ranges},
+                   "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": f"pp{world}", "stage_layers": ranges, "stage_decode_path": path_used},
         "single_stream": {"tokens_per_s": args.steps / single, "ms_per_token": single * 1e3 / args.steps,
                           "note": "one stream through the same pipeline: layers are sequential, so this cannot exceed the 1-GPU rate"},
         "hbm": {"algorithmic_bytes_per_token": int(bpt.item()), "achieved_GBps_aggregate": bpt.item() * total_tok_s / 1e9},

@@ -108,6 +108,8 @@ class RWKVSharedLibrary:
         L.rwkv_mi_set_graph_enabled.restype = None
         L.rwkv_mi_decode_path.argtypes = [c_ctx]
         L.rwkv_mi_decode_path.restype = ctypes.c_int
+        L.rwkv_mi_decode_healthy.argtypes = [c_ctx]
+        L.rwkv_mi_decode_healthy.restype = ctypes.c_bool
 
     # --- rwkv.h ---------------------------------------------------------------------------------------------
 
