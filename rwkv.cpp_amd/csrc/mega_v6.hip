@@ -149,18 +149,33 @@ __device__ __forceinline__ void tq_store_block(xrsrc xr, int base, int blk, int 
     else tg_store(xr, base + 3 * blk + 2, (unsigned) g0, (unsigned) g1, f16_bits(d16) | (f16_bits(s16) << 16), (unsigned) isum & 0xFFFFu, tag);
 }
 
+// Staging of a quantised vector into its lohi image in LDS, lanes 0..63 of ONE wave owning units lane, lane + 64, ...
+// Unit i = 3 b + k carries dwords j = 3 k + t (t = 0, 1, 2) of block b; j < 4 lands in the lo plane, 4 <= j < 8 in the hi
+// plane, j = 8 is the fp16 pair. 64 = 3 * 21 + 1, so (b, k) of slot u follow from (lane / 3, lane % 3) without a division
+// per unit. (The first version divided, branched three ways per unit and cost ~1300 instructions for the F-vector -- on
+// the one wave every other wave of the workgroup is waiting for.)
 template <int MAXU, int NT>
 __device__ __forceinline__ void stage_qvec(Poll & pl, xrsrc xr, int src, int K, unsigned tag, unsigned char * l, int tid) {
+    static_assert(NT == 64, "stage_qvec: one wave");
     const int nb = K / 32;
     const QVec q = qvec_at(l, K);
-    unsigned * lo = reinterpret_cast<unsigned *>(l);
-    unsigned * hi = reinterpret_cast<unsigned *>(l + nb * 16);
+    unsigned * img = reinterpret_cast<unsigned *>(l);
+    const int b0 = tid / 3, k0 = tid - 3 * b0;
     poll_units<MAXU, NT>(pl, xr, src, 3 * nb, tag, tid, [&](int i, const v4u & v) {
-        const int b = i / 3, k = i - 3 * b;
-        if (k == 0) { lo[b * 4 + 0] = v.x; lo[b * 4 + 1] = v.y; lo[b * 4 + 2] = v.z; }
-        else if (k == 1) { lo[b * 4 + 3] = v.x; hi[b * 4 + 0] = v.y; hi[b * 4 + 1] = v.z; }
-        else {
-            hi[b * 4 + 2] = v.x; hi[b * 4 + 3] = v.y;
+        const int u = (i - tid) >> 6;              // slot (compile-time after unrolling)
+        const int kk = k0 + u % 3;                  // 0..4
+        const int k = kk >= 3 ? kk - 3 : kk;
+        const int b = b0 + 21 * u + u / 3 + (kk >= 3 ? 1 : 0);
+        const int j0 = 3 * k;                       // dword index of v.x within the block's eight code dwords
+        const int a0 = (j0 < 4 ? 0 : 4 * nb) + 4 * b + (j0 & 3);
+        const int j1 = j0 + 1;
+        const int a1 = (j1 < 4 ? 0 : 4 * nb) + 4 * b + (j1 & 3);
+        img[a0] = v.x;
+        img[a1] = v.y;
+        if (k < 2) {
+            const int j2 = j0 + 2;
+            img[(j2 < 4 ? 0 : 4 * nb) + 4 * b + (j2 & 3)] = v.z;
+        } else {
             q.d[b] = h2f_bits((uint16_t) (v.z & 0xFFFFu)); q.s[b] = h2f_bits((uint16_t) (v.z >> 16));
             q.isum[b] = (int) (short) (v.w >> 16);
         }
@@ -591,14 +606,24 @@ struct K6 {
                     const bool has = q == 0 ? blk < NCH : b_chunk2 >= 0;
                     if (has) {
                         const float * tlf = l.tl + bf[q] * R;
-                        // R is 32 or 64: two straight-line halves. (A per-term `if (m < R)` compiled into 64 basic blocks, each
-                        // waiting for its own LDS read: 4 us per chunk instead of 0.5.)
+                        // R is 32 or 64: two straight-line halves, each reading its 32 tl values as eight 16-byte LDS loads up
+                        // front. (A per-term `if (m < R)` compiled into 64 basic blocks, and a per-term scalar LDS read into 64
+                        // separate waits on the LDS counter: 4 us and 1.7 us per chunk instead of 0.5.)
+                        const float4 * tl4 = reinterpret_cast<const float4 *>(tlf);
                         float acc = 0.0f;
+                        {
+                            float4 t4[8];
 #pragma unroll
-                        for (int m = 0; m < 32; m++) acc += (&wB4[q][m >> 2].x)[m & 3] * tlf[m];
+                            for (int j = 0; j < 8; j++) t4[j] = tl4[j];
+#pragma unroll
+                            for (int m = 0; m < 32; m++) acc += (&wB4[q][m >> 2].x)[m & 3] * (&t4[m >> 2].x)[m & 3];
+                        }
                         if (R > 32) {
+                            float4 t4[8];
 #pragma unroll
-                            for (int m = 32; m < 64; m++) acc += (&wB4[q][m >> 2].x)[m & 3] * tlf[m];
+                            for (int j = 0; j < 8; j++) t4[j] = tl4[8 + j];
+#pragma unroll
+                            for (int m = 0; m < 32; m++) acc += (&wB4[q][8 + (m >> 2)].x)[m & 3] * (&t4[m >> 2].x)[m & 3];
                         }
                         const float mm = (acc + wBmaa[q]) * l.sx[bd[q]];
                         const float o = mm + l.xn[bd[q]];
@@ -685,13 +710,19 @@ struct K6 {
                 float o = 0.0f;
                 float * so = sout_l + 2 * D + (long long) d_head * S * S;
 #pragma unroll
-                for (int i = 0; i < S; i++) {
-                    const float4 b4 = bc[i];
-                    const float kv = vj * b4.x;
-                    const float prev = s[i];
-                    const float temp = kv * b4.y + prev;
-                    o += temp * b4.z;
-                    so[i * S + lane] = prev * b4.w + kv;
+                for (int i0 = 0; i0 < S; i0 += 8) {
+                    float4 b8[8];   // eight broadcast reads in flight, not one LDS round trip per step
+#pragma unroll
+                    for (int u = 0; u < 8; u++) b8[u] = bc[i0 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int i = i0 + u;
+                        const float kv = vj * b8[u].x;
+                        const float prev = s[i];
+                        const float temp = kv * b8[u].y + prev;
+                        o += temp * b8[u].z;
+                        so[i * S + lane] = prev * b8[u].w + kv;
+                    }
                 }
                 // 4. GroupNorm over the head, * ln_x, gate
                 const float mean = (float) (wave_sum_d((double) o) / (double) S);
