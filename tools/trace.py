@@ -40,5 +40,9 @@ for name,(ws,k) in (('tl stored',(W,17)),('act5 stored',([0],19)),('rkvg stored'
     byx=[rel[x::8].mean() for x in range(8)]
     late=np.argsort(-rel)[:5]
     print('%-13s spread %.2f us; mean lateness by XCD %s; latest workgroups %s'%(name,rel.max(),' '.join('%.2f'%v for v in byx),' '.join('%d(%.2f)'%(b,rel[b]) for b in late)))
+# is the comm wave (wave 0: also the eighth row owner) the straggler of the row phases?
+for name,k in (('rkvg stored',21),('x_att stored',24),('x_ffn stored',28)):
+    rel=(R[:,:,k]-R[:,:,k].min())/100
+    print('%-13s mean lateness by wave: %s'%(name,' '.join('%.2f'%rel[:,w].mean() for w in range(8))))
 print('layer wall (xffn stored, max over all) - (x staged A, min): %.2f us'%((max(R[:,w,28].max() for w in range(8))-R[:,0,17].min())/100))
 sys.stdout.flush(); os._exit(0)
