@@ -95,3 +95,26 @@ def test_mega_stages_reproduce_full_model(tmp_path):
     for s in stages:
         s.close()
     full.free()
+
+
+def test_mega_health_and_trace(tmp_path):
+    """rwkv_mi_decode_healthy stays true over ordinary use; rwkv_mi_trace_phases returns monotonic stamps per wave."""
+    import ctypes
+    lib = library()
+    p = str(tmp_path / "m.bin")
+    synth.write_model(p, synth.CONFIGS["mega-v6-2048"], "Q4_0", seed=3)
+    m = model(p)
+    assert m.decode_path() == 2
+    m.state_load(None)
+    m.decode_greedy(3, 8)
+    L = lib.library
+    assert L.rwkv_mi_decode_healthy(m._ctx.ptr)
+    L.rwkv_mi_trace_phases.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.rwkv_mi_trace_phases.restype = ctypes.c_bool
+    out = np.zeros(256 * 8 * 32, dtype=np.int64)
+    assert L.rwkv_mi_trace_phases(m._ctx.ptr, 5, 1, 2, out.ctypes.data)
+    t = out.reshape(256, 8, 32)
+    assert (np.diff(t[:, 1:, :17], axis=2) >= 0).all() and (t[:, 1:, 16] > t[:, 1:, 0]).all()   # worker shader-clock stamps
+    assert (np.diff(t[:, 0, :13], axis=1) >= 0).all()                                              # comm wave
+    assert L.rwkv_mi_decode_healthy(m._ctx.ptr)
+    m.free()
