@@ -53,10 +53,10 @@ __global__ __launch_bounds__(1024) void k6_att_prep(P6A p) {
     __syncthreads();
     double sacc = 0.0;
     if (pro) sacc = ln_partial_sum(l_row, D);
-    const float mean = (float)(block_sum_d_8w(sacc, red) / (double) D);
+    const float mean = (float)(block_sum_d_1b(sacc, red) / (double) D);
     double s2 = 0.0;
     if (pro) s2 = ln_partial_var(l_row, D, mean);
-    const float var = (float)(block_sum_d_8w(s2, red) / (double) D);
+    const float var = (float)(block_sum_d_1b(s2, red + 256) / (double) D);
     const float scale = 1.0f / sqrtf(var + 1e-5f);
     // elementwise + quantise: every thread, 4 independent element steps interleaved
     auto fin = [&](int64_t i, float lw, float lb, float pv, float mx) -> float {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
     unsigned char * l_k = smem + D * 4;
     unsigned char * l_r = l_k + qb;
     double * red = reinterpret_cast<double *>(l_r + qb);
-    float * l_out = reinterpret_cast<float *>(red + 258);
+    float * l_out = reinterpret_cast<float *>(red + 512);
     const QVec qk = qvec_at(l_k, D), qr = qvec_at(l_r, D);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool pro = threadIdx.x < 256;
@@ -345,10 +345,10 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
     __syncthreads();
     double sacc = 0.0;
     if (pro) sacc = ln_partial_sum(l_row, D);
-    const float mean = (float)(block_sum_d_8w(sacc, red) / (double) D);
+    const float mean = (float)(block_sum_d_1b(sacc, red) / (double) D);
     double s2 = 0.0;
     if (pro) s2 = ln_partial_var(l_row, D, mean);
-    const float var = (float)(block_sum_d_8w(s2, red) / (double) D);
+    const float var = (float)(block_sum_d_1b(s2, red + 256) / (double) D);
     const float scale = 1.0f / sqrtf(var + 1e-5f);
     auto fin = [&](int64_t i, float lw, float lb, float pv, float mk, float mr, float & xk, float & xr) {
         const float y = l_row[i] * scale;
@@ -490,7 +490,7 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
 
     const int gridA = (int) ((R5 + 3) / 4);
     P6A a{x, f(L.ln1_w), f(L.ln1_b), sin + D, f(L.att_time_maa_x), sout + D, s.xn, s.sx, planes(L.att_time_maa_w1), R5, s.tl, D};
-    launch6(pf, 0, k6_att_prep<FMT>, dim3((unsigned) gridA), dim3(1024), (size_t) D * 4 + qbD + 257 * 8, st, a);
+    launch6(pf, 0, k6_att_prep<FMT>, dim3((unsigned) gridA), dim3(1024), (size_t) D * 4 + qbD + 512 * 8, st, a);
 
     P6B b{f(L.att_time_maa_w2), s.tl, {f(L.att_time_maa_w), f(L.att_time_maa_k), f(L.att_time_maa_v), f(L.att_time_maa_r), f(L.att_time_maa_g)},
           s.sx, s.xn, s.act5, D, R, s.act_stride};
@@ -514,7 +514,7 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
     const int gpb = (int) ((groups + 255) / 256) < 3 ? (int) ((groups + 255) / 256) : 3;   // ~one workgroup per CU: the prologue runs once per CU
     P6F ff{x, f(L.ln2_w), f(L.ln2_b), sin, f(L.ffn_time_maa_k), f(L.ffn_time_maa_r), sout, planes(L.ffn_key), planes(L.ffn_receptance), s.kq, s.rr, D, F, gpb};
     launch6(pf, L.ffn_key->nbytes + L.ffn_receptance->nbytes + D * 12 + qvec_bytes(F) + D * 4, k6_ffn_kr<FMT>, dim3((unsigned) ((groups + gpb - 1) / gpb)), dim3(512),
-            (size_t) D * 4 + 2 * qbD + 258 * 8 + (size_t) gpb * 32 * 4, st, ff);
+            (size_t) D * 4 + 2 * qbD + 512 * 8 + (size_t) gpb * 32 * 4, st, ff);
 
     P6E g{planes(L.ffn_value), s.kq, x, s.rr, D, F};
     launch6(pf, L.ffn_value->nbytes + qvec_bytes(F) + D * 12, k6_proj_res<FMT, 4, 4, true>, dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);

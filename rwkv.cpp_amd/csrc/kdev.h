@@ -209,6 +209,17 @@ __device__ __forceinline__ double block_sum_d_8w(double v, double * red /* [257]
     return red[256];
 }
 
+// The same tree with ONE workgroup barrier: the caller passes a scratch array of 256 doubles that no wave can still be
+// reading (a different array per reduction of a kernel), and every wave folds the 256 partials itself -- identical additions
+// in identical order in every wave -- instead of waiting for wave 0 to publish the total. Any workgroup size >= 256.
+__device__ __forceinline__ double block_sum_d_1b(double v, double * red /* [256], fresh */) {
+    if (threadIdx.x < 256) red[threadIdx.x] = v;
+    __syncthreads();
+    const int i = threadIdx.x & 63;
+    const double t = (red[i] + red[i + 128]) + (red[i + 64] + red[i + 192]);
+    return wave_sum_d(t);
+}
+
 __device__ __forceinline__ float apply_epi(const Epi & e, float acc, int64_t t, int64_t n, int64_t ldy) {
     switch (e.op) {
         case EPI_NONE: return acc;

@@ -303,18 +303,8 @@ struct K6 {
     struct PF { float4 lw[V4], lb[V4], pv[V4], mk[V4], mr[V4]; };
 
     // LayerNorm statistics of the row in l.x (256 partials, threads 0..255); leaves x - mean in l.x
-    // The tree of block_sum_d_8w (kdev.h) with ONE workgroup barrier instead of three: the two sums of a prologue use two
-    // scratch arrays (several barriers lie between two prologues, so neither can still be in use when it is written again),
-    // and every wave folds the 256 partials itself -- the same additions in the same order in all eight waves -- instead of
-    // waiting for wave 0 to publish the total. A workgroup barrier costs ~0.5 us here (the waves arrive unevenly): 8 fewer
-    // per layer were worth 8 %.
-    static __device__ __forceinline__ double block_sum_fresh(double v, double * red, int tid) {
-        if (tid < 256) red[tid] = v;
-        __syncthreads();
-        const int i = tid & 63;
-        const double t = (red[i] + red[i + 128]) + (red[i + 64] + red[i + 192]);
-        return wave_sum_d(t);
-    }
+    // block_sum_d_1b (kdev.h): ONE workgroup barrier per reduction instead of three. A workgroup barrier costs ~0.5 us here
+    // (the eight waves arrive unevenly): 8 fewer per layer were worth 4 %.
     static __device__ __forceinline__ float ln_stats(const Lds & l, int tid) {
         // Thread t < 256 owns the partial over elements t, t + 256, ... (summed in that order). The D / 256 values are read
         // into registers in one batch: as a rolled loop every iteration waited for its own LDS read (~130 cycles x 16 x 2).
@@ -330,13 +320,13 @@ struct K6 {
 #pragma unroll
             for (int j = 0; j < NP; j++) sacc += (double) xv[j];
         }
-        const float mean = (float) (block_sum_fresh(sacc, l.red, tid) / (double) D);
+        const float mean = (float) (block_sum_d_1b(sacc, l.red) / (double) D);
         double s2 = 0.0;
         if (pro) {
 #pragma unroll
             for (int j = 0; j < NP; j++) { const float v = xv[j] - mean; l.x[tid + 256 * j] = v; s2 += (double) (v * v); }
         }
-        const float var = (float) (block_sum_fresh(s2, l.red + 256, tid) / (double) D);
+        const float var = (float) (block_sum_d_1b(s2, l.red + 256) / (double) D);
         return 1.0f / sqrtf(var + 1e-5f);
     }
 
