@@ -23,6 +23,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 MFMA = 2x the bf16 rate (MI355X_MICROARCH.md: bf16 ~2.5 PF dense, I8 >= 3944 TOPS measured)
+MFMA_F16_PEAK_TOPS = 2500.0
 
 
 def pmc_traffic(path_id, args):
@@ -52,6 +54,11 @@ def parse_args():
     ap.add_argument("--model-dir", default=os.environ.get("RWKV_BENCH_DIR", "/tmp"))
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline leg (0 disables it)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event pass")
+    ap.add_argument("--mode", default="decode", choices=["decode", "prefill"],
+                    help="decode: BASELINE.json's headline metric (default). prefill: rwkv_eval_sequence over --seq-len tokens (BASELINE config 3)")
+    ap.add_argument("--seq-len", type=int, default=1024)
+    ap.add_argument("--parity-tokens", type=int, default=64, help="greedy tokens compared GPU vs CPU oracle on the benchmarked file (0 disables)")
+    ap.add_argument("--abi-tokens", type=int, default=24, help="tokens timed through the unmodified rwkv_eval ABI (host state in/out every call; 0 disables)")
     return ap.parse_args()
 
 
@@ -82,9 +89,38 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
+DTYPE_DESC = {
+    "Q4_0": "int8 x int4 dot, f32 accumulate (Q4_0 weights, Q8_0 activations); f16 head",
+    "Q4_1": "int8 x uint4 dot, f32 accumulate (Q4_1 weights, Q8_1 activations); f16 head",
+    "Q5_0": "int8 x int5 dot, f32 accumulate (Q5_0 weights, Q8_0 activations); f16 head",
+    "Q5_1": "int8 x uint5 dot, f32 accumulate (Q5_1 weights, Q8_1 activations); f16 head",
+    "Q8_0": "int8 x int8 dot, f32 accumulate (Q8_0 weights, Q8_0 activations); f16 head",
+    "FP16": "f16 weights x f16-rounded activations, f32 accumulate",
+    "FP32": "f32",
+}
+
+
+def abi_rate(model, first_token, n):
+    """Tokens/s through the UNMODIFIED reference ABI: rwkv_eval with the state handed in and out through host memory on every
+    call (rwkv_eval.inc:2-22) plus the logits download -- what a caller that does not know the rwkv_mi_* extensions sees."""
+    import numpy as np
+    state = model.init_state()
+    logits = np.empty(model.n_vocab, dtype=np.float32)
+    tok = first_token
+    model.eval(tok, state, state, logits)  # warm
+    tok = int(np.argmax(logits))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        model.eval(tok, state, state, logits)
+        tok = int(np.argmax(logits))
+    dt = time.perf_counter() - t0
+    return {"tokens_per_s": n / dt, "ms_per_token": dt * 1e3 / n, "tokens": n,
+            "note": "rwkv_eval(ctx, token, state, state, logits): host state in + out and logits out on every call, numpy argmax on the host"}
+
+
 def cpu_baseline(path, first_token, budget_s):
     """Times the CPU oracle (oracle/rwkv_oracle.c: ggml's CPU algorithm restated, OpenMP) on the same file and the same
-    greedy decode. Bounded sample; reported, never the target."""
+    greedy decode. Bounded sample; reported, never the target. The greedy tokens are kept: main() compares them with the GPU's."""
     import numpy as np
     import oracle_lib
     cores = usable_cores()
@@ -94,16 +130,143 @@ def cpu_baseline(path, first_token, budget_s):
     load_s = time.time() - t0
     state = om.init_state()
     tok, n, t_start = first_token, 0, time.time()
+    toks = []
     while True:
         logits, state = om.eval(tok, state)
         tok = int(np.argmax(logits))
+        toks.append(tok)
         n += 1
         el = time.time() - t_start
         if n >= 2 and (el + el / n > budget_s or n >= 64):
             break
     om.free()
     return {"value": n / el, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{n} greedy decode tokens of the same model file on the host CPU ({el:.1f}s, load {load_s:.1f}s)"}
+            "sample": f"{n} greedy decode tokens of the same model file on the host CPU ({el:.1f}s, load {load_s:.1f}s)"}, toks
+
+
+KERNEL_NAMES = {2: "k6_mega (persistent decode kernel: all layers of the stage in one launch)",
+                1: "fused single-token layer kernels (quantised row phases)",
+                0: "k_mvq_t1 (quantised single-token projection)"}
+
+
+def bench_decode(args, pkg, lib, path, spec, torch):
+    """One step = one decoded token (embedding row, every layer, ln_out, head, on-device argmax), state resident in HBM."""
+    import numpy as np
+    t0 = time.time()
+    model = pkg.RWKVModel(lib, path, thread_count=1, gpu_layer_count=spec.n_layer + 1)
+    load_s = time.time() - t0
+    bpt = model.bytes_per_token()
+    first = 1103515245 % spec.n_vocab
+    model.state_load(None)
+    if args.warmup > 0:
+        model.decode_greedy(first, args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks, ev_ms = model.decode_greedy(first, args.steps)
+    torch.cuda.synchronize()
+    wall_s = time.perf_counter() - t0
+    tok_s = args.steps / wall_s
+    path_id = model.decode_path()
+    result = {
+        "metric": "tokens/sec single-stream decode", "value": tok_s, "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall_s * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": DTYPE_DESC.get(args.dtype, args.dtype), "data": "synthetic",
+        "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode, state resident in HBM", "layers": spec.n_layer,
+                   "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": "1 GPU", "decode_path": path_id},
+        "hbm": {"algorithmic_bytes_per_token": bpt, "achieved_GBps": bpt * tok_s / 1e9, "frac_of_8TBps": bpt * tok_s / 1e9 / HBM_PEAK_GBS,
+                "hip_event_ms_per_token": ev_ms / args.steps},
+        "load_seconds": load_s,
+    }
+    if not args.no_profile:
+        p = model.profile_decode(first, min(args.steps, 32))
+        if p["launches"] > 0:
+            ach = p["bytes"] / max(p["kernel_ms"], 1e-9) / 1e6
+            traffic, traffic_src = pmc_traffic(path_id, args)
+            result["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAMES[path_id] + f" [{args.dtype}]", "achieved": ach,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                                  "launches": p["launches"], "avg_launch_us": p["kernel_ms"] * 1e3 / p["launches"],
+                                  "avg_bytes_per_launch": p["bytes"] / p["launches"]}
+    # GPU tokens for the parity leg: a fresh state, and -- on the persistent path -- the rolling hand-over tag preset so that
+    # the compared tokens cross its 16-bit wrap (it advances 8 per layer: every 256 tokens at 32 layers).
+    gpu_toks, wrap = None, False
+    if args.parity_tokens > 0 and args.cpu_seconds > 0:
+        if path_id == 2:
+            wrap = model.test_set_tag(0x10000 - 8 * spec.n_layer * (args.parity_tokens // 4))
+        model.state_load(None)
+        gpu_toks, _ = model.decode_greedy(first, args.parity_tokens)
+        healthy = model.healthy()
+    if args.abi_tokens > 0:
+        result["abi"] = abi_rate(model, first, args.abi_tokens)
+    model.free()
+    if args.cpu_seconds > 0:
+        result["cpu_baseline"], cpu_toks = cpu_baseline(path, first, args.cpu_seconds)
+        if gpu_toks is not None:
+            n = min(len(cpu_toks), len(gpu_toks))
+            equal = bool(n > 0 and list(gpu_toks[:n]) == list(cpu_toks[:n]) and healthy)
+            result["parity"] = {"tokens_checked": n, "equal": equal, "crosses_tag_wrap": bool(wrap and n > args.parity_tokens // 4),
+                                "what": "greedy tokens of rwkv_mi_decode_greedy on this file vs the CPU oracle's from the same first token and a fresh state"}
+            if not equal:
+                print(json.dumps(result))
+                raise SystemExit(f"[bench] PARITY FAILURE: GPU greedy tokens differ from the CPU oracle's within the first {n} tokens")
+    return result
+
+
+def bench_prefill(args, pkg, lib, path, spec, torch):
+    """One step = one rwkv_eval_sequence pass over --seq-len prompt tokens (BASELINE config 3: the prefill GEMMs), state resident."""
+    import numpy as np
+    t0 = time.time()
+    model = pkg.RWKVModel(lib, path, thread_count=1, gpu_layer_count=spec.n_layer + 1)
+    load_s = time.time() - t0
+    T = args.seq_len
+    prompt = [int((1103515245 * i + 12345) % spec.n_vocab) for i in range(T)]
+    model.state_load(None)
+    for _ in range(max(1, args.warmup)):
+        model.eval_resident(prompt, want_logits=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = model.eval_resident(prompt, want_logits=True)
+    torch.cuda.synchronize()
+    wall_s = time.perf_counter() - t0
+    tok_s = args.steps * T / wall_s
+    flops = model.prefill_flops(T)
+    result = {
+        "metric": "tokens/sec prefill (rwkv_eval_sequence)", "value": tok_s, "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall_s * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": DTYPE_DESC.get(args.dtype, args.dtype), "data": "synthetic",
+        "config": {"workload": f"{spec.name} {args.dtype} prefill of {T} tokens per pass (rwkv_mi_eval_resident = rwkv_eval_sequence with the state resident)",
+                   "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "seq_len": T, "parallelism": "1 GPU"},
+        "load_seconds": load_s,
+    }
+    peak = MFMA_I8_PEAK_TOPS if args.dtype.startswith("Q") else MFMA_F16_PEAK_TOPS
+    result["roofline"] = {"bound": "mfma", "kernel": "quantised projection GEMMs of the sequence pass", "achieved": flops * args.steps / wall_s / 1e12, "peak": peak,
+                          "unit": "TFLOP/s" if not args.dtype.startswith("Q") else "TOP/s (int8)", "frac": flops * args.steps / wall_s / 1e12 / peak,
+                          "traffic": None, "flops_per_pass": flops,
+                          "note": "whole-pass rate: 2*T*sum(2-D layer weights) + 2*V*D over the wall time of the pass (WKV, LayerNorm, mixes included in the time)"}
+    prof = model.profile_prefill(prompt) if hasattr(model, "profile_prefill") else None
+    if prof:
+        result["roofline"].update(prof)
+    if args.parity_tokens > 0 and args.cpu_seconds > 0:
+        import oracle_lib
+        oracle_lib.lib().orc_set_threads(usable_cores())
+        om = oracle_lib.OracleModel(path)
+        n = min(T, 48)
+        t0 = time.time()
+        ol, ost = om.eval_sequence(prompt[:n], om.init_state())
+        cpu_s = time.time() - t0
+        om.free()
+        model.state_load(None)
+        gl = model.eval_resident(prompt[:n], want_logits=True)
+        gst = model.state_store()
+        equal = bool(np.array_equal(gl, ol) and np.array_equal(gst, ost))
+        result["parity"] = {"tokens_checked": n, "equal": equal, "what": "logits and state after the first tokens of the prompt, GPU sequence pass vs CPU oracle, bit for bit"}
+        result["cpu_baseline"] = {"value": n / cpu_s, "unit": "tokens/s", "cores": usable_cores(), "kind": "port",
+                                  "sample": f"{n}-token sequence pass of the same file on the host CPU ({cpu_s:.1f}s)"}
+        if not equal:
+            print(json.dumps(result))
+            raise SystemExit("[bench] PARITY FAILURE: GPU sequence pass differs from the CPU oracle")
+    model.free()
+    return result
 
 
 def main():
@@ -140,46 +303,10 @@ def main():
     if world > 1:
         from rwkv_cpp_amd import pipeline  # layer pipeline over RCCL send/recv
         result = pipeline.bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world)
+    elif args.mode == "prefill":
+        result = bench_prefill(args, pkg, lib, path, spec, torch)
     else:
-        t0 = time.time()
-        model = pkg.RWKVModel(lib, path, thread_count=1, gpu_layer_count=spec.n_layer + 1)
-        load_s = time.time() - t0
-        bpt = model.bytes_per_token()
-        first = 1103515245 % spec.n_vocab
-        model.state_load(None)
-        if args.warmup > 0:
-            model.decode_greedy(first, args.warmup)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        toks, ev_ms = model.decode_greedy(first, args.steps)
-        torch.cuda.synchronize()
-        wall_s = time.perf_counter() - t0
-        tok_s = args.steps / wall_s
-        result = {
-            "metric": "tokens/sec single-stream decode", "value": tok_s, "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall_s * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "int8 x int4 dot, f32 accumulate (Q4_0 weights, Q8_0 activations); f16 head", "data": "synthetic",
-            "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode, state resident in HBM", "layers": spec.n_layer,
-                       "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": "1 GPU"},
-            "hbm": {"algorithmic_bytes_per_token": bpt, "achieved_GBps": bpt * tok_s / 1e9, "frac_of_8TBps": bpt * tok_s / 1e9 / HBM_PEAK_GBS,
-                    "hip_event_ms_per_token": ev_ms / args.steps},
-            "load_seconds": load_s,
-        }
-        if not args.no_profile:
-            path_id = model.decode_path()
-            p = model.profile_decode(first, min(args.steps, 32))
-            ach = p["bytes"] / max(p["kernel_ms"], 1e-9) / 1e6
-            kname = {2: "k6_mega (persistent decode kernel: all layers of the stage in one launch)",
-                     1: "quantised single-token projection kernels: k6_rkvgw, k6_proj_res, k6_ffn_kr",
-                     0: "k_mvq_t1 (quantised single-token projection)"}[path_id] + f" [{args.dtype}]"
-            traffic, traffic_src = pmc_traffic(path_id, args)
-            result["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                                  "launches": p["launches"], "avg_launch_us": p["kernel_ms"] * 1e3 / p["launches"],
-                                  "avg_bytes_per_launch": p["bytes"] / p["launches"]}
-        model.free()
-        if args.cpu_seconds > 0:
-            result["cpu_baseline"] = cpu_baseline(path, first, args.cpu_seconds)
+        result = bench_decode(args, pkg, lib, path, spec, torch)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

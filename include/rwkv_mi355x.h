@@ -39,6 +39,8 @@ RWKV_API bool rwkv_mi_profile_decode(struct rwkv_context * ctx, uint32_t first_t
  * embedding row, state read + write, logits write. */
 RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx);
 RWKV_API uint64_t rwkv_mi_weight_bytes(const struct rwkv_context * ctx);
+/* Arithmetic of one rwkv_eval_sequence pass over n_tokens: 2 * n_tokens * (elements of every 2-D layer matrix) + 2 * n_vocab * n_embed. */
+RWKV_API uint64_t rwkv_mi_prefill_flops(const struct rwkv_context * ctx, size_t n_tokens);
 
 /* Detected architecture (4, 5.1, 5.2, 6, 7) and head geometry. Any pointer may be NULL. */
 RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major, uint32_t * minor, uint32_t * head_count, uint32_t * head_size);
@@ -80,6 +82,10 @@ RWKV_API bool rwkv_mi_stage_step(struct rwkv_context * ctx, const uint32_t * d_t
 RWKV_API bool rwkv_mi_logits_store(struct rwkv_context * ctx, float * logits_out);
 /* Device pointer of the context's logits (n_vocab floats), valid after a step that produced logits. */
 RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx);
+
+/* Test hook (used by tests/ and bench.py's parity leg only): presets the rolling hand-over tag of decode path 2 (the kernel
+ * compares its low 16 bits; it advances by 8 per layer), so that a short run crosses the 16-bit wrap. false if path 2 is off. */
+RWKV_API bool rwkv_mi_test_set_tag(struct rwkv_context * ctx, uint32_t base);
 
 /* Test hook (used by tests/ only): the activation quantiser; n multiple of 32; d, s, isum have n/32 entries. */
 RWKV_API bool rwkv_mi_test_quantize_act(const float * x, int64_t n, int8_t * q, float * d, float * s, int32_t * isum);

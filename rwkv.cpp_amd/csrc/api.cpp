@@ -51,12 +51,23 @@ static bool run_tokens(rwkv_context * ctx, const uint32_t * tokens, size_t n, bo
     return true;
 }
 
-static bool fetch_outputs(rwkv_context * ctx, float * state_out, float * logits_out) {
+static const char * k_abort_msg = "persistent decode kernel timed out waiting for a workgroup (is the GPU shared with another process?); "
+                                  "the context continues on the per-layer launches";
+
+// Copies the requested outputs and drains the stream. *aborted (when given) reports a poll time-out of the persistent kernel
+// since the last check instead of failing: the caller repeats the step on the per-layer path (rwkv_eval). The abort word
+// travels with the other copies through a pinned mirror, no extra device round trip.
+static bool fetch_outputs(rwkv_context * ctx, float * state_out, float * logits_out, bool * aborted = nullptr) {
+    if (aborted) *aborted = false;
     if (state_out && !state_to_host(ctx, state_out)) return false;
     if (logits_out) HIP_CTX_OK(ctx, hipMemcpyAsync(logits_out, ctx->d_logits, (size_t) ctx->model->n_vocab() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->mega) (void) mega_v6_ctl_fetch(ctx->mega, ctx->stream);
     HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
-    RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, !(ctx->mega && mega_v6_aborted(ctx->mega)),
-                 "persistent decode kernel timed out waiting for a workgroup (is the GPU shared with another process?)");
+    if (ctx->mega && mega_v6_aborted_cached(ctx->mega)) {
+        recover_from_abort(ctx);
+        if (aborted) { *aborted = true; return true; }
+        RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, false, "%s", k_abort_msg);
+    }
     return true;
 }
 
@@ -87,7 +98,16 @@ RWKV_API bool rwkv_eval(struct rwkv_context * ctx, const uint32_t token, const f
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     if (!state_from_host(ctx, state_in)) return false;
     if (!run_tokens(ctx, &token, 1, logits_out != nullptr)) return false;
-    return fetch_outputs(ctx, state_out, logits_out);
+    bool aborted = false;
+    if (!fetch_outputs(ctx, state_out, logits_out, &aborted)) return false;
+    if (aborted) {
+        // The persistent kernel gave up (device shared with another process' persistent kernel). It only writes the OTHER state
+        // buffer, so the input state is intact: flip back and repeat the token on the per-layer launches.
+        ctx->cur ^= 1;
+        if (!run_tokens(ctx, &token, 1, logits_out != nullptr)) return false;
+        return fetch_outputs(ctx, state_out, logits_out);
+    }
+    return true;
 }
 
 RWKV_API bool rwkv_eval_sequence(struct rwkv_context * ctx, const uint32_t * sequence, const size_t sequence_len,
@@ -238,8 +258,9 @@ RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_to
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, n_tokens > 0, "n_tokens is 0");
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     if (!upload_tokens(ctx, &first_token, 1)) return false;
-    uint32_t * d_hist = nullptr;
-    HIP_CTX_OK(ctx, hipMalloc((void **) &d_hist, n_tokens * sizeof(uint32_t)));
+    struct DevBuf { uint32_t * p = nullptr; ~DevBuf() { if (p) (void) hipFree(p); } } hist;   // freed on every exit
+    HIP_CTX_OK(ctx, hipMalloc((void **) &hist.p, n_tokens * sizeof(uint32_t)));
+    uint32_t * d_hist = hist.p;
     HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
     HIP_CTX_OK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     bool ok = true;
@@ -253,13 +274,10 @@ RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_to
     if (ok) {
         ok = hipEventRecord(ctx->ev1, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
         if (ok && elapsed_ms) ok = hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1) == hipSuccess;
-        if (ok && tokens_out) ok = hipMemcpy(tokens_out, d_hist, n_tokens * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok && tokens_out) ok = hipMemcpyAsync(tokens_out, d_hist, n_tokens * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
     }
-    (void) hipFree(d_hist);
     RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, ok, "greedy decode failed: %s", hipGetErrorString(hipGetLastError()));
-    RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, !(ctx->mega && mega_v6_aborted(ctx->mega)),
-                 "persistent decode kernel timed out waiting for a workgroup (is the GPU shared with another process?)");
-    return true;
+    return fetch_outputs(ctx, nullptr, nullptr);   // drains the stream; a poll time-out invalidates the whole run (state included)
 }
 
 // Eager (graph-free) greedy decode with a HIP-event pair around every launch of the dominant kernel.
@@ -298,6 +316,21 @@ RWKV_API bool rwkv_mi_profile_decode(struct rwkv_context * ctx, uint32_t first_t
 RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx) { return ctx->model->bytes_per_token; }
 RWKV_API uint64_t rwkv_mi_weight_bytes(const struct rwkv_context * ctx) { return ctx->model->weight_bytes; }
 
+// Arithmetic of one sequence pass over T tokens: 2 * T * (elements of every 2-D layer matrix) + 2 * V * D
+// (the head runs on the last token only). Embedding, vectors and the elementwise v7 r_k table are not matrices of the pass.
+RWKV_API uint64_t rwkv_mi_prefill_flops(const struct rwkv_context * ctx, size_t n_tokens) {
+    const Model & m = *ctx->model;
+    uint64_t w = 0;
+    for (const auto & t : m.tensors) {
+        if (t->ndim != 2 || t.get() == m.emb || t.get() == m.head) continue;
+        if (t->name.find("att.r_k") != std::string::npos) continue;
+        w += (uint64_t) t->ne[0] * (uint64_t) t->ne[1];
+    }
+    uint64_t f = 2ull * (uint64_t) n_tokens * w;
+    if (m.has_head && m.head) f += 2ull * (uint64_t) m.head->ne[0] * (uint64_t) m.head->ne[1];
+    return f;
+}
+
 RWKV_API void rwkv_mi_get_arch(const struct rwkv_context * ctx, uint32_t * major, uint32_t * minor, uint32_t * head_count, uint32_t * head_size) {
     if (major) *major = (uint32_t) ctx->model->arch_major;
     if (minor) *minor = (uint32_t) ctx->model->arch_minor;
@@ -309,7 +342,7 @@ RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled)
 
 RWKV_API bool rwkv_mi_decode_healthy(struct rwkv_context * ctx) {
     if (hipSetDevice(ctx->model->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
-    return !(ctx->mega && mega_v6_aborted(ctx->mega));
+    return !(ctx->mega && mega_v6_aborted(ctx->mega, ctx->stream));
 }
 
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx) { return ctx->mega ? 2 : (ctx->fused_v6 ? 1 : 0); }
@@ -397,6 +430,13 @@ RWKV_API bool rwkv_mi_trace_phases(struct rwkv_context * ctx, uint32_t token, in
     (void) hipStreamSynchronize(ctx->stream);
     ctx->use_graph = g;
     return ok && mega_v6_trace(ctx->mega, layer, out, true);
+}
+
+// Test hook: presets the persistent kernel's rolling 16-bit hand-over tag (e.g. a few tokens below its wrap).
+RWKV_API bool rwkv_mi_test_set_tag(struct rwkv_context * ctx, uint32_t base) {
+    if (!ctx->mega) return false;
+    if (hipSetDevice(ctx->model->device) != hipSuccess) return false;
+    return mega_v6_set_tag(ctx->mega, base, ctx->stream);
 }
 
 // Test hook: the activation quantiser (f32 -> Q8_0/Q8_1 blocks) on standalone buffers.

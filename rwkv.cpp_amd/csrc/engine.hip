@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstring>
+#include <mutex>
 
 namespace rwkvmi {
 
@@ -24,6 +25,48 @@ void ctx_fail(struct ::rwkv_context * ctx, int flags, const char * file, int lin
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The persistent decode kernel needs every CU of its device at once. Two contexts of one process (rwkv_clone_context: one
+// clone per thread, rwkv.h:64-68) launching it concurrently on their own streams could each become half resident and spin
+// until both time out. Launches are therefore chained per device: a context's launch waits (on the device, not the host) for
+// the completion event of the previous persistent launch of the process. Other processes cannot be seen from here: a poll
+// time-out is recovered from by dropping to the per-layer launches (recover_from_abort).
+// ---------------------------------------------------------------------------------------------------------------
+static std::mutex g_mega_mu;
+static constexpr int k_max_devices = 64;
+static hipEvent_t g_mega_last[k_max_devices] = {};
+static rwkv_context * g_mega_last_owner[k_max_devices] = {};
+static int g_mega_contexts[k_max_devices] = {};   // contexts of this process holding a persistent kernel, per device
+
+static int mega_chain_count(rwkv_context * ctx, int delta) {
+    std::lock_guard<std::mutex> lk(g_mega_mu);
+    const int dev = ctx->model->device;
+    if (dev < 0 || dev >= k_max_devices) return 0;
+    return g_mega_contexts[dev] += delta;
+}
+
+static void mega_chain_begin(rwkv_context * ctx) {
+    g_mega_mu.lock();
+    const int dev = ctx->model->device;
+    if (dev >= 0 && dev < k_max_devices && g_mega_last[dev] && g_mega_last_owner[dev] != ctx) (void) hipStreamWaitEvent(ctx->stream, g_mega_last[dev], 0);
+}
+static void mega_chain_end(rwkv_context * ctx) {
+    const int dev = ctx->model->device;
+    // (a single persistent context per device -- the usual case -- records nothing: no marker between graph replays)
+    if (dev >= 0 && dev < k_max_devices && g_mega_contexts[dev] > 1 && ctx->mega_done && hipEventRecord(ctx->mega_done, ctx->stream) == hipSuccess) {
+        g_mega_last[dev] = ctx->mega_done; g_mega_last_owner[dev] = ctx;
+    }
+    g_mega_mu.unlock();
+}
+static void mega_chain_forget(rwkv_context * ctx) {
+    std::lock_guard<std::mutex> lk(g_mega_mu);
+    const int dev = ctx->model->device;
+    if (dev >= 0 && dev < k_max_devices && g_mega_last_owner[dev] == ctx) {
+        if (g_mega_last[dev]) (void) hipEventSynchronize(g_mega_last[dev]);
+        g_mega_last[dev] = nullptr; g_mega_last_owner[dev] = nullptr;
+    }
+}
 
 // The persistent kernel is bound by cross-XCD hand-over latency, the seven-launch path by launch boundaries; which one wins
 // depends on the device (measured: 2.0 ms vs 2.6 ms per token on most MI355X boxes, 3.4 ms vs 2.9 ms on some). A few
@@ -57,12 +100,36 @@ static void calibrate_decode_path(rwkv_context * ctx) {
     ctx->cur = 0;
     ctx->last_error = 0;
     (void) hipFree(tok);
-    if (!ok || mega_v6_aborted(mega) || t_fused < 0.97f * t_mega) { mega_v6_destroy(mega); ctx->mega = nullptr; }
+    if (!ok || mega_v6_aborted(mega, ctx->stream) || t_fused < 0.97f * t_mega) {
+        if (mega_v6_aborted_cached(mega)) (void) mega_v6_clear_abort(mega, ctx->stream);
+        mega_chain_forget(ctx);
+        mega_chain_count(ctx, -1);
+        mega_v6_destroy(mega); ctx->mega = nullptr;
+    }
+}
+
+// After a poll time-out of the persistent kernel (the device was shared): the stream is drained, the abort word cleared, the
+// persistent path and the captured graphs dropped; the context continues on the per-layer launches. The state buffer the failed
+// step READ is intact (the kernel only writes the other one): the caller may flip `cur` back and repeat the step.
+void recover_from_abort(rwkv_context * ctx) {
+    if (!ctx->mega) return;
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) mega_v6_clear_abort(ctx->mega, ctx->stream);
+    mega_chain_forget(ctx);
+    mega_chain_count(ctx, -1);
+    mega_v6_destroy(ctx->mega);
+    ctx->mega = nullptr;
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (ctx->graph_exec[a][b]) { (void) hipGraphExecDestroy(ctx->graph_exec[a][b]); ctx->graph_exec[a][b] = nullptr; }
 }
 
 rwkv_context * create_context(Model * m, uint32_t n_threads) {
     std::unique_ptr<rwkv_context> ctx(new (std::nothrow) rwkv_context());
-    RW_CHECK(RWKV_ERROR_CTX | RWKV_ERROR_ALLOC, nullptr, ctx != nullptr, "Failed to allocate rwkv_context");
+    if (!ctx) {
+        // a model that no context references yet (rwkv_init_from_file / rwkv_mi_init_stage) would be orphaned
+        if (m->refcount.load() == 0) { m->refcount++; release_model(m); }
+        global_fail(RWKV_ERROR_CTX | RWKV_ERROR_ALLOC, __FILE__, __LINE__, "ctx != nullptr", "Failed to allocate rwkv_context");
+        return nullptr;
+    }
     ctx->model = m;
     ctx->n_threads = n_threads;
     m->refcount++;
@@ -80,6 +147,7 @@ rwkv_context * create_context(Model * m, uint32_t n_threads) {
     if ((e = hipMalloc((void **) &ctx->d_next_token, 64)) != hipSuccess) return fail(e);
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return fail(e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail(e);
+    if ((e = hipEventCreateWithFlags(&ctx->mega_done, hipEventDisableTiming)) != hipSuccess) return fail(e);
     const char * g = getenv("RWKV_MI_NO_GRAPH");
     ctx->use_graph = !(g && g[0] == '1');
     const char * nf = getenv("RWKV_MI_NO_FUSED");
@@ -88,8 +156,15 @@ rwkv_context * create_context(Model * m, uint32_t n_threads) {
         ctx->fused_v6 = true;
         const char * nm = getenv("RWKV_MI_NO_MEGA");
         if (!(nm && nm[0] == '1')) ctx->mega = mega_v6_create(*m);
+        // a second persistent context on this device: launches the first one made while it was alone carry no completion event
+        if (ctx->mega && mega_chain_count(ctx.get(), +1) > 1) (void) hipDeviceSynchronize();
         calibrate_decode_path(ctx.get());
     }
+    // A new context starts from the reference's fresh state (rwkv_eval.inc:224-241), whatever the calibration left behind:
+    // rwkv_mi_eval_resident / rwkv_mi_decode_greedy / rwkv_mi_stage_step continue from the resident state without a load.
+    ctx->cur = 0;
+    if (!state_from_host(ctx.get(), nullptr) || (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e);
+    ctx->last_error = 0;
     return ctx.release();
 }
 
@@ -104,7 +179,8 @@ void destroy_context(rwkv_context * ctx) {
     for (int i = 0; i < 2; i++) if (ctx->state[i]) (void) hipFree(ctx->state[i]);
     if (ctx->scratch) (void) hipFree(ctx->scratch);
     if (ctx->fused_scratch) (void) hipFree(ctx->fused_scratch);
-    if (ctx->mega) mega_v6_destroy(ctx->mega);
+    if (ctx->mega) { mega_chain_forget(ctx); mega_chain_count(ctx, -1); mega_v6_destroy(ctx->mega); }
+    if (ctx->mega_done) (void) hipEventDestroy(ctx->mega_done);
     if (ctx->d_tokens) (void) hipFree(ctx->d_tokens);
     if (ctx->d_logits) (void) hipFree(ctx->d_logits);
     if (ctx->d_next_token) (void) hipFree(ctx->d_next_token);
@@ -354,7 +430,10 @@ bool forward(rwkv_context * ctx, int64_t T, bool want_logits) {
     if (!ensure_scratch(ctx, T)) return false;
     Model & m = *ctx->model;
     Runner r{ctx, m, ctx->stream, T, m.n_embed(), m.head_count, m.head_size, ctx->b};
+    const bool chained = T == 1 && ctx->mega;
+    if (chained) mega_chain_begin(ctx);
     r.run(want_logits);
+    if (chained) mega_chain_end(ctx);
     ctx->cur ^= 1;
     HIP_CTX_OK(ctx, hipGetLastError());
     return true;
@@ -377,7 +456,11 @@ bool forward_decode(rwkv_context * ctx, bool want_logits) {
         (void) hipGraphDestroy(graph);
         RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, e == hipSuccess, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
     }
-    HIP_CTX_OK(ctx, hipGraphLaunch(ge, ctx->stream));
+    const bool chained = ctx->mega != nullptr;
+    if (chained) mega_chain_begin(ctx);
+    const hipError_t le = hipGraphLaunch(ge, ctx->stream);
+    if (chained) mega_chain_end(ctx);
+    HIP_CTX_OK(ctx, le);
     ctx->cur ^= 1;
     return true;
 }

@@ -945,6 +945,7 @@ struct MegaV6 {
     M6Layer * d_layers = nullptr;
     void * xch = nullptr;
     unsigned * ctl = nullptr;
+    unsigned * h_ctl = nullptr;   // pinned host mirror of ctl[0..1], refreshed by mega_v6_ctl_fetch on the caller's stream
     M6P proto{};
     long long * trace = nullptr;
     int variant = -1, n_blocks = 0;
@@ -991,6 +992,8 @@ void mega_v6_destroy(void * h) {
     if (mg->w2b) (void) hipFree(mg->w2b);
     if (mg->xch) (void) hipFree(mg->xch);
     if (mg->ctl) (void) hipFree(mg->ctl);
+    if (mg->h_ctl) (void) hipHostFree(mg->h_ctl);
+    if (mg->trace) (void) hipFree(mg->trace);
     delete mg;
 }
 
@@ -1056,7 +1059,9 @@ void * mega_v6_create(const Model & m) {
     bool ok = hipMalloc((void **) &mg->d_layers, hl.size() * sizeof(M6Layer)) == hipSuccess
            && hipMemcpy(mg->d_layers, hl.data(), hl.size() * sizeof(M6Layer), hipMemcpyHostToDevice) == hipSuccess
            && hipMalloc(&mg->xch, (size_t) units * 16) == hipSuccess && hipMemset(mg->xch, 0, (size_t) units * 16) == hipSuccess
-           && hipMalloc((void **) &mg->ctl, 256) == hipSuccess;
+           && hipMalloc((void **) &mg->ctl, 256) == hipSuccess
+           && hipHostMalloc((void **) &mg->h_ctl, 64, hipHostMallocDefault) == hipSuccess;
+    if (ok) { mg->h_ctl[0] = 8u; mg->h_ctl[1] = 0u; }
     const unsigned init[2] = {8u, 0u};
     ok = ok && hipMemcpy(mg->ctl, init, sizeof(init), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { mega_v6_destroy(mg); return nullptr; }
@@ -1108,11 +1113,29 @@ void mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipSt
     }
 }
 
-// true when a poll timed out in some launch since creation (co-residency lost or a bug): results are not valid
-bool mega_v6_aborted(void * h) {
-    unsigned c[2] = {0, 0};
-    if (hipMemcpy(c, ((MegaV6 *) h)->ctl, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return true;
-    return c[1] != 0;
+// The abort word (a poll timed out: co-residency lost or a bug; results since then are not valid) is read through a pinned
+// host mirror: an asynchronous copy on the caller's stream, checked after the caller's own stream synchronisation. (A
+// blocking hipMemcpy would go through the legacy null stream and couple every blocking stream of the process.)
+bool mega_v6_ctl_fetch(void * h, hipStream_t st) {
+    MegaV6 * mg = (MegaV6 *) h;
+    return hipMemcpyAsync(mg->h_ctl, mg->ctl, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess;
+}
+bool mega_v6_aborted_cached(void * h) { return ((MegaV6 *) h)->h_ctl[1] != 0; }
+bool mega_v6_aborted(void * h, hipStream_t st) {
+    if (!mega_v6_ctl_fetch(h, st) || hipStreamSynchronize(st) != hipSuccess) return true;
+    return mega_v6_aborted_cached(h);
+}
+// clears the abort word (after the caller has drained the stream), so that the handle -- or the context that drops it -- is usable again
+bool mega_v6_clear_abort(void * h, hipStream_t st) {
+    MegaV6 * mg = (MegaV6 *) h;
+    mg->h_ctl[1] = 0u;
+    return hipMemsetAsync(mg->ctl + 1, 0, sizeof(unsigned), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+}
+// Test hook: presets the rolling tag generation (ctl[0]; the kernel compares its low 16 bits), e.g. just below a 16-bit wrap.
+bool mega_v6_set_tag(void * h, unsigned base, hipStream_t st) {
+    MegaV6 * mg = (MegaV6 *) h;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    return hipMemcpy(mg->ctl, &base, sizeof(unsigned), hipMemcpyHostToDevice) == hipSuccess;
 }
 
 }  // namespace rwkvmi

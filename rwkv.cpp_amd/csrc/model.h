@@ -108,6 +108,7 @@ struct rwkv_context {
     bool use_graph = true;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t mega_done = nullptr;   // completion of this context's latest persistent-kernel launch (engine.hip: launches are chained per device)
 
     // fused single-token path (fused_v6.hip) when the model qualifies
     bool  fused_v6 = false;
@@ -148,9 +149,15 @@ void   fused_v6_layer(const Model & m, const LayerW & L, float * x, const float 
 void *   mega_v6_create(const Model & m);   // nullptr: not applicable
 void     mega_v6_destroy(void * h);
 void     mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf);
-bool     mega_v6_aborted(void * h);
+bool     mega_v6_ctl_fetch(void * h, hipStream_t st);       // async copy of the control words into the pinned mirror
+bool     mega_v6_aborted_cached(void * h);                  // the mirror's abort word (valid after the stream was synchronised)
+bool     mega_v6_aborted(void * h, hipStream_t st);         // fetch + synchronise + check
+bool     mega_v6_clear_abort(void * h, hipStream_t st);
+bool     mega_v6_set_tag(void * h, unsigned base, hipStream_t st);
 uint64_t mega_v6_bytes(void * h);
 bool     mega_v6_trace(void * h, int layer, long long * out, bool fetch);
+// after a poll time-out of the persistent kernel: drain, clear, drop the persistent path (see engine.hip)
+void recover_from_abort(rwkv_context * ctx);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
 bool forward_decode(rwkv_context * ctx, bool want_logits);
 // grows the per-context activation scratch to hold T tokens

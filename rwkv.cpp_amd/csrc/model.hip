@@ -140,8 +140,16 @@ static bool validate_shapes(Model & m) {
     };
     auto mat = [&](const DevTensor * t, int64_t K, int64_t N, const char * what) {
         if (!t) return;
-        const bool kdiv = t->ne[0] % 32 == 0;  // 32-element steps in every projection kernel
-        if ((K > 0 && t->ne[0] != K) || (N > 0 && t->ne[1] * t->ne[2] != N) || !kdiv) {
+        // Every projection kernel of this library walks a row in 32-element steps (quantised blocks; ggml's 32-partial dot order
+        // for F32/F16). The reference accepts other lengths for F32/F16 matrices; this build does not and says so.
+        if (t->ne[0] % 32 != 0) {
+            global_fail(RWKV_ERROR_MODEL_PARAMS | RWKV_ERROR_UNSUPPORTED, __FILE__, __LINE__, "matrix rows are a multiple of 32 elements",
+                        "Parameter %s (%s) has rows of %" PRId64 " elements; librwkv.so for MI355X supports row lengths (n_embed, ffn size, low-rank sizes) "
+                        "that are multiples of 32 only", t->name.c_str(), what, t->ne[0]);
+            ok = false;
+            return;
+        }
+        if ((K > 0 && t->ne[0] != K) || (N > 0 && t->ne[1] * t->ne[2] != N)) {
             global_fail(RWKV_ERROR_MODEL_PARAMS | RWKV_ERROR_DIMENSION, __FILE__, __LINE__, "matrix parameter has the expected shape",
                         "Parameter %s (%s) has unexpected shape [%" PRId64 ", %" PRId64 ", %" PRId64 "]", t->name.c_str(), what, t->ne[0], t->ne[1], t->ne[2]);
             ok = false;

@@ -3,6 +3,7 @@
 // tensors, never emb/head/v7 low-rank/r_k) and ggml's reference block quantisers, so the output is
 // byte-identical to the fixtures the reference ships (tests/tiny-rwkv-*-Q5_0.bin / -Q5_1.bin).
 #include "common.h"
+#include <cinttypes>
 
 #include <cmath>
 #include <cstring>
@@ -133,7 +134,10 @@ extern "C" RWKV_API bool rwkv_quantize_model_file(const char * in_path, const ch
         const uint8_t * payload = raw.data();
         uint64_t out_bytes = t.nbytes;
         int write_type = t.type;
-        const bool quantize = (t.type == T_F32 || t.type == T_F16) && t.ndim == 2 && tensor_needs_quant(t.name) && t.ne[0] % 32 == 0;
+        const bool quantize = (t.type == T_F32 || t.type == T_F16) && t.ndim == 2 && tensor_needs_quant(t.name);
+        // the reference hands every such tensor to ggml_quantize_chunk, which aborts on a row length that is not a whole number of blocks
+        RW_CHECK(RWKV_ERROR_MODEL_PARAMS | RWKV_ERROR_SHAPE, false, !quantize || t.ne[0] % 32 == 0,
+                 "Tensor %s has rows of %" PRId64 " elements: quantised formats need a multiple of 32", t.name.c_str(), t.ne[0]);
         if (g_print_errors) fprintf(stderr, "%48s - [%5u, %5u, %5u], type = %6s ", t.name.c_str(), (unsigned) t.ne[0], (unsigned) t.ne[1], (unsigned) t.ne[2], dtype_name(t.type));
         if (quantize) {
             const int64_t n = t.nelements();

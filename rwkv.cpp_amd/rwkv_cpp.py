@@ -90,6 +90,8 @@ class RWKVSharedLibrary:
         L.rwkv_mi_bytes_per_token.restype = ctypes.c_uint64
         L.rwkv_mi_weight_bytes.argtypes = [c_ctx]
         L.rwkv_mi_weight_bytes.restype = ctypes.c_uint64
+        L.rwkv_mi_prefill_flops.argtypes = [c_ctx, ctypes.c_size_t]
+        L.rwkv_mi_prefill_flops.restype = ctypes.c_uint64
         L.rwkv_mi_get_arch.argtypes = [c_ctx, P_UINT32, P_UINT32, P_UINT32, P_UINT32]
         L.rwkv_mi_get_arch.restype = None
         L.rwkv_mi_init_stage.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
@@ -110,6 +112,8 @@ class RWKVSharedLibrary:
         L.rwkv_mi_decode_path.restype = ctypes.c_int
         L.rwkv_mi_decode_healthy.argtypes = [c_ctx]
         L.rwkv_mi_decode_healthy.restype = ctypes.c_bool
+        L.rwkv_mi_test_set_tag.argtypes = [c_ctx, ctypes.c_uint32]
+        L.rwkv_mi_test_set_tag.restype = ctypes.c_bool
 
     # --- rwkv.h ---------------------------------------------------------------------------------------------
 
@@ -310,12 +314,22 @@ class RWKVModel:
     def bytes_per_token(self) -> int:
         return int(self._library.library.rwkv_mi_bytes_per_token(self._ctx.ptr))
 
+    def prefill_flops(self, n_tokens: int) -> int:
+        return int(self._library.library.rwkv_mi_prefill_flops(self._ctx.ptr, n_tokens))
+
     def set_graph_enabled(self, enabled: bool) -> None:
         self._library.library.rwkv_mi_set_graph_enabled(self._ctx.ptr, enabled)
 
     def decode_path(self) -> int:
         """0 = per-op kernels, 1 = fused RWKV-6 layer, 2 = persistent whole-stage kernel."""
         return int(self._library.library.rwkv_mi_decode_path(self._ctx.ptr))
+
+    def healthy(self) -> bool:
+        return bool(self._library.library.rwkv_mi_decode_healthy(self._ctx.ptr))
+
+    def test_set_tag(self, base: int) -> bool:
+        """Test hook: presets the persistent kernel's rolling hand-over tag (see include/rwkv_mi355x.h)."""
+        return bool(self._library.library.rwkv_mi_test_set_tag(self._ctx.ptr, base & 0xFFFFFFFF))
 
     def clone(self, thread_count: int = 1) -> "RWKVModel":
         other = object.__new__(RWKVModel)

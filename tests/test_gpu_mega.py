@@ -118,3 +118,111 @@ def test_mega_health_and_trace(tmp_path):
     assert (np.diff(t[:, 0, :13], axis=1) >= 0).all()                                              # comm wave
     assert L.rwkv_mi_decode_healthy(m._ctx.ptr)
     m.free()
+
+
+@pytest.mark.parametrize("name,fmt", [("mega-v6-2048", "Q4_0"), ("mega-v6-4096", "Q5_1")])
+def test_mega_across_the_16_bit_tag_wrap(tmp_path, name, fmt):
+    """The hand-over tag is a rolling 16-bit generation advancing 8 per layer (wraps every 256 tokens at 32 layers). Preset a few
+    layers below the wrap, then logits and state must stay bit-identical to the oracle while the tag rolls over -- serially
+    (rwkv_eval) and through the graph-replayed greedy loop."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS[name]
+    synth.write_model(p, spec, fmt, seed=17)
+    om = O.OracleModel(p)
+    m = model(p)
+    assert m.decode_path() == 2
+    per_token = 8 * spec.n_layer
+    for base in (0x10000 - 2 * per_token - 8, 0xFFFFFFF8 - 3 * per_token):      # 16-bit wrap inside token 2 / 32-bit wrap of the counter itself
+        assert m.test_set_tag(base)
+        ost, st = om.init_state(), None
+        for i, t in enumerate(TOKENS[:6]):
+            ol, ost = om.eval(t, ost)
+            lg, st = m.eval(t, st)
+            assert np.array_equal(lg, ol), (name, hex(base), i)
+            assert np.array_equal(st, ost), (name, hex(base), i)
+    assert m.test_set_tag(0x10000 - 3 * per_token)
+    m.state_load(None)
+    toks, _ = m.decode_greedy(5, 8)
+    ost, tok, ref = om.init_state(), 5, []
+    for _ in range(8):
+        ol, ost = om.eval(tok, ost)
+        tok = int(np.argmax(ol))
+        ref.append(tok)
+    assert list(toks) == ref
+    assert np.array_equal(m.state_store(), ost)
+    assert m.healthy()
+    m.free()
+    om.free()
+
+
+def test_concurrent_clones_on_the_persistent_path(tmp_path):
+    """rwkv.h:64-68: parallel inference = one clone per thread. Every clone owns a persistent kernel on its own stream; their
+    launches are chained per device (engine.hip), so two threads decoding at once neither dead-lock nor time out."""
+    import threading
+    library()
+    p = str(tmp_path / "m.bin")
+    synth.write_model(p, synth.CONFIGS["mega-v6-2048"], "Q4_0", seed=23)
+    om = O.OracleModel(p)
+    ost, tok, ref = om.init_state(), 7, []
+    for _ in range(24):
+        ol, ost = om.eval(tok, ost)
+        tok = int(np.argmax(ol))
+        ref.append(tok)
+    a = model(p)
+    b = a.clone()
+    assert a.decode_path() == 2 and b.decode_path() == 2
+    out, errs = {}, []
+
+    def greedy(name, m):
+        try:
+            m.state_load(None)
+            toks, _ = m.decode_greedy(7, 24)
+            out[name] = list(toks)
+        except Exception as e:   # noqa: BLE001
+            errs.append((name, repr(e)))
+
+    def serial(name, m):
+        try:
+            st, tok, got = None, 7, []
+            for _ in range(24):
+                lg, st = m.eval(tok, st)
+                tok = int(np.argmax(lg))
+                got.append(tok)
+            out[name] = got
+        except Exception as e:   # noqa: BLE001
+            errs.append((name, repr(e)))
+
+    for rnd in range(2):
+        th = [threading.Thread(target=greedy if rnd == 0 else serial, args=("a", a)), threading.Thread(target=serial, args=("b", b))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        assert out["a"] == ref and out["b"] == ref
+    assert a.healthy() and b.healthy()
+    b.free()
+    a.free()
+    om.free()
+
+
+def test_new_context_starts_from_the_fresh_state(tmp_path):
+    """A context (or clone) used through the resident-state extensions without an explicit load starts from the reference's fresh
+    state, not from what the creation-time calibration left in the buffers."""
+    library()
+    p = str(tmp_path / "m.bin")
+    synth.write_model(p, synth.CONFIGS["mega-v6-2048"], "Q4_0", seed=29)
+    os.environ.pop("RWKV_MI_NO_AUTOTUNE", None)
+    try:
+        m = model(p)
+        c = m.clone()
+    finally:
+        os.environ["RWKV_MI_NO_AUTOTUNE"] = "1"
+    toks_c, _ = c.decode_greedy(3, 6)
+    toks_m, _ = m.decode_greedy(3, 6)
+    m.state_load(None)
+    toks_r, _ = m.decode_greedy(3, 6)
+    assert list(toks_c) == list(toks_r) == list(toks_m)
+    c.free()
+    m.free()

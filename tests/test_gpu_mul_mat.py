@@ -22,7 +22,8 @@ def _weights(rng, fmt, K, N):
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
-@pytest.mark.parametrize("K,N", [(64, 96), (2560, 130), (4096, 515), (14336, 67)])
+# K of every BASELINE configuration: RWKV-4 169M (768, 3072), RWKV-6 1.6B (2048, 7168), RWKV-7 2.9B (2560, 10240), RWKV-6 7B (4096, 14336)
+@pytest.mark.parametrize("K,N", [(64, 96), (2560, 130), (4096, 515), (14336, 67), (768, 200), (3072, 70), (2048, 133), (7168, 66), (10240, 35)])
 def test_single_token_matches_oracle(fmt, K, N):
     rng = np.random.default_rng(K * 7 + N)
     t, wb = _weights(rng, fmt, K, N)
@@ -35,7 +36,7 @@ def test_single_token_matches_oracle(fmt, K, N):
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
-@pytest.mark.parametrize("K,N,T", [(128, 40, 3), (4096, 70, 9), (14336, 33, 17), (2560, 50, 8)])
+@pytest.mark.parametrize("K,N,T", [(128, 40, 3), (4096, 70, 9), (14336, 33, 17), (2560, 50, 8), (768, 40, 5), (2048, 70, 33), (7168, 33, 12), (10240, 20, 6), (3072, 24, 4)])
 def test_token_tiled_is_bit_identical_to_single_token(fmt, K, N, T):
     rng = np.random.default_rng(K + N + T)
     t, wb = _weights(rng, fmt, K, N)
@@ -45,6 +46,20 @@ def test_token_tiled_is_bit_identical_to_single_token(fmt, K, N, T):
     assert np.array_equal(y, ref)
     for i in range(T):
         assert np.array_equal(gpu_mul_mat(t, wb, K, N, x[i])[0], y[i]), (fmt, K, N, T, i)
+
+
+@pytest.mark.parametrize("K,V,rows", [(768, 50277, 1200), (2048, 65536, 700)])
+def test_head_slice_f16(K, V, rows):
+    """The F16 head of RWKV-4 169M (50277 x 768: a vocabulary that is no multiple of the 64-row tile) and of the World models:
+    the first / last rows of a full-size head against the oracle."""
+    rng = np.random.default_rng(V)
+    w = (rng.standard_normal((V, K)) * 0.03).astype(np.float16)
+    x = rng.standard_normal(K).astype(np.float32)
+    y = gpu_mul_mat(O.TYPE_IDS["FP16"], w.view(np.uint8).reshape(-1), K, V, x)[0]
+    for sl in (slice(0, rows), slice(V - rows, V)):
+        ws = np.ascontiguousarray(w[sl])
+        ref = O.mul_mat(O.TYPE_IDS["FP16"], ws.view(np.uint8).reshape(-1), K, ws.shape[0], x)[0]
+        assert np.array_equal(y[sl], ref)
 
 
 def test_linearity_property_q8_0():
