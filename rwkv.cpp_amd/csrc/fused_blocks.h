@@ -132,11 +132,11 @@ __device__ __forceinline__ void batch_issue(Batch<FMT, R, U> & bt, const uint8_t
             const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
             const uint8_t * rq = qs + row * nb * QF<FMT>::QS;
             RawBlk<FMT> & o = bt.raw[u][r];
-            if constexpr (QF<FMT>::HM) o.sc = (reinterpret_cast<const uint32_t *>(sc) + row * nb)[b];
-            else o.sc = (reinterpret_cast<const uint16_t *>(sc) + row * nb)[b];
-            if constexpr (QF<FMT>::QH) o.qh = (qh + row * nb)[b];
-            o.q[0] = *reinterpret_cast<const int4 *>(rq + b * QF<FMT>::QS);
-            if constexpr (QF<FMT>::QS == 32) o.q[1] = *reinterpret_cast<const int4 *>(rq + b * QF<FMT>::QS + 16);
+            if constexpr (QF<FMT>::HM) o.sc = ldw4(reinterpret_cast<const uint32_t *>(sc) + row * nb + b);
+            else o.sc = ldw2(reinterpret_cast<const uint16_t *>(sc) + row * nb + b);
+            if constexpr (QF<FMT>::QH) o.qh = ldw4(qh + row * nb + b);
+            o.q[0] = ldw16(rq + b * QF<FMT>::QS);
+            if constexpr (QF<FMT>::QS == 32) o.q[1] = ldw16(rq + b * QF<FMT>::QS + 16);
         }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -257,17 +257,55 @@ struct RawBlk {
     unsigned sc;                // fp16 d in the low half (+ fp16 m in the high half for Q4_1 / Q5_1)
 };
 
-template <int FMT>
+// Weight-stream loads. A decode step reads every weight byte exactly once, from one CU: with the non-temporal policy (`nt`) the
+// lines are not kept in L2 / MALL for a re-use that never comes (MI355X_MICROARCH.md, row nt-weights: issued -> landed -18 %,
+// a decode layer -5...10 %). RWKV_NT_WEIGHTS=0 builds the default-policy variant for A/B runs.
+#ifndef RWKV_NT_WEIGHTS
+#define RWKV_NT_WEIGHTS 1
+#endif
+typedef int wv4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 ldw16(const void * p) {
+#if RWKV_NT_WEIGHTS
+    const wv4i v = __builtin_nontemporal_load(reinterpret_cast<const wv4i *>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const int4 *>(p);
+#endif
+}
+__device__ __forceinline__ uint32_t ldw4(const uint32_t * p) {
+#if RWKV_NT_WEIGHTS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint32_t ldw2(const uint16_t * p) {
+#if RWKV_NT_WEIGHTS
+    return (uint32_t) __builtin_nontemporal_load(p);
+#else
+    return (uint32_t) *p;
+#endif
+}
+
+template <int FMT, bool ONCE = true>   // ONCE = false: weights that many workgroups re-read (token-tiled sequence kernels) keep the default policy
 __device__ __forceinline__ void load_raw(RawBlk<FMT> & r, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
                                          const void * __restrict__ sc, int64_t blk) {
-    if constexpr (QF<FMT>::HM) r.sc = reinterpret_cast<const uint32_t *>(sc)[blk];
-    else r.sc = reinterpret_cast<const uint16_t *>(sc)[blk];
-    if constexpr (QF<FMT>::QH) r.qh = qh[blk];
+    if constexpr (!ONCE) {
+        if constexpr (QF<FMT>::HM) r.sc = reinterpret_cast<const uint32_t *>(sc)[blk];
+        else r.sc = reinterpret_cast<const uint16_t *>(sc)[blk];
+        if constexpr (QF<FMT>::QH) r.qh = qh[blk];
+        r.q[0] = *reinterpret_cast<const int4 *>(qs + blk * QF<FMT>::QS);
+        if constexpr (QF<FMT>::QS == 32) r.q[1] = *reinterpret_cast<const int4 *>(qs + blk * 32 + 16);
+        return;
+    }
+    if constexpr (QF<FMT>::HM) r.sc = ldw4(reinterpret_cast<const uint32_t *>(sc) + blk);
+    else r.sc = ldw2(reinterpret_cast<const uint16_t *>(sc) + blk);
+    if constexpr (QF<FMT>::QH) r.qh = ldw4(qh + blk);
     if constexpr (QF<FMT>::QS == 32) {
-        r.q[0] = *reinterpret_cast<const int4 *>(qs + blk * 32);
-        r.q[1] = *reinterpret_cast<const int4 *>(qs + blk * 32 + 16);
+        r.q[0] = ldw16(qs + blk * 32);
+        r.q[1] = ldw16(qs + blk * 32 + 16);
     } else {
-        r.q[0] = *reinterpret_cast<const int4 *>(qs + blk * 16);
+        r.q[0] = ldw16(qs + blk * 16);
     }
 }
 
@@ -304,11 +342,11 @@ __device__ __forceinline__ void unpack_raw(WBlk<FMT> & w, const RawBlk<FMT> & r)
     if constexpr (QF<FMT>::HM) w.m = h2f_bits((uint16_t)(r.sc >> 16)); else w.m = 0.0f;
 }
 
-template <int FMT>
+template <int FMT, bool ONCE = true>
 __device__ __forceinline__ void load_wblk(WBlk<FMT> & w, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh,
                                           const void * __restrict__ sc, int64_t blk) {
     RawBlk<FMT> r;
-    load_raw<FMT>(r, qs, qh, sc, blk);
+    load_raw<FMT, ONCE>(r, qs, qh, sc, blk);
     unpack_raw<FMT>(w, r);
 }
 

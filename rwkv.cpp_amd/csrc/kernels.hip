@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_mvq_tn(const uint8_t * __restrict__ qs,
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int64_t row = (row0 + r < N) ? row0 + r : N - 1;
-                load_wblk<FMT>(w[r], qs, qh, sc, row * nb + b);
+                load_wblk<FMT, false>(w[r], qs, qh, sc, row * nb + b);
             }
 #pragma unroll
             for (int tt = 0; tt < TT; tt++) {
@@ -213,14 +213,15 @@ __global__ __launch_bounds__(256) void k_mvf(const void * __restrict__ W, int64_
             float w[8];
             const int64_t e0 = rowc * K + k0 + 32 * s + 8 * q;
             if constexpr (F16) {
-                const int4 raw = *reinterpret_cast<const int4 *>(reinterpret_cast<const uint16_t *>(W) + e0);
+                const int4 raw = TT == 1 ? ldw16(reinterpret_cast<const uint16_t *>(W) + e0) : *reinterpret_cast<const int4 *>(reinterpret_cast<const uint16_t *>(W) + e0);
                 const unsigned u[4] = {(unsigned) raw.x, (unsigned) raw.y, (unsigned) raw.z, (unsigned) raw.w};
 #pragma unroll
                 for (int i = 0; i < 4; i++) { w[2 * i] = h2f_bits((uint16_t)(u[i] & 0xFFFFu)); w[2 * i + 1] = h2f_bits((uint16_t)(u[i] >> 16)); }
             } else {
-                const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(W) + e0);
-                const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(W) + e0 + 4);
-                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+                const int4 a = TT == 1 ? ldw16(reinterpret_cast<const float *>(W) + e0) : *reinterpret_cast<const int4 *>(reinterpret_cast<const float *>(W) + e0);
+                const int4 b = TT == 1 ? ldw16(reinterpret_cast<const float *>(W) + e0 + 4) : *reinterpret_cast<const int4 *>(reinterpret_cast<const float *>(W) + e0 + 4);
+                w[0] = __int_as_float(a.x); w[1] = __int_as_float(a.y); w[2] = __int_as_float(a.z); w[3] = __int_as_float(a.w);
+                w[4] = __int_as_float(b.x); w[5] = __int_as_float(b.y); w[6] = __int_as_float(b.z); w[7] = __int_as_float(b.w);
             }
 #pragma unroll
             for (int tt = 0; tt < TT; tt++) {

@@ -587,7 +587,7 @@ struct K6 {
                 bd[q] = (ch % (D / 64)) * 64 + lane;
                 const float4 * cb = reinterpret_cast<const float4 *>(p.w2b + L.w2b + (long long) ch * R * 64);
 #pragma unroll
-                for (int m4 = 0; m4 < 16; m4++) wB4[q][m4] = cb[(m4 < R / 4 ? m4 : R / 4 - 1) * 64 + lane];
+                for (int m4 = 0; m4 < 16; m4++) { const int4 t = ldw16(cb + (m4 < R / 4 ? m4 : R / 4 - 1) * 64 + lane); wB4[q][m4] = make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(t.w)); }
                 wBmaa[q] = ar.f(L.maa[bf[q]])[bd[q]];
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -15,7 +15,8 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "librwkv.so")
+# RWKV_LIB_DIR selects an alternative in-tree build directory (A/B variants built with `make LIBDIR=... OBJDIR=... EXTRA=-D...`)
+LIB_PATH = os.path.join(PKG_DIR, os.environ.get("RWKV_LIB_DIR", "lib"), "librwkv.so")
 
 QUANTIZED_FORMAT_NAMES = ("Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0")
 P_FLOAT = ctypes.POINTER(ctypes.c_float)
