@@ -4,6 +4,7 @@
 #include "rwkv_mi355x.h"
 
 #include <cinttypes>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -509,8 +510,36 @@ RWKV_API bool rwkv_mi_test_mul_mat(int type, const void * w, int64_t K, int64_t 
             qa.d = (float *) ((uint8_t *) d_q + (((size_t) T * K + 255) / 256) * 256);
             qa.s = qa.d + nbk;
             qa.isum = (int *) (qa.s + nbk);
-            launch_quantize_act((const float *) d_x, T, K, qa, st);
-            launch_matvec_q(W, qa, T, (float *) d_y, N, Epi(), st);
+            if (T >= k_mfma_min_tokens) {
+                // sequence mode: tile-major quantiser + int8 GEMM on the matrix cores (what the engine does for T >= 32)
+                void * d_tile = nullptr;
+                if (chk(hipMalloc(&d_tile, tile_act_bytes(T, K)))) {
+                    const TileAct ta = tile_act_at(d_tile, T, K);
+                    launch_quantize_act_tiles((const float *) d_x, T, K, type, ta, st);
+                    if (!launch_mmq_mfma(W, ta, T, (float *) d_y, N, Epi(), st)) ok = false;
+                    chk(hipDeviceSynchronize());
+                    if (const char * rep = getenv("RWKV_MI_TIME_MM")) {   // kernel timing aid (tools/gemm_bench.py): average of n back-to-back launches
+                        const int n = atoi(rep);
+                        hipEvent_t e0, e1;
+                        if (n > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                            (void) hipEventRecord(e0, st);
+                            for (int i = 0; i < n; i++) (void) launch_mmq_mfma(W, ta, T, (float *) d_y, N, Epi(), st);
+                            (void) hipEventRecord(e1, st);
+                            (void) hipEventSynchronize(e1);
+                            float ms = 0.0f;
+                            (void) hipEventElapsedTime(&ms, e0, e1);
+                            fprintf(stderr, "[time_mm] type %d K %lld N %lld T %lld: %.2f us per launch, %.1f TOP/s\n", type, (long long) K, (long long) N, (long long) T,
+                                    ms * 1e3 / n, 2.0 * K * N * T / (ms * 1e-3 / n) / 1e12);
+                            (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+                        }
+                    }
+                    (void) hipFree(d_tile);
+                    free_pf(W);
+                }
+            } else {
+                launch_quantize_act((const float *) d_x, T, K, qa, st);
+                launch_matvec_q(W, qa, T, (float *) d_y, N, Epi(), st);
+            }
         } else {
             W.data = d_raw;
             launch_matvec_f(W, (const float *) d_x, K, T, (float *) d_y, N, Epi(), st);

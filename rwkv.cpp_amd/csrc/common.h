@@ -90,6 +90,11 @@ struct DevTensor {
     uint8_t *  qs = nullptr;
     uint32_t * qh = nullptr;
     void *     sc = nullptr;
+    // second, tile-major image of a quantised matrix for the sequence-mode GEMM (prefill.hip), built on first use with T >= 32
+    mutable uint8_t *  pf_qs = nullptr;
+    mutable uint32_t * pf_sc = nullptr;
+    mutable uint32_t * pf_qh = nullptr;
+    mutable int64_t    pf_rows = 0;
     int64_t rows() const { return ne[1] * ne[2]; }
     int64_t cols() const { return ne[0]; }
 };

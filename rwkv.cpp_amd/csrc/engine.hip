@@ -204,6 +204,7 @@ bool ensure_scratch(rwkv_context * ctx, int64_t T) {
     const size_t n_D = 3 + 6 + 6 + 3 + 1 + 1;  // x xn sx | m[6] | r k v g w a | t0 t1 t2 | out | v_first
     size_t total = n_D * fsz(D) + fsz(F) + 2 * fsz(LR) + align_up(D * sizeof(float), 256);
     total += align_up((size_t) T * KQ, 256) + 3 * align_up((size_t) T * (KQ / 32) * 4, 256);
+    if (T >= k_mfma_min_tokens) total += align_up(tile_act_bytes(T, (int64_t) KQ), 256);
     if (ctx->scratch) { HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream)); (void) hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_T = 0; }
     drop_graphs(ctx);
     HIP_CTX_OK(ctx, hipMalloc(&ctx->scratch, total));
@@ -221,6 +222,8 @@ bool ensure_scratch(rwkv_context * ctx, int64_t T) {
     b.qa.d = (float *) p; p += align_up((size_t) T * (KQ / 32) * 4, 256);
     b.qa.s = (float *) p; p += align_up((size_t) T * (KQ / 32) * 4, 256);
     b.qa.isum = (int *) p; p += align_up((size_t) T * (KQ / 32) * 4, 256);
+    b.tile = nullptr;
+    if (T >= k_mfma_min_tokens) { b.tile = p; p += align_up(tile_act_bytes(T, (int64_t) KQ), 256); }
     ctx->scratch_T = T;
     return true;
 }
@@ -260,7 +263,12 @@ struct Runner {
     // y[T][N] = epi(W . x[T][K])    (ggml_mul_mat)
     void mm(const DevTensor * W, const float * x, float * y, const Epi & epi = Epi()) {
         const int64_t N = W->rows(), K = W->cols();
-        if (dtype_quantized(W->type)) {
+        if (dtype_quantized(W->type) && T >= k_mfma_min_tokens && b.tile) {
+            // sequence mode: int8 GEMM on the matrix cores (prefill.hip), bit-identical to the single-token kernel per (row, token)
+            const TileAct ta = tile_act_at(b.tile, T, K);
+            launch_quantize_act_tiles(x, T, K, W->type, ta, st);
+            if (!launch_mmq_mfma(*W, ta, T, y, N, epi, st)) ctx->last_error |= RWKV_ERROR_GRAPH | RWKV_ERROR_ALLOC;
+        } else if (dtype_quantized(W->type)) {
             launch_quantize_act(x, T, K, b.qa, st);
             auto & pf = ctx->prof;
             const bool timed = pf.on && T == 1 && W->type == (int) m.header.data_type;
@@ -279,6 +287,12 @@ struct Runner {
         } else {
             launch_matvec_f(*W, x, K, T, y, N, epi, st);
         }
+    }
+    // WKV-5/6: long sequences on the lane-pipelined kernel (one wave per value column), otherwise one wave per head
+    void wkv6(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
+              const float * state_in, float * state_out, float * out) {
+        if (S == 64 && T >= k_mfma_min_tokens) launch_wkv6_seq(r, k, v, u, u_per_chan, w, w_mode, state_in, state_out, out, T, H, st);
+        else launch_wkv6(r, k, v, u, u_per_chan, w, w_mode, state_in, state_out, out, T, H, S, st);
     }
     static const float * f(const DevTensor * t) { return (const float *) t->data; }
     static Epi epi(int op, const float * bias = nullptr, const float * res = nullptr, const float * aux = nullptr) {
@@ -331,8 +345,8 @@ struct Runner {
         mm(L.att_key, b.m[0], b.k);
         mm(L.att_value, b.m[1], b.v);
         if (v52) mm(L.att_gate, b.m[3], b.g, epi(EPI_SILU));
-        launch_wkv6(b.r, b.k, b.v, v52 ? f(L.att_time_faaaa) : f(L.att_time_first), v52 ? 1 : 0, f(L.att_time_decay), v52 ? 1 : 0,
-                    sin + 2 * D, sout + 2 * D, b.out, T, H, S, st);
+        wkv6(b.r, b.k, b.v, v52 ? f(L.att_time_faaaa) : f(L.att_time_first), v52 ? 1 : 0, f(L.att_time_decay), v52 ? 1 : 0,
+             sin + 2 * D, sout + 2 * D, b.out);
         launch_groupnorm(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), 1e-5f, v52 ? b.g : nullptr, nullptr, nullptr, nullptr, nullptr, T, H, S, st);
         mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
     }
@@ -349,7 +363,7 @@ struct Runner {
         v.maa[0] = f(L.att_time_maa_w); v.maa[1] = f(L.att_time_maa_k); v.maa[2] = f(L.att_time_maa_v);
         v.maa[3] = f(L.att_time_maa_r); v.maa[4] = f(L.att_time_maa_g);
         for (int i = 0; i < 5; i++) v.out[i] = b.m[i];  // xw, xk, xv, xr, xg
-        launch_v6_mix2(v, T, D, R, st);
+        if (!(T >= k_mfma_min_tokens && launch_v6_mix2_seq(v, T, D, R, st))) launch_v6_mix2(v, T, D, R, st);
         mm(L.att_receptance, b.m[3], b.r);
         mm(L.att_key, b.m[1], b.k);
         mm(L.att_value, b.m[2], b.v);
@@ -357,7 +371,7 @@ struct Runner {
         mm(L.att_time_decay_w1, b.m[0], b.lr2, epi(EPI_TANH));
         // decay_w2 consumes [T][DR] rows of lr2
         mm(L.att_time_decay_w2, b.lr2, b.w, epi(EPI_V6_DECAY, f(L.att_time_decay)));
-        launch_wkv6(b.r, b.k, b.v, f(L.att_time_faaaa), 1, b.w, 2, sin + 2 * D, sout + 2 * D, b.out, T, H, S, st);
+        wkv6(b.r, b.k, b.v, f(L.att_time_faaaa), 1, b.w, 2, sin + 2 * D, sout + 2 * D, b.out);
         launch_groupnorm(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), 64e-5f, b.g, nullptr, nullptr, nullptr, nullptr, T, H, S, st);
         mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
     }

@@ -61,6 +61,22 @@ struct Model {
     int64_t state_len() const { return state_per_layer() * n_layer(); }
 };
 
+// ---- sequence mode on the matrix cores (prefill.hip) ----
+struct TileAct {   // quantised activations of T tokens in the tile-major image (see prefill.hip)
+    int8_t * q = nullptr; float * d = nullptr; float * s = nullptr; float * o = nullptr;
+    int64_t T_pad = 0;
+};
+size_t  tile_act_bytes(int64_t T, int64_t K);
+TileAct tile_act_at(void * base, int64_t T, int64_t K);
+void launch_quantize_act_tiles(const float * x, int64_t T, int64_t K, int wtype, const TileAct & out, hipStream_t st);
+bool launch_mmq_mfma(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st);
+bool ensure_pf(const DevTensor & W, hipStream_t st);
+void free_pf(const DevTensor & W);
+bool launch_wkv6_seq(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
+                     const float * state_in, float * state_out, float * out, int64_t T, int64_t H, hipStream_t st);
+bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, hipStream_t st);
+constexpr int64_t k_mfma_min_tokens = 32;   // sequence calls of at least this many tokens per pass take the GEMM path
+
 // Loads [layer_begin, layer_end) of the file (layer_end == UINT32_MAX: all layers) onto the current HIP device.
 // Returns nullptr with the thread-local error set, like the reference loader (rwkv_model_loading.inc:288-419).
 Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end);
@@ -92,6 +108,7 @@ struct rwkv_context {
     struct Buf {
         float *x, *xn, *sx, *m[6], *r, *k, *v, *g, *w, *a, *t0, *t1, *t2, *out, *ffk, *lr1, *lr2, *v_first, *xlast;
         rwkvmi::QAct qa;
+        void * tile = nullptr;   // tile-major quantised activations (T >= k_mfma_min_tokens)
     } b{};
 
     uint32_t * d_tokens = nullptr;

@@ -402,6 +402,7 @@ Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end) 
 void release_model(Model * m) {
     if (!m) return;
     if (--m->refcount > 0) return;
+    for (const auto & t : m->tensors) free_pf(*t);
     if (m->arena) (void) hipFree(m->arena);
     delete m;
 }

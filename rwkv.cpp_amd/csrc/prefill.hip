@@ -1,0 +1,645 @@
+// prefill.hip -- sequence mode (rwkv_eval_sequence, T tokens at once) on the matrix cores:
+//
+//   k_mmq_mfma<FMT>    every quantised projection of the sequence graph (rwkv_build_sequential_graph, rwkv_graph.inc:744-866:
+//                      each ggml_mul_mat with T columns) as a dense int8 GEMM on v_mfma_i32_32x32x32_i8. K = 32 of the
+//                      instruction is exactly one quantisation block, so an MFMA returns the EXACT integer block sums of a
+//                      32-token x 32-row tile; the block is then folded into the f32 accumulators with the same statement
+//                      as the single-token kernel (kdev.h blk_fma):  P = fma(d_w * d_x, isum, P) [+ fma(m_w, s_x, P)].
+//   k_quant_act_tiles  the activation quantiser of ggml's mul_mat (Q8_0 / Q8_1) writing the tile-major image the GEMM reads.
+//   k_pf_repack        load-/first-use-time copy of a quantised matrix into the tile-major image the GEMM reads.
+//   k_wkv6_seq         the WKV-5/6 recurrence with the T loop pipelined across the 64 lanes of a wave (one wave per value
+//                      column instead of one wave per head).
+//
+// Bit-exactness with the single-token path (the reference guarantees serial == sequence and tests it with memcmp,
+// tests/test_eval_sequence_in_chunks.c:54; here it holds for every format). A row sum of k_mvq_t1 is a fixed expression:
+// 64 partials P[l], l = b mod 64, each a chain over its blocks in increasing b, then the xor-butterfly 32, 16, 8, 4, 2, 1 --
+// a binary tree whose root splits the leaves by bit 0 of l, the next level by bit 1, ... A depth-first walk of that tree
+// visits the leaves in bit-reversed order l = 0, 32, 16, 48, 8, ..., so the GEMM walks the K dimension in that order and
+// needs a stack of only six partial sums per output (plus the running leaf): after leaf number c, as many merges as c has
+// trailing one bits. Every output element therefore sees exactly the additions of the single-token kernel, in the same order.
+// Leaves without blocks (l >= K/32) are +0.0 there (acc + 0 is the identity on these values) and +0.0 here.
+//
+// Memory. A depth-first walk touches blocks 0, 64, ..., 32, 96, ...: in the row-major planes of the decode path that is one
+// 16-byte piece per 128-byte line and eight fetches of every line. The GEMM reads a second image of the matrix instead
+// ("pf": per 32-row tile and block one contiguous 512-byte run of codes, 128 bytes of scales), built on the GPU the first
+// time a matrix is used with T >= 32; 288 GB of HBM make the second copy of the quantised matrices a non-issue, and the
+// decode path keeps its own layout. Activations are quantised straight into the matching image (per 32-token tile and
+// block 1 KiB of codes in MFMA operand order + 128 bytes of scales).
+//
+// Work decomposition: a 512-thread workgroup (8 waves, two per SIMD) owns a 128-row x 64-token output tile; wave (rg, tg)
+// owns rows [32 rg, +32) x tokens [32 tg, +32). The K walk is cut into chunks of 8 steps (blocks); a chunk's operands (4.8 KB
+// per step for Q4_0) are staged by all threads into one of two LDS buffers while the previous chunk is computed, one
+// workgroup barrier per chunk. Per step and wave: four 16-byte LDS reads of operands + four of token scales, one MFMA,
+// ~60 VALU instructions of unpack and scale-accumulate -- the kernel is bound by that VALU work (the f32 fold per block
+// is what ggml's arithmetic prescribes), the MFMA itself is ~1/4 of the step.
+#include "kdev.h"
+#include "model.h"
+
+#include <mutex>
+
+namespace rwkvmi {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// tile-major images
+// ---------------------------------------------------------------------------------------------------------------
+
+// weights: row tile rt (32 rows), block b:
+//   qs  Q4/Q5: [rt][b][n][16 B]        Q8_0: [rt][b][half][n][16 B]      (n = row within the tile)
+//   sc  [rt][b][n] u32 = fp16 d | fp16 m << 16 (m = 0 for the formats without one)
+//   qh  [rt][b][n] u32 (Q5 only)
+__global__ __launch_bounds__(256) void k_pf_repack(int type, const uint8_t * __restrict__ qs, const uint32_t * __restrict__ qh, const void * __restrict__ sc,
+                                                   int64_t N, int nb, uint8_t * __restrict__ pq, uint32_t * __restrict__ psc, uint32_t * __restrict__ pqh) {
+    const int64_t RT = (N + 31) / 32;
+    const int64_t idx = (int64_t) blockIdx.x * 256 + threadIdx.x;   // over (rt, b, n)
+    if (idx >= RT * nb * 32) return;
+    const int n = (int) (idx & 31);
+    const int64_t rb = idx >> 5;
+    const int b = (int) (rb % nb);
+    const int64_t rt = rb / nb;
+    const int64_t row = rt * 32 + n;
+    const bool valid = row < N;
+    const int64_t src = row * nb + b;
+    const bool q8 = type == T_Q8_0;
+    const bool hm = type == T_Q4_1 || type == T_Q5_1;
+    int4 a = make_int4(0, 0, 0, 0), c = make_int4(0, 0, 0, 0);
+    uint32_t s = 0, h = 0;
+    if (valid) {
+        if (q8) { a = *reinterpret_cast<const int4 *>(qs + src * 32); c = *reinterpret_cast<const int4 *>(qs + src * 32 + 16); }
+        else a = *reinterpret_cast<const int4 *>(qs + src * 16);
+        s = hm ? reinterpret_cast<const uint32_t *>(sc)[src] : (uint32_t) reinterpret_cast<const uint16_t *>(sc)[src];
+        if (qh) h = qh[src];
+    }
+    if (q8) {
+        *reinterpret_cast<int4 *>(pq + ((rb * 2 + 0) * 32 + n) * 16) = a;
+        *reinterpret_cast<int4 *>(pq + ((rb * 2 + 1) * 32 + n) * 16) = c;
+    } else {
+        *reinterpret_cast<int4 *>(pq + (rb * 32 + n) * 16) = a;
+    }
+    psc[rb * 32 + n] = s;
+    if (pqh) pqh[rb * 32 + n] = h;
+}
+
+// activations, token tile tt (32 tokens), block b:
+//   q [tt][b][half][i][16 B]   (i = token within the tile; half 0 = elements 0..15: the MFMA A-operand image, lane = half * 32 + i)
+//   d [tt][b][i] f32 = fp16-rounded amax / 127, times dscale       s [tt][b][i] f32 = fp16(d * sum q)       o [tt][b][i] f32 = off * sum q
+// Tokens t >= T of the last tiles are written as zeros (their products are never stored).
+// One wave = one (token tile, block): lane = half * 32 + i owns the 16 elements of its half of token i's block -- exactly its
+// 16 bytes of the A-operand image, so the wave reads 32 full 128-byte lines and writes one contiguous KiB. The block's amax and
+// code sum combine the two halves through one permlane32 swap (max and integer sum are order-free: same result as k_quant_act).
+__global__ __launch_bounds__(256) void k_quant_act_tiles(const float * __restrict__ x, int64_t T, int64_t T_pad, int nb, float dscale, float off,
+                                                         int8_t * __restrict__ q, float * __restrict__ d, float * __restrict__ s, float * __restrict__ o) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);   // (tt, b)
+    const int64_t n_tiles = (T_pad >> 5) * nb;
+    if (wv >= n_tiles) return;                                          // whole waves
+    const int64_t tt = wv / nb;
+    const int b = (int) (wv - tt * nb);
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t t = tt * 32 + i;
+    const bool live = t < T;
+    float v[16];
+    const float4 * src = reinterpret_cast<const float4 *>(x + ((live ? t : 0) * nb + b) * 32 + h * 16);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float4 f = live ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[4 * j] = f.x; v[4 * j + 1] = f.y; v[4 * j + 2] = f.z; v[4 * j + 3] = f.w;
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) amax = fmaxf(amax, fabsf(v[j]));
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+        amax = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    const float dd = amax / 127.0f;
+    const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+    int sum = 0;
+    int w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const int qi = (int) roundf(v[4 * j + e] * id); sum += qi; w |= (qi & 0xFF) << (8 * e); }
+        w4[j] = w;
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned) sum, (unsigned) sum, false, false);
+        sum = (int) r[0] + (int) r[1];
+    }
+    const int64_t tb = tt * nb + b;
+    *reinterpret_cast<int4 *>(q + tb * 1024 + lane * 16) = make_int4(w4[0], w4[1], w4[2], w4[3]);
+    if (h == 0) {
+        const float d16 = round_f16(dd);
+        d[tb * 32 + i] = d16 * dscale;   // a power of two: exact
+        if (s) s[tb * 32 + i] = round_f16((float) sum * dd);
+        if (o) o[tb * 32 + i] = off * (float) sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the GEMM
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int FMT> struct MF {
+    static constexpr bool Q8 = FMT == T_Q8_0;
+    static constexpr bool QH = QF<FMT>::QH, HM = QF<FMT>::HM;
+    static constexpr bool XO = FMT == T_Q5_0;                   // offset through the activation sums (float, exact)
+    // workgroup = RGN x 2 waves: RGN row groups of 32 rows x 2 token groups of 32 tokens. Measured (2048 x 2048 x 1024, Q4_0): RGN = 4
+    // (512 threads, 128 x 64 tile, one workgroup per CU) 36.6 us; RGN = 2 (256 threads, 64 x 64 tile, two workgroups per CU covering
+    // each other's barrier / DMA stalls) 44.0 us -- the larger tile's operand reuse is worth more than the second workgroup.
+    static constexpr int  RGN = 4, NT = RGN * 2 * 64, ROWS = RGN * 32;
+    static constexpr int  WC = ROWS * (Q8 ? 32 : 16);           // LDS bytes per step
+    static constexpr int  OFF_WC = 0, OFF_WSC = WC, OFF_WQH = OFF_WSC + ROWS * 4, OFF_XQ = OFF_WQH + (QH ? ROWS * 4 : 0), OFF_XD = OFF_XQ + 2048,
+                          OFF_XS = OFF_XD + 256, OFF_XO = OFF_XS + (HM ? 256 : 0), SLOT = OFF_XO + (XO ? 256 : 0);
+    // 16-byte pieces per step
+    static constexpr int P_WC = WC / 16, P_WSC = ROWS / 4, P_WQH = QH ? ROWS / 4 : 0, P_XQ = 128, P_XD = 16, P_XS = HM ? 16 : 0, P_XO = XO ? 16 : 0;
+    static constexpr int PS = P_WC + P_WSC + P_WQH + P_XQ + P_XD + P_XS + P_XO;
+    static constexpr int NLD = (8 * PS + NT - 1) / NT;          // staging loads per thread and chunk
+};
+
+struct PfW { const uint8_t * qs; const uint32_t * sc; const uint32_t * qh; };
+struct PfX { const int8_t * q; const float * d; const float * s; const float * o; };
+
+template <int FMT>
+__global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64_t N, int nb, int64_t T, int RT /* row tiles of 32 */, int C /* token tiles of 64 */,
+                                                  const unsigned short * __restrict__ order, float * __restrict__ y, int64_t ldy, Epi epi) {
+    typedef MF<FMT> M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // XCD-aware tile map: block id -> XCD id % 8; the token tiles of one 128-row panel run on the same XCD and share its L2
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int rp = (kk / C) * 8 + xcd;          // row panel (RGN row tiles)
+    const int ct = kk % C;                       // token tile of 64
+    if (rp * M::RGN >= RT) return;               // (whole workgroup: before any barrier)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave % M::RGN, tg = wave / M::RGN;
+    const int nn = lane & 31, h = lane >> 5;
+    const int rt0 = rp * M::RGN, tt0 = ct * 2;
+
+    // ---- staging: chunk k = steps [8k, 8k + 8) goes straight from global memory into LDS buffer k & 1 (LDS-DMA, 16 bytes per lane,
+    //      1 KiB per wave-instruction, no staging registers). A chunk is a linear array of 8 * PS pieces: piece p at byte 16 p. ----
+    const unsigned lds_base = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) lds;
+    auto issue = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < M::NLD; i++) {
+            const int p = tid + M::NT * i;
+            const int sidx = p / M::PS, qq = p - sidx * M::PS;
+            int step = 8 * k + sidx;
+            if (step >= nb) step = nb - 1;                       // (tail of the last chunk: harmless duplicate)
+            const int64_t b = order[step];
+            const unsigned char * src;
+            if (qq < M::P_WC) {
+                if constexpr (M::Q8) {
+                    const int r4 = qq >> 6, rest = qq & 63;       // rest = half * 32 + n
+                    int rt = rt0 + r4; rt = rt < RT ? rt : RT - 1;
+                    src = w.qs + (((int64_t) rt * nb + b) * 64 + rest) * 16;
+                } else {
+                    const int r4 = qq >> 5, n = qq & 31;
+                    int rt = rt0 + r4; rt = rt < RT ? rt : RT - 1;
+                    src = w.qs + (((int64_t) rt * nb + b) * 32 + n) * 16;
+                }
+            } else if (qq < M::P_WC + M::P_WSC) {
+                const int q2 = qq - M::P_WC, r4 = q2 >> 3, part = q2 & 7;
+                int rt = rt0 + r4; rt = rt < RT ? rt : RT - 1;
+                src = reinterpret_cast<const unsigned char *>(w.sc) + (((int64_t) rt * nb + b) * 32) * 4 + part * 16;
+            } else if (qq < M::P_WC + M::P_WSC + M::P_WQH) {
+                const int q2 = qq - M::P_WC - M::P_WSC, r4 = q2 >> 3, part = q2 & 7;
+                int rt = rt0 + r4; rt = rt < RT ? rt : RT - 1;
+                src = reinterpret_cast<const unsigned char *>(w.qh) + (((int64_t) rt * nb + b) * 32) * 4 + part * 16;
+            } else if (qq < M::P_WC + M::P_WSC + M::P_WQH + M::P_XQ) {
+                const int q2 = qq - M::P_WC - M::P_WSC - M::P_WQH, t2 = q2 >> 6, rest = q2 & 63;
+                src = reinterpret_cast<const unsigned char *>(x.q) + (((int64_t) (tt0 + t2) * nb + b) * 1024) + rest * 16;
+            } else {
+                const int q2 = qq - M::P_WC - M::P_WSC - M::P_WQH - M::P_XQ;
+                const int which = q2 >> 4, q3 = q2 & 15, t2 = q3 >> 3, part = q3 & 7;   // d, then s (HM) / o (XO)
+                const float * base = which == 0 ? x.d : (M::HM ? x.s : x.o);
+                src = reinterpret_cast<const unsigned char *>(base) + (((int64_t) (tt0 + t2) * nb + b) * 32) * 4 + part * 16;
+            }
+            // Issued through inline asm on purpose: the compiler cannot prove that an LDS-DMA does not alias the operand reads
+            // of the steps that follow and would put `s_waitcnt vmcnt(0)` in front of every one of them (measured: the whole DMA
+            // latency exposed once per chunk, 3.4x on the kernel). Its completion is waited for by hand at the chunk boundary.
+            if (wave * 64 + M::NT * i < 8 * M::PS && p < 8 * M::PS) {   // (first test is wave-uniform: a wave without pieces issues nothing)
+                const unsigned dst = lds_base + (unsigned) ((8 * (k & 1)) * M::SLOT + (wave * 64 + M::NT * i) * 16);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        }
+    };
+
+    // two chunk buffers (a third one in flight was measured: no gain -- the kernel is bound by its VALU work, not by the DMA)
+    const int n_chunks = (nb + 7) / 8;
+    issue(0);
+
+    // ---- the walk: leaves in bit-reversed order, 8 per iteration of the outer loop (the merges are compile-time code) ----
+    float s0[16], s1[16], s2[16], S3[16], S4[16], S5[16], V[16];
+    int sigma = 0;
+    constexpr int REV3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+#pragma unroll 1
+    for (int a = 0; a < 8; a++) {
+        const int ra = ((a & 1) << 2) | (a & 2) | (a >> 2);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int l = 8 * REV3[u] + ra;
+            // A leaf whose value starts a new subtree (even u) accumulates straight into s0: no copy. Other leaves use `tmp`.
+            float tmp[16];
+            float (&cur)[16] = (u & 1) ? tmp : s0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) cur[r] = 0.0f;
+            for (int b = l; b < nb; b += 64) {
+                if ((sigma & 7) == 0) {
+                    // chunk boundary: this wave's part of chunk k has landed (issued one chunk ago); after the barrier everybody's
+                    // has, and every wave has left the buffer the next chunk goes into
+                    const int k = sigma >> 3;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (k + 1 < n_chunks) issue(k + 1);
+                }
+                const unsigned char * S = lds + (size_t) (sigma & 15) * M::SLOT;
+                // operands
+                const int4 braw = *reinterpret_cast<const int4 *>(S + M::OFF_WC + (M::Q8 ? (rg * 64 + h * 32 + nn) : (rg * 32 + nn)) * 16);
+                const unsigned scw = *reinterpret_cast<const unsigned *>(S + M::OFF_WSC + (rg * 32 + nn) * 4);
+                const v4i aop = *reinterpret_cast<const v4i *>(S + M::OFF_XQ + (tg * 64 + lane) * 16);
+                v4i bop;
+                const int raw[4] = {braw.x, braw.y, braw.z, braw.w};
+                if constexpr (FMT == T_Q8_0) {
+                    bop[0] = raw[0]; bop[1] = raw[1]; bop[2] = raw[2]; bop[3] = raw[3];
+                } else if constexpr (FMT == T_Q4_0) {
+                    // signed (q - 8) placed in the HIGH nibble: the MFMA returns 16 x the block sum, the token scales carry 1/16
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const int t = h ? raw[i] : (raw[i] << 4); bop[i] = (t & (int) 0xF0F0F0F0) ^ (int) 0x80808080; }
+                } else if constexpr (FMT == T_Q4_1) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) bop[i] = (raw[i] >> (4 * h)) & 0x0F0F0F0F;
+                } else {
+                    const unsigned qhw = *reinterpret_cast<const unsigned *>(S + M::OFF_WQH + (rg * 32 + nn) * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const unsigned nl = (qhw >> (16 * h + 4 * i)) & 0xFu;
+                        bop[i] = ((raw[i] >> (4 * h)) & 0x0F0F0F0F) | (int) (((nl * 0x00204081u) & 0x01010101u) << 4);
+                    }
+                }
+                const float dw = h2f_bits((uint16_t) (scw & 0xFFFFu));
+                const float mw = M::HM ? h2f_bits((uint16_t) (scw >> 16)) : 0.0f;
+                v16i acc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0;
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop, bop, acc, 0, 0, 0);
+                // fold the block: tokens of register r: (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float4 dx4 = *reinterpret_cast<const float4 *>(S + M::OFF_XD + (tg * 32 + 8 * g + 4 * h) * 4);
+                    const float dxv[4] = {dx4.x, dx4.y, dx4.z, dx4.w};
+                    float aux[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if constexpr (M::HM || M::XO) {
+                        const float4 a4 = *reinterpret_cast<const float4 *>(S + (M::HM ? M::OFF_XS : M::OFF_XO) + (tg * 32 + 8 * g + 4 * h) * 4);
+                        aux[0] = a4.x; aux[1] = a4.y; aux[2] = a4.z; aux[3] = a4.w;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int r = 4 * g + q;
+                        float sf = (float) acc[r];
+                        if constexpr (M::XO) sf = sf - aux[q];        // exact: integers below 2^24
+                        const float dd = dw * dxv[q];
+                        cur[r] = fmaf(dd, sf, cur[r]);
+                        if constexpr (M::HM) cur[r] = fmaf(mw, aux[q], cur[r]);
+                    }
+                }
+                sigma++;
+            }
+            // merges after leaf c = 8 a + u: one per trailing one bit of c
+            if (u == 1 || u == 5) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) s1[r] = s0[r] + cur[r];
+            } else if (u == 3) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const float t = s0[r] + cur[r]; s2[r] = s1[r] + t; }
+            } else if (u == 7) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const float t = s0[r] + cur[r]; const float t2 = s1[r] + t; V[r] = s2[r] + t2; }
+            }
+        }
+        if ((a & 1) == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) S3[r] = V[r];
+        } else if ((a & 2) == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) S4[r] = S3[r] + V[r];
+        } else if ((a & 4) == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const float t = S3[r] + V[r]; S5[r] = S4[r] + t; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const float t = S3[r] + V[r]; const float t2 = S4[r] + t; V[r] = S5[r] + t2; }
+        }
+    }
+    // ---- epilogue: row n = column of the tile (lane), tokens along the registers ----
+    const int64_t n = (int64_t) (rt0 + rg) * 32 + nn;
+    if (n < N) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t t = (int64_t) (tt0 + tg) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (t < T) y[t * ldy + n] = apply_epi(epi, V[r], t, n, ldy);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// WKV-5/6 over a sequence (ggml_rwkv_wkv6, rwkv_graph.inc:275,370), pipelined across the lanes of a wave.
+//
+// out[t][j] = sum_i r_i (u_i k_i v_j + s_ij), accumulated over i = 0 .. 63 IN THAT ORDER (the reference's and the oracle's
+// loop), s_ij <- s_ij w_i + k_i v_j. One wave owns ONE value column j of a head; lane i owns the state element s_ij. The
+// ordered sum over i would be a 64-step dependent chain per token, so the chain is run as a systolic pipeline instead: at
+// step sigma lane i works on token sigma - i, adds its term to the running sum it receives from lane i - 1 (one DPP
+// wave_shr:1 add; lane 0 receives 0.0f, as the reference's `o = 0`), and lane 63 emits out[sigma - 63][j]. Every lane is
+// busy on a different token each step: ~10 VALU instructions per token and column, 64 x 64 x H lanes wide, instead of the
+// 64-step loop of one wave per head of the single-token form (k_wkv6). Per-token operands are read diagonally from an LDS
+// ring of 128 tokens (lane i reads row (sigma - i) mod 128, column i: conflict-free), refilled 64 tokens at a time through
+// registers, one pair of workgroup barriers per 64 steps. The workgroup = 8 waves = 8 adjacent columns of one head.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WMODE>
+__global__ __launch_bounds__(512) void k_wkv6_seq(const float * __restrict__ r, const float * __restrict__ k, const float * __restrict__ v,
+                                                  const float * __restrict__ u, int u_per_chan, const float * __restrict__ w,
+                                                  const float * __restrict__ state_in, float * __restrict__ state_out, float * __restrict__ out,
+                                                  int T, int H) {
+    constexpr int S = 64, RING = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float * l_k = reinterpret_cast<float *>(lds_raw);            // [RING][64]; l_r at +RING*64 floats, l_w at +2*RING*64 (immediate offsets of one address)
+    float * l_v = l_k + 3 * RING * 64;                            // [8][RING]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t h = blockIdx.x >> 3;
+    const int j = (int) (blockIdx.x & 7) * 8 + wave;
+    const int64_t D = (int64_t) H * S;
+    float s = state_in[h * S * S + (int64_t) lane * S + j];
+    const float ui = u_per_chan ? u[h * S + lane] : u[h];
+    const float wconst = WMODE == 2 ? 0.0f : (WMODE == 1 ? w[h * S + lane] : w[h]);
+    const int n_chunks = (T + 63 + 63) / 64;   // steps 0 .. T + 62
+
+    // staging registers: chunk c = tokens [64 c, 64 c + 64): 64 x 16 float4 per array, two per thread
+    float4 gk0, gk1, gr0, gr1, gw0 = make_float4(0.f, 0.f, 0.f, 0.f), gw1 = gw0;
+    float gv;
+    auto issue = [&](int c) {
+        int t0 = 64 * c + (tid >> 4), t1 = t0 + 32;
+        t0 = t0 < T ? t0 : T - 1;                     // (clamped rows are never used: their steps are masked)
+        t1 = t1 < T ? t1 : T - 1;
+        const int64_t o0 = (int64_t) t0 * D + h * S + (tid & 15) * 4, o1 = (int64_t) t1 * D + h * S + (tid & 15) * 4;
+        gk0 = *reinterpret_cast<const float4 *>(k + o0); gk1 = *reinterpret_cast<const float4 *>(k + o1);
+        gr0 = *reinterpret_cast<const float4 *>(r + o0); gr1 = *reinterpret_cast<const float4 *>(r + o1);
+        if (WMODE == 2) { gw0 = *reinterpret_cast<const float4 *>(w + o0); gw1 = *reinterpret_cast<const float4 *>(w + o1); }
+        int t = 64 * c + lane;
+        t = t < T ? t : T - 1;
+        gv = v[(int64_t) t * D + h * S + j];
+    };
+    auto commit = [&](int c) {
+        const int base = (c & 1) * 64;
+        const int row0 = base + (tid >> 4), row1 = row0 + 32, col = (tid & 15) * 4;
+        *reinterpret_cast<float4 *>(l_k + row0 * 64 + col) = gk0; *reinterpret_cast<float4 *>(l_k + row1 * 64 + col) = gk1;
+        *reinterpret_cast<float4 *>(l_k + RING * 64 + row0 * 64 + col) = gr0; *reinterpret_cast<float4 *>(l_k + RING * 64 + row1 * 64 + col) = gr1;
+        if (WMODE == 2) { *reinterpret_cast<float4 *>(l_k + 2 * RING * 64 + row0 * 64 + col) = gw0; *reinterpret_cast<float4 *>(l_k + 2 * RING * 64 + row1 * 64 + col) = gw1; }
+        l_v[wave * RING + base + lane] = gv;
+    };
+
+    issue(0);
+    float o_prev = 0.0f;
+    for (int c = 0; c < n_chunks; c++) {
+        __syncthreads();                 // every wave is done with the steps of chunk c - 1 (which still read chunk c - 2's half)
+        commit(c);
+        __syncthreads();
+        if (c + 1 < n_chunks) issue(c + 1);
+        float cap = 0.0f;                // lane q captures what lane 63 emits at step 64 c + q: out[64 c + q - 63][j]
+#pragma unroll 1
+        for (int q0 = 0; q0 < 64; q0 += 4) {
+            // the LDS reads of four steps go out together; the dependent chain runs behind them
+            float kk[4], rr[4], ww[4], vv[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int t = 64 * c + q0 + e - lane;
+                const int slot = t & (RING - 1);
+                kk[e] = l_k[slot * 64 + lane];
+                rr[e] = l_k[RING * 64 + slot * 64 + lane];
+                ww[e] = WMODE == 2 ? l_k[2 * RING * 64 + slot * 64 + lane] : wconst;
+                vv[e] = l_v[wave * RING + slot];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int t = 64 * c + q0 + e - lane;
+                const bool valid = t >= 0 && t < T;
+                const float kv = vv[e] * kk[e];
+                const float ku = kv * ui;
+                const float temp = ku + s;
+                const float p = temp * rr[e];
+                const float sw = s * ww[e];
+                const float sn = sw + kv;
+                // running sum from lane i - 1 (same token, previous step); lane 0 starts from 0.0f like the reference's `o = 0`
+                const float o_in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o_prev), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+                o_prev = o_in + p;
+                s = valid ? sn : s;
+                const float emitted = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o_prev), 63));
+                cap = lane == q0 + e ? emitted : cap;
+            }
+        }
+        const int t_out = 64 * c + lane - 63;
+        if (t_out >= 0 && t_out < T) out[(int64_t) t_out * D + h * S + j] = cap;
+    }
+    state_out[h * S * S + (int64_t) lane * S + j] = s;
+}
+
+// RWKV-6 data-dependent mixes over a sequence (rwkv_graph.inc:323-346; same statement order as k_v6_mix2): thread = (f, d) keeps
+// its R columns of W2 in registers across a tile of tokens; the tokens' tanh'ed low-rank vectors sit in LDS (broadcast reads).
+template <int R, int TT>
+__global__ __launch_bounds__(256) void k_v6_mix2_seq(V6Mix2Args a, int T, int D) {
+    __shared__ __attribute__((aligned(16))) float l_tl[TT * R];
+    const int dblocks = D / 256;
+    const int f = blockIdx.x / dblocks, d = (blockIdx.x % dblocks) * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * TT;
+    float wc[R];
+    const float * col = a.w2 + (int64_t) f * R * D + d;   // W2 transposed at load: [5][R][D]
+#pragma unroll
+    for (int m = 0; m < R; m++) wc[m] = col[(int64_t) m * D];
+    const float maa = a.maa[f][d];
+    for (int i = threadIdx.x; i < TT * R; i += 256) {
+        const int tt = i / R, m = i - tt * R;
+        l_tl[i] = t0 + tt < T ? a.tl[(int64_t) (t0 + tt) * 5 * R + f * R + m] : 0.0f;
+    }
+    __syncthreads();
+    const int tn = T - t0 < TT ? T - t0 : TT;
+    for (int tt = 0; tt < tn; tt++) {
+        const float4 * tl4 = reinterpret_cast<const float4 *>(l_tl + tt * R);
+        float acc = 0.0f;
+#pragma unroll
+        for (int m4 = 0; m4 < R / 4; m4++) {
+            const float4 t4 = tl4[m4];
+            float pr;
+            pr = wc[4 * m4] * t4.x; acc += pr;
+            pr = wc[4 * m4 + 1] * t4.y; acc += pr;
+            pr = wc[4 * m4 + 2] * t4.z; acc += pr;
+            pr = wc[4 * m4 + 3] * t4.w; acc += pr;
+        }
+        const int64_t o = (int64_t) (t0 + tt) * D + d;
+        const float mm = (acc + maa) * a.sx[o];
+        a.out[f][o] = mm + a.xn[o];
+    }
+}
+
+bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, hipStream_t st) {
+    constexpr int TT = 32;
+    if (D % 256 != 0 || !(R == 32 || R == 64)) return false;
+    const dim3 grid((unsigned) (5 * D / 256), (unsigned) ((T + TT - 1) / TT));
+    if (R == 32) hipLaunchKernelGGL((k_v6_mix2_seq<32, TT>), grid, dim3(256), 0, st, a, (int) T, (int) D);
+    else hipLaunchKernelGGL((k_v6_mix2_seq<64, TT>), grid, dim3(256), 0, st, a, (int) T, (int) D);
+    return true;
+}
+
+bool launch_wkv6_seq(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
+                     const float * state_in, float * state_out, float * out, int64_t T, int64_t H, hipStream_t st) {
+    const size_t lds = (size_t) (3 * 128 * 64 + 8 * 128) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) k_wkv6_seq<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) k_wkv6_seq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) k_wkv6_seq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned) (H * 8));
+    switch (w_mode) {
+        case 0: hipLaunchKernelGGL((k_wkv6_seq<0>), grid, dim3(512), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
+        case 1: hipLaunchKernelGGL((k_wkv6_seq<1>), grid, dim3(512), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
+        default: hipLaunchKernelGGL((k_wkv6_seq<2>), grid, dim3(512), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+
+// visiting order of the blocks of a row of nb blocks (see the header): leaves in bit-reversed order, a leaf's blocks ascending.
+// `out`: the blocks alone (what the staging reads); `walk`: one entry per block plus one per leaf without blocks, with the merge
+// code of the kernel (0 = leaf continues; m + 1 = leaf ends, m = trailing one bits of the leaf's number in visiting order).
+static void walk_order(int nb, std::vector<unsigned short> & out, std::vector<unsigned> & walk) {
+    out.clear(); walk.clear();
+    for (int c = 0; c < 64; c++) {
+        int l = 0, m = 0;
+        for (int k = 0; k < 6; k++) if (c & (1 << k)) l |= 1 << (5 - k);
+        while (m < 6 && (c & (1 << m))) m++;
+        const size_t first = walk.size();
+        for (int b = l; b < nb; b += 64) { out.push_back((unsigned short) b); walk.push_back((unsigned) b); }
+        if (walk.size() == first) walk.push_back(0xFFFFu);
+        walk.back() |= (unsigned) (m + 1) << 16;
+    }
+}
+
+static std::mutex g_pf_mu;
+
+// device tables per (device, row length): a few hundred bytes each, kept for the life of the process
+struct WalkTab { unsigned short * order; unsigned * walk; int n_walk; };
+static std::unordered_map<long long, WalkTab> g_walk_tables;
+
+static const WalkTab * walk_table(int nb) {
+    std::lock_guard<std::mutex> lk(g_pf_mu);
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    const long long key = ((long long) dev << 32) | (unsigned) nb;
+    auto & walk_tables = g_walk_tables;
+    auto it = walk_tables.find(key);
+    if (it != walk_tables.end()) return &it->second;
+    std::vector<unsigned short> o;
+    std::vector<unsigned> wk;
+    walk_order(nb, o, wk);
+    unsigned char * d = nullptr;
+    const size_t ob = (o.size() * sizeof(unsigned short) + 255) / 256 * 256;
+    if (hipMalloc((void **) &d, ob + wk.size() * sizeof(unsigned) + 64) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, o.data(), o.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + ob, wk.data(), wk.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(d); return nullptr; }
+    WalkTab wt{(unsigned short *) d, (unsigned *) (d + ob), (int) wk.size()};
+    walk_tables[key] = wt;
+    return &walk_tables[key];
+}
+
+// builds (once) the tile-major image of a quantised matrix
+bool ensure_pf(const DevTensor & W, hipStream_t st) {
+    if (W.pf_qs) return true;
+    std::lock_guard<std::mutex> lk(g_pf_mu);
+    if (W.pf_qs) return true;
+    const int64_t N = W.rows();
+    const int nb = (int) (W.cols() / 32);
+    const int64_t RT = (N + 31) / 32;
+    const bool q8 = W.type == T_Q8_0, qh = W.type == T_Q5_0 || W.type == T_Q5_1;
+    const size_t n_qs = (size_t) RT * nb * 32 * (q8 ? 32 : 16), n_sc = (size_t) RT * nb * 32 * 4;
+    const size_t total = n_qs + n_sc + (qh ? n_sc : 0);
+    uint8_t * base = nullptr;
+    if (hipMalloc((void **) &base, total) != hipSuccess) return false;
+    uint32_t * psc = reinterpret_cast<uint32_t *>(base + n_qs);
+    uint32_t * pqh = qh ? reinterpret_cast<uint32_t *>(base + n_qs + n_sc) : nullptr;
+    const int64_t n_thr = RT * nb * 32;
+    hipLaunchKernelGGL(k_pf_repack, dim3((unsigned) ((n_thr + 255) / 256)), dim3(256), 0, st, W.type, W.qs, W.qh, W.sc, N, nb, base, psc, pqh);
+    if (hipStreamSynchronize(st) != hipSuccess) { (void) hipFree(base); return false; }
+    W.pf_sc = psc; W.pf_qh = pqh; W.pf_rows = RT * 32;
+    W.pf_qs = base;   // published last
+    return true;
+}
+
+void free_pf(const DevTensor & W) {
+    if (W.pf_qs) (void) hipFree(W.pf_qs);
+    W.pf_qs = nullptr; W.pf_sc = nullptr; W.pf_qh = nullptr;
+}
+
+size_t tile_act_bytes(int64_t T, int64_t K) {
+    const int64_t T_pad = (T + 63) / 64 * 64;
+    return (size_t) T_pad * K + 3 * (size_t) T_pad * (K / 32) * 4 + 1024;
+}
+
+TileAct tile_act_at(void * base, int64_t T, int64_t K) {
+    const int64_t T_pad = (T + 63) / 64 * 64;
+    TileAct a;
+    a.q = (int8_t *) base;
+    a.d = (float *) ((uint8_t *) base + (((size_t) T_pad * K + 255) / 256) * 256);
+    a.s = a.d + T_pad * (K / 32);
+    a.o = a.s + T_pad * (K / 32);
+    a.T_pad = T_pad;
+    return a;
+}
+
+void launch_quantize_act_tiles(const float * x, int64_t T, int64_t K, int wtype, const TileAct & out, hipStream_t st) {
+    const int nb = (int) (K / 32);
+    const int64_t n_tiles = (out.T_pad / 32) * nb;
+    const float dscale = wtype == T_Q4_0 ? 0.0625f : 1.0f;
+    const bool hm = wtype == T_Q4_1 || wtype == T_Q5_1, xo = wtype == T_Q5_0;
+    hipLaunchKernelGGL(k_quant_act_tiles, dim3((unsigned) ((n_tiles + 3) / 4)), dim3(256), 0, st, x, T, out.T_pad, nb, dscale, 16.0f,
+                       out.q, out.d, hm ? out.s : nullptr, xo ? out.o : nullptr);
+}
+
+template <int FMT>
+static bool launch_mmq_mfma_t(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
+    typedef MF<FMT> M;
+    const int64_t N = W.rows();
+    const int nb = (int) (W.cols() / 32);
+    const WalkTab * wt = walk_table(nb);
+    if (!wt || !ensure_pf(W, st)) return false;
+    const int RT = (int) ((N + 31) / 32), RP = (RT + M::RGN - 1) / M::RGN, C = (int) ((T + 63) / 64);
+    const size_t lds = (size_t) 16 * M::SLOT;
+    static bool attr_set = false;
+    if (!attr_set) { (void) hipFuncSetAttribute((const void *) k_mmq_mfma<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr_set = true; }
+    const unsigned grid = (unsigned) (((RP + 7) / 8) * 8 * C);
+    PfW pw{W.pf_qs, W.pf_sc, W.pf_qh};
+    PfX px{x.q, x.d, x.s, x.o};
+    hipLaunchKernelGGL((k_mmq_mfma<FMT>), dim3(grid), dim3(M::NT), lds, st, pw, px, N, nb, T, RT, C, wt->order, y, ldy, epi);
+    return true;
+}
+
+bool launch_mmq_mfma(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
+    switch (W.type) {
+        case T_Q4_0: return launch_mmq_mfma_t<T_Q4_0>(W, x, T, y, ldy, epi, st);
+        case T_Q4_1: return launch_mmq_mfma_t<T_Q4_1>(W, x, T, y, ldy, epi, st);
+        case T_Q5_0: return launch_mmq_mfma_t<T_Q5_0>(W, x, T, y, ldy, epi, st);
+        case T_Q5_1: return launch_mmq_mfma_t<T_Q5_1>(W, x, T, y, ldy, epi, st);
+        case T_Q8_0: return launch_mmq_mfma_t<T_Q8_0>(W, x, T, y, ldy, epi, st);
+        default: return false;
+    }
+}
+
+}  // namespace rwkvmi

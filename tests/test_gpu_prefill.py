@@ -1,0 +1,79 @@
+"""Sequence mode on the matrix cores (prefill.hip): the int8 MFMA GEMM, the tile-major activation quantiser and the lane-pipelined
+WKV-5/6 kernel against the CPU oracle -- bit for bit, like the single-token path (the reference guarantees and tests
+serial == sequence with memcmp, tests/test_eval_sequence_in_chunks.c:54; here it holds for every weight format)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_lib import gpu_mul_mat, library, model, synth
+
+pytestmark = pytest.mark.gpu
+
+QFORMATS = ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0"]
+
+
+def _weights(rng, fmt, K, N):
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    t = O.TYPE_IDS[fmt]
+    return t, np.concatenate([O.quantize_row(t, w[n]) for n in range(N)])
+
+
+# K: 64 = 2 blocks (RWKV-6 decay_w2), 768 / 2560 = 24 / 80 blocks (partial leaf set), 2048 = exactly 64 leaves, 4096 / 7168 / 14336 = 2 / 3.5 / 7
+# blocks per leaf. N: below a row tile, ragged row tiles, more than one 128-row panel. T: one MFMA tile, ragged, several 64-token tiles.
+@pytest.mark.parametrize("fmt", QFORMATS)
+@pytest.mark.parametrize("K,N,T", [(64, 40, 32), (768, 70, 33), (2560, 130, 64), (2048, 160, 100), (4096, 129, 65), (7168, 33, 130), (14336, 64, 40)])
+def test_mfma_gemm_matches_oracle(fmt, K, N, T):
+    rng = np.random.default_rng(K * 3 + N + T)
+    t, wb = _weights(rng, fmt, K, N)
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    x[0, :32] *= 40.0
+    x[T - 1] *= 0.01
+    x[T // 2, 32:64] = 0.0          # an all-zero block (d = 0)
+    y = gpu_mul_mat(t, wb, K, N, x)
+    ref = O.mul_mat(t, wb, K, N, x)
+    assert np.array_equal(y, ref), (fmt, K, N, T, float(np.abs(y - ref).max()))
+    for i in (0, T // 2, T - 1):     # ... and identical to the single-token kernel
+        assert np.array_equal(gpu_mul_mat(t, wb, K, N, x[i])[0], y[i])
+
+
+@pytest.mark.parametrize("name,fmt", [("test-v6", "Q4_0"), ("test-v6", "Q5_1"), ("test-v6", "Q8_0"), ("test-v5.2", "Q4_1"), ("test-v5.1", "Q5_0"),
+                                      ("test-v4", "Q4_0"), ("test-v7", "Q8_0"), ("test-v6", "FP16")])
+@pytest.mark.parametrize("T", [32, 97])
+def test_sequence_pass_matches_oracle_and_serial(tmp_path, name, fmt, T):
+    library()
+    src = str(tmp_path / "f.bin")
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS[name]
+    if fmt == "FP16":
+        synth.write_model(p, spec, "FP16", seed=31)
+    else:
+        synth.write_model(src, spec, "FP32", seed=31)
+        O.quantize_file(src, p, fmt)
+    toks = [int((1103515245 * i + 12345) % spec.n_vocab) for i in range(T)]
+    om = O.OracleModel(p)
+    ol, ost = om.eval_sequence(toks, om.init_state())
+    m = model(p)
+    gl, gst = m.eval_sequence(toks, None)
+    assert np.array_equal(gl, ol), (name, fmt, T, float(np.abs(gl - ol).max()))
+    assert np.array_equal(gst, ost), (name, fmt, T, float(np.abs(gst - ost).max()))
+    # chunked: a GEMM pass of 40 tokens, then single tokens / small tiles on the other kernels
+    cl, cst = m.eval_sequence_in_chunks(toks, None, chunk_size=40)
+    assert np.array_equal(cl, ol) and np.array_equal(cst, ost)
+    m.free()
+    om.free()
+
+
+def test_sequence_pass_on_the_real_head_geometry(tmp_path):
+    """RWKV-6 with D = 2048 (32 heads of 64, 64 leaves per row, ffn rows of 3.5 blocks per leaf): 3 layers, 200 tokens."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS["mega-v6-2048"]
+    synth.write_model(p, spec, "Q4_0", seed=41)
+    toks = [int((1103515245 * i + 12345) % spec.n_vocab) for i in range(200)]
+    om = O.OracleModel(p)
+    ol, ost = om.eval_sequence(toks, om.init_state())
+    m = model(p)
+    gl, gst = m.eval_sequence(toks, None)
+    assert np.array_equal(gl, ol) and np.array_equal(gst, ost)
+    m.free()
+    om.free()
