@@ -346,7 +346,7 @@ RWKV_API bool rwkv_mi_decode_healthy(struct rwkv_context * ctx) {
     return !(ctx->mega && mega_v6_aborted(ctx->mega, ctx->stream));
 }
 
-RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx) { return ctx->mega ? 2 : (ctx->fused_v6 ? 1 : 0); }
+RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx) { return ctx->mega ? 2 : ((ctx->fused_v6 || ctx->fused_v7 || ctx->fused_v4) ? 1 : 0); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Layer pipeline (one process per GPU; the hand-off itself is done by the caller with RCCL send/recv)

@@ -160,6 +160,14 @@ rwkv_context * create_context(Model * m, uint32_t n_threads) {
         if (ctx->mega && mega_chain_count(ctx.get(), +1) > 1) (void) hipDeviceSynchronize();
         calibrate_decode_path(ctx.get());
     }
+    if (!(nf && nf[0] == '1') && fused_v7_supported(*m)) {
+        if ((e = hipMalloc(&ctx->fused_scratch, fused_v7_scratch_bytes(*m))) != hipSuccess) return fail(e);
+        ctx->fused_v7 = true;
+    }
+    if (!(nf && nf[0] == '1') && fused_v4_supported(*m)) {
+        if ((e = hipMalloc(&ctx->fused_scratch, fused_v4_scratch_bytes(*m))) != hipSuccess) return fail(e);
+        ctx->fused_v4 = true;
+    }
     // A new context starts from the reference's fresh state (rwkv_eval.inc:224-241), whatever the calibration left behind:
     // rwkv_mi_eval_resident / rwkv_mi_decode_greedy / rwkv_mi_stage_step continue from the resident state without a load.
     ctx->cur = 0;
@@ -417,6 +425,8 @@ struct Runner {
             const float * li = sin + (int64_t) i * per_layer;
             float * lo = sout + (int64_t) i * per_layer;
             if (T == 1 && ctx->fused_v6) { fused_v6_layer(m, L, b.x, li, lo, ctx->fused_scratch, st, &ctx->prof); continue; }
+            if (T == 1 && ctx->fused_v4) { fused_v4_layer(m, L, b.x, li, lo, ctx->fused_scratch, st, &ctx->prof); continue; }
+            if (T == 1 && ctx->fused_v7) { fused_v7_layer(m, L, (int) i, b.x, b.v_first, li, lo, ctx->fused_scratch, st, &ctx->prof); continue; }
             switch (m.arch_major) {
                 case 4: att_v4(L, li, lo); break;
                 case 5: att_v5(L, li, lo); break;

@@ -300,6 +300,8 @@ struct P6F {
     float * r_out;  // D floats (raw Wr xr)
     int64_t D, F;
     int groups_per_block;
+    int mix_mode;   // 1: x_f = (x_prev - xn) * c_f + xn (v6, v7);  0: x_f = xn * c_f + (x_prev - x_prev * c_f) (v4, v5)
+    int64_t r_rows; // rows of the receptance matrix handled here (D, or 0: RWKV-7 has none)
 };
 
 // Workgroup = 8 waves owning up to three 32-row groups (key groups first, then receptance groups): about one workgroup per
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool pro = threadIdx.x < 256;
 
-    const int64_t GK = F / 32, GT = GK + D / 32;
+    const int64_t GK = F / 32, GT = GK + p.r_rows / 32;
     const int gpb = p.groups_per_block;
     const int64_t g0 = (int64_t) blockIdx.x * gpb;
     const int ng = (int) ((GT - g0) < gpb ? (GT - g0) : gpb);
@@ -354,11 +356,18 @@ __global__ __launch_bounds__(512) void k6_ffn_kr(P6F p) {
         const float y = l_row[i] * scale;
         const float yw = y * lw;
         const float xn = yw + lb;
-        const float sx = pv - xn;
-        const float sk = sx * mk;
-        xk = sk + xn;
-        const float sr = sx * mr;
-        xr = sr + xn;
+        if (p.mix_mode == 1) {
+            const float sx = pv - xn;
+            const float sk = sx * mk;
+            xk = sk + xn;
+            const float sr = sx * mr;
+            xr = sr + xn;
+        } else {
+            const float xck = xn * mk, pck = pv * mk;
+            xk = xck + (pv - pck);
+            const float xcr = xn * mr, pcr = pv * mr;
+            xr = xcr + (pv - pcr);
+        }
         if (blockIdx.x == 0) p.ffn_xx_out[i] = xn;
     };
     int64_t i0 = threadIdx.x;
@@ -512,12 +521,58 @@ static void fused_v6_layer_t(const Model & m, const LayerW & L, float * x, const
 
     const int64_t groups = F / 32 + D / 32;
     const int gpb = (int) ((groups + 255) / 256) < 3 ? (int) ((groups + 255) / 256) : 3;   // ~one workgroup per CU: the prologue runs once per CU
-    P6F ff{x, f(L.ln2_w), f(L.ln2_b), sin, f(L.ffn_time_maa_k), f(L.ffn_time_maa_r), sout, planes(L.ffn_key), planes(L.ffn_receptance), s.kq, s.rr, D, F, gpb};
+    P6F ff{x, f(L.ln2_w), f(L.ln2_b), sin, f(L.ffn_time_maa_k), f(L.ffn_time_maa_r), sout, planes(L.ffn_key), planes(L.ffn_receptance), s.kq, s.rr, D, F, gpb, 1, D};
     launch6(pf, L.ffn_key->nbytes + L.ffn_receptance->nbytes + D * 12 + qvec_bytes(F) + D * 4, k6_ffn_kr<FMT>, dim3((unsigned) ((groups + gpb - 1) / gpb)), dim3(512),
             (size_t) D * 4 + 2 * qbD + 512 * 8 + (size_t) gpb * 32 * 4, st, ff);
 
     P6E g{planes(L.ffn_value), s.kq, x, s.rr, D, F};
     launch6(pf, L.ffn_value->nbytes + qvec_bytes(F) + D * 12, k6_proj_res<FMT, 4, 4, true>, dim3((unsigned) ((D + 15) / 16)), dim3(256), ((qvec_bytes(F) + 15) / 16) * 16, st, g);
+}
+
+// ---- the projection / channel-mixing launches shared with the other architectures' fused layers (fused_v7.hip, fused_v4.hip) ----
+template <int FMT>
+static void fused_proj_res_t(const DevTensor * W, const void * act, float * x, const float * rgate, int64_t N, int64_t K, bool long_rows, hipStream_t st, rwkv_context::Prof * pf) {
+    P6E e{planes(W), act, x, rgate, N, K};
+    const uint64_t bytes = W->nbytes + qvec_bytes(K) + (uint64_t) N * (rgate ? 12 : 8);
+    const size_t shm = ((qvec_bytes(K) + 15) / 16) * 16;
+    // rows per wave: 4 unless that leaves CUs without a workgroup (N / 16 workgroups), then 2
+    const bool small = (N + 15) / 16 < 224;
+    if (long_rows && small) launch6(pf, bytes, k6_proj_res<FMT, 2, 4, true>, dim3((unsigned) ((N + 7) / 8)), dim3(256), shm, st, e);
+    else if (long_rows) launch6(pf, bytes, k6_proj_res<FMT, 4, 4, true>, dim3((unsigned) ((N + 15) / 16)), dim3(256), shm, st, e);
+    else if (small) launch6(pf, bytes, k6_proj_res<FMT, 2, 2, false>, dim3((unsigned) ((N + 7) / 8)), dim3(256), shm, st, e);
+    else launch6(pf, bytes, k6_proj_res<FMT, 4, 2, false>, dim3((unsigned) ((N + 15) / 16)), dim3(256), shm, st, e);
+}
+void fused_proj_res(int fmt, const DevTensor * W, const void * act, float * x, const float * rgate, int64_t N, int64_t K, bool long_rows, hipStream_t st, rwkv_context::Prof * pf) {
+    switch (fmt) {
+        case T_Q4_0: fused_proj_res_t<T_Q4_0>(W, act, x, rgate, N, K, long_rows, st, pf); break;
+        case T_Q4_1: fused_proj_res_t<T_Q4_1>(W, act, x, rgate, N, K, long_rows, st, pf); break;
+        case T_Q5_0: fused_proj_res_t<T_Q5_0>(W, act, x, rgate, N, K, long_rows, st, pf); break;
+        case T_Q5_1: fused_proj_res_t<T_Q5_1>(W, act, x, rgate, N, K, long_rows, st, pf); break;
+        case T_Q8_0: fused_proj_res_t<T_Q8_0>(W, act, x, rgate, N, K, long_rows, st, pf); break;
+        default: break;
+    }
+}
+template <int FMT>
+static void fused_ffn_kr_t(const float * x, const float * ln_w, const float * ln_b, const float * xx_in, float * xx_out, const float * maa_k, const float * maa_r, int mix_mode,
+                           const DevTensor * wk, const DevTensor * wr, void * k_out, float * r_out, int64_t D, int64_t F, hipStream_t st, rwkv_context::Prof * pf) {
+    const int64_t r_rows = wr ? D : 0;
+    const int64_t groups = F / 32 + r_rows / 32;
+    const int gpb = (int) ((groups + 255) / 256) < 3 ? (int) ((groups + 255) / 256) : 3;   // (one group per workgroup with two workgroups per CU measured slower)
+    const size_t qbD = ((qvec_bytes(D) + 15) / 16) * 16;
+    P6F ff{x, ln_w, ln_b, xx_in, maa_k, maa_r, xx_out, planes(wk), wr ? planes(wr) : planes(wk), k_out, r_out, D, F, gpb, mix_mode, r_rows};
+    launch6(pf, wk->nbytes + (wr ? wr->nbytes : 0) + D * 12 + qvec_bytes(F) + r_rows * 4, k6_ffn_kr<FMT>, dim3((unsigned) ((groups + gpb - 1) / gpb)), dim3(512),
+            (size_t) D * 4 + 2 * qbD + 512 * 8 + (size_t) gpb * 32 * 4, st, ff);
+}
+void fused_ffn_kr(int fmt, const float * x, const float * ln_w, const float * ln_b, const float * xx_in, float * xx_out, const float * maa_k, const float * maa_r, int mix_mode,
+                  const DevTensor * wk, const DevTensor * wr, void * k_out, float * r_out, int64_t D, int64_t F, hipStream_t st, rwkv_context::Prof * pf) {
+    switch (fmt) {
+        case T_Q4_0: fused_ffn_kr_t<T_Q4_0>(x, ln_w, ln_b, xx_in, xx_out, maa_k, maa_r, mix_mode, wk, wr, k_out, r_out, D, F, st, pf); break;
+        case T_Q4_1: fused_ffn_kr_t<T_Q4_1>(x, ln_w, ln_b, xx_in, xx_out, maa_k, maa_r, mix_mode, wk, wr, k_out, r_out, D, F, st, pf); break;
+        case T_Q5_0: fused_ffn_kr_t<T_Q5_0>(x, ln_w, ln_b, xx_in, xx_out, maa_k, maa_r, mix_mode, wk, wr, k_out, r_out, D, F, st, pf); break;
+        case T_Q5_1: fused_ffn_kr_t<T_Q5_1>(x, ln_w, ln_b, xx_in, xx_out, maa_k, maa_r, mix_mode, wk, wr, k_out, r_out, D, F, st, pf); break;
+        case T_Q8_0: fused_ffn_kr_t<T_Q8_0>(x, ln_w, ln_b, xx_in, xx_out, maa_k, maa_r, mix_mode, wk, wr, k_out, r_out, D, F, st, pf); break;
+        default: break;
+    }
 }
 
 void fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf) {

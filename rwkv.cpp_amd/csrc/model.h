@@ -129,6 +129,8 @@ struct rwkv_context {
 
     // fused single-token path (fused_v6.hip) when the model qualifies
     bool  fused_v6 = false;
+    bool  fused_v7 = false;   // fused RWKV-7 layer (fused_v7.hip)
+    bool  fused_v4 = false;   // fused RWKV-4 / RWKV-5 layer (fused_v4.hip)
     void * fused_scratch = nullptr;
     // persistent whole-stage decode kernel (mega_v6.hip) when the model and the device qualify; takes precedence
     void * mega = nullptr;
@@ -162,6 +164,14 @@ bool forward(rwkv_context * ctx, int64_t T, bool want_logits);
 bool   fused_v6_supported(const Model & m);
 size_t fused_v6_scratch_bytes(const Model & m);
 void   fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf);
+// fused RWKV-7 decode layer (fused_v7.hip): six launches per layer
+bool   fused_v7_supported(const Model & m);
+size_t fused_v7_scratch_bytes(const Model & m);
+void   fused_v7_layer(const Model & m, const LayerW & L, int layer, float * x, float * v_first, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf);
+// fused RWKV-4 decode layer (fused_v7.hip): four launches per layer
+bool   fused_v4_supported(const Model & m);
+size_t fused_v4_scratch_bytes(const Model & m);
+void   fused_v4_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf);
 // persistent single-launch RWKV-6 decode over all layers of the stage (mega_v6.hip)
 void *   mega_v6_create(const Model & m);   // nullptr: not applicable
 void     mega_v6_destroy(void * h);
