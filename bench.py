@@ -125,6 +125,8 @@ def cpu_baseline(path, first_token, budget_s):
     import oracle_lib
     cores = usable_cores()
     oracle_lib.lib().orc_set_threads(cores)
+    oracle_lib.lib().orc_set_fast(1)   # AVX2 / AVX-512-VNNI row kernels (oracle/rwkv_oracle_fast.c): bit-identical to the scalar oracle
+    simd = "AVX-512-VNNI" if oracle_lib.lib().orc_fast_uses_vnni() else "AVX2"
     t0 = time.time()
     om = oracle_lib.OracleModel(path)
     load_s = time.time() - t0
@@ -140,8 +142,9 @@ def cpu_baseline(path, first_token, budget_s):
         if n >= 2 and (el + el / n > budget_s or n >= 64):
             break
     om.free()
-    return {"value": n / el, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{n} greedy decode tokens of the same model file on the host CPU ({el:.1f}s, load {load_s:.1f}s)"}, toks
+    return {"value": n / el, "unit": "tokens/s", "cores": cores, "kind": "port", "simd": simd,
+            "sample": f"{n} greedy decode tokens of the same model file on the host CPU ({el:.1f}s, load {load_s:.1f}s); "
+                      f"ggml's CPU algorithm restated with {simd} block dots, OpenMP over rows"}, toks
 
 
 KERNEL_NAMES = {2: "k6_mega (persistent decode kernel: all layers of the stage in one launch)",
@@ -249,6 +252,7 @@ def bench_prefill(args, pkg, lib, path, spec, torch):
     if args.parity_tokens > 0 and args.cpu_seconds > 0:
         import oracle_lib
         oracle_lib.lib().orc_set_threads(usable_cores())
+        oracle_lib.lib().orc_set_fast(1)
         om = oracle_lib.OracleModel(path)
         n = min(T, 48)
         t0 = time.time()

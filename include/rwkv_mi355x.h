@@ -30,6 +30,14 @@ RWKV_API bool rwkv_mi_eval_resident(struct rwkv_context * ctx, const uint32_t * 
  * time of the whole loop measured on the context's stream. */
 RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, uint32_t * tokens_out, float * elapsed_ms);
 
+/* Temperature / top-p sampling ON THE DEVICE from the logits of the last evaluation (the reference samples on the host:
+ * python/sampling.py:10-52 -- same statements: softmax, top-p cut-off, p^(1/temperature), renormalise, draw). temperature == 0: argmax;
+ * top_p == 0 means 1. u in [0, 1): the caller's uniform random number; u < 0: the context's counter-based generator with `seed`. */
+RWKV_API bool rwkv_mi_sample(struct rwkv_context * ctx, float temperature, float top_p, float u, uint64_t seed, uint32_t * token_out);
+/* Sampling decode loop entirely on the device (like rwkv_mi_decode_greedy, the sampled token feeds the next embedding lookup). */
+RWKV_API bool rwkv_mi_decode_sample(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, float temperature, float top_p, uint64_t seed,
+                                    uint32_t * tokens_out, float * elapsed_ms);
+
 /* Measurement aid: eager greedy decode with a HIP-event pair (on the context's stream) around every launch of the dominant
  * kernel -- the single-token projection of the model's quantised format. out[0] = summed kernel ms, out[1] = launches,
  * out[2] = summed algorithmic bytes (weight rows + quantised activation + outputs), out[3] = wall ms of the loop. */

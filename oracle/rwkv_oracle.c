@@ -362,6 +362,11 @@ void orc_quantize_act(const float * x, int64_t n, int8_t * q, float * dq, float 
 /* Knob for experiments only: 0 = keep activations f32 for F16 weights; 1 (default) = ggml's behaviour. */
 static int g_f16_round_act = 1;
 void orc_set_f16_act_rounding(int on) { g_f16_round_act = on; }
+/* SIMD row kernels (rwkv_oracle_fast.c): bit-identical, used by bench.py's cpu_baseline leg; off by default */
+static int g_fast = 0;
+void orc_set_fast(int on) { g_fast = on; }
+float orc_fast_row_q(int wtype, const uint8_t * row, const int8_t * q, const float * dq, const float * sq, const int32_t * xsum, int64_t nb);
+float orc_fast_row_f(int wtype, const uint8_t * row, const float * x, int64_t K);
 static int g_threads = 0;
 void orc_set_threads(int n) {
     g_threads = n;
@@ -397,6 +402,7 @@ void orc_mul_mat(int wtype, const void * Wv, int64_t K, int64_t N, const float *
             if (xr) { for (int64_t k = 0; k < K; k++) xr[k] = orc_f16_to_f32(orc_f32_to_f16(xt[k])); xt = xr; }
             #pragma omp parallel for schedule(static) if (N * K > 65536)
             for (int64_t n = 0; n < N; n++) {
+                if (g_fast && K % 32 == 0) { y[t * N + n] = orc_fast_row_f(wtype, W + (size_t) n * K * (wtype == ORC_F32 ? 4 : 2), xt, K); continue; }
                 float ps[32];
                 for (int i = 0; i < 32; i++) ps[i] = 0.0f;
                 if (wtype == ORC_F32) {
@@ -418,11 +424,14 @@ void orc_mul_mat(int wtype, const void * Wv, int64_t K, int64_t N, const float *
     int8_t * q = (int8_t *) malloc((size_t) K);
     float * dq = (float *) malloc((size_t) nb * sizeof(float) * 2);
     float * sq = dq + nb;
+    int32_t * xsum = g_fast ? (int32_t *) malloc((size_t) nb * sizeof(int32_t)) : NULL;
     for (int64_t t = 0; t < T; t++) {
         orc_quantize_act(x + t * K, K, q, dq, sq);
+        if (xsum) for (int64_t b = 0; b < nb; b++) { int32_t sm = 0; for (int j = 0; j < QK; j++) sm += q[b * QK + j]; xsum[b] = sm; }
         #pragma omp parallel for schedule(static) if (N * K > 65536)
         for (int64_t n = 0; n < N; n++) {
             const uint8_t * row = W + (size_t) n * nb * ts;
+            if (xsum) { y[t * N + n] = orc_fast_row_q(wtype, row, q, dq, sq, xsum, nb); continue; }
             float lanes[64];
             for (int i = 0; i < 64; i++) lanes[i] = 0.0f;
             for (int64_t b = 0; b < nb; b++) {
@@ -456,7 +465,7 @@ void orc_mul_mat(int wtype, const void * Wv, int64_t K, int64_t N, const float *
             y[t * N + n] = fold_f(lanes, 64);
         }
     }
-    free(q); free(dq);
+    free(q); free(dq); free(xsum);
 }
 
 /* ------------------------------------------------------------------------------------------------ */

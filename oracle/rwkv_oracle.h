@@ -42,6 +42,9 @@ size_t      orc_state_len(const orc_model * m);
 uint64_t    orc_bytes_per_token(const orc_model * m);
 void        orc_init_state(const orc_model * m, float * state);
 void        orc_set_threads(int n);
+/* 1: the projections use the SIMD row kernels of rwkv_oracle_fast.c (AVX2, AVX-512-VNNI when the CPU has it): bit-identical results */
+void        orc_set_fast(int on);
+int         orc_fast_uses_vnni(void);
 
 /* state_in may be NULL (fresh state); state_out / logits_out may be NULL. in/out may alias. Returns 0 on success. */
 int orc_eval(orc_model * m, uint32_t token, const float * state_in, float * state_out, float * logits_out);

@@ -281,6 +281,56 @@ RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_to
     return fetch_outputs(ctx, nullptr, nullptr);   // drains the stream; a poll time-out invalidates the whole run (state included)
 }
 
+static bool ensure_sampler(rwkv_context * ctx) {
+    if (!ctx->d_probs) HIP_CTX_OK(ctx, hipMalloc((void **) &ctx->d_probs, (size_t) ctx->model->n_vocab() * sizeof(float)));
+    if (!ctx->d_rng_counter) {
+        HIP_CTX_OK(ctx, hipMalloc((void **) &ctx->d_rng_counter, 64));
+        HIP_CTX_OK(ctx, hipMemsetAsync(ctx->d_rng_counter, 0, 64, ctx->stream));
+    }
+    return true;
+}
+
+// Samples one token from the logits of the last evaluation on the device (reference: python/sampling.py sample_logits, run there on
+// the host after downloading the logits). u in [0, 1): the caller's uniform random number; u < 0: the context's generator (seed).
+RWKV_API bool rwkv_mi_sample(struct rwkv_context * ctx, float temperature, float top_p, float u, uint64_t seed, uint32_t * token_out) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, temperature >= 0.0f && top_p >= 0.0f && top_p <= 1.0f && u < 1.0f && token_out, "bad sampling arguments");
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, ctx->model->has_head, "this stage has no head");
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    if (!ensure_sampler(ctx)) return false;
+    launch_sample(ctx->d_logits, (int) ctx->model->n_vocab(), temperature, top_p, u, seed, ctx->d_rng_counter, ctx->d_probs, ctx->d_next_token, nullptr, 0, ctx->stream);
+    HIP_CTX_OK(ctx, hipMemcpyAsync(token_out, ctx->d_next_token, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return true;
+}
+
+// Sampling decode loop entirely on the device: feeds first_token, then n_tokens - 1 times a token sampled (temperature, top_p, generator
+// seeded with `seed`) from the previous logits. tokens_out[i] = token sampled after step i.
+RWKV_API bool rwkv_mi_decode_sample(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, float temperature, float top_p, uint64_t seed,
+                                    uint32_t * tokens_out, float * elapsed_ms) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    const size_t n_vocab = (size_t) ctx->model->n_vocab();
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, first_token < n_vocab && n_tokens > 0, "bad arguments");
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, temperature >= 0.0f && top_p >= 0.0f && top_p <= 1.0f, "bad sampling arguments");
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    if (!upload_tokens(ctx, &first_token, 1) || !ensure_sampler(ctx)) return false;
+    HIP_CTX_OK(ctx, hipMemsetAsync(ctx->d_rng_counter, 0, 8, ctx->stream));
+    struct DevBuf { uint32_t * p = nullptr; ~DevBuf() { if (p) (void) hipFree(p); } } hist;
+    HIP_CTX_OK(ctx, hipMalloc((void **) &hist.p, n_tokens * sizeof(uint32_t)));
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_CTX_OK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (size_t i = 0; i < n_tokens; i++) {
+        if (!forward_decode(ctx, true)) return false;
+        // the sampled token is written where the embedding kernel of the next step reads it
+        launch_sample(ctx->d_logits, (int) n_vocab, temperature, top_p, -1.0f, seed, ctx->d_rng_counter, ctx->d_probs, ctx->d_tokens, hist.p, (int) i, ctx->stream);
+    }
+    HIP_CTX_OK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (tokens_out) HIP_CTX_OK(ctx, hipMemcpyAsync(tokens_out, hist.p, n_tokens * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (!fetch_outputs(ctx, nullptr, nullptr)) return false;
+    if (elapsed_ms) HIP_CTX_OK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return true;
+}
+
 // Eager (graph-free) greedy decode with a HIP-event pair around every launch of the dominant kernel.
 // out[0] = summed kernel time (ms), out[1] = launches, out[2] = summed algorithmic bytes, out[3] = wall ms of the loop.
 RWKV_API bool rwkv_mi_profile_decode(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, double * out) {

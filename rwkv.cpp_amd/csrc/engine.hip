@@ -192,6 +192,8 @@ void destroy_context(rwkv_context * ctx) {
     if (ctx->d_tokens) (void) hipFree(ctx->d_tokens);
     if (ctx->d_logits) (void) hipFree(ctx->d_logits);
     if (ctx->d_next_token) (void) hipFree(ctx->d_next_token);
+    if (ctx->d_probs) (void) hipFree(ctx->d_probs);
+    if (ctx->d_rng_counter) (void) hipFree(ctx->d_rng_counter);
     if (ctx->h_tokens) (void) hipHostFree(ctx->h_tokens);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);

@@ -77,6 +77,11 @@ bool launch_wkv6_seq(const float * r, const float * k, const float * v, const fl
 bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, hipStream_t st);
 constexpr int64_t k_mfma_min_tokens = 32;   // sequence calls of at least this many tokens per pass take the GEMM path
 
+// temperature / top-p sampling on the logits in HBM (sampling.hip). u < 0: draw from the counter-based generator (seed, *counter; the
+// counter is advanced on the device). The token is written to out_token (and to hist[hist_pos] when hist is given).
+void launch_sample(const float * logits, int n, float temperature, float top_p, float u, unsigned long long seed, unsigned long long * counter,
+                   float * probs, uint32_t * out_token, uint32_t * hist, int hist_pos, hipStream_t st);
+
 // Loads [layer_begin, layer_end) of the file (layer_end == UINT32_MAX: all layers) onto the current HIP device.
 // Returns nullptr with the thread-local error set, like the reference loader (rwkv_model_loading.inc:288-419).
 Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end);
@@ -115,6 +120,8 @@ struct rwkv_context {
     int64_t    d_tokens_cap = 0;
     float *    d_logits = nullptr;
     uint32_t * d_next_token = nullptr;
+    float *    d_probs = nullptr;                 // sampler scratch (n_vocab floats), allocated on first use
+    unsigned long long * d_rng_counter = nullptr;
 
     // pinned host staging for tokens / logits
     uint32_t * h_tokens = nullptr;

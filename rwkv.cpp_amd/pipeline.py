@@ -319,16 +319,22 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
     bpt = torch.tensor([ex.bytes_per_token()], dtype=torch.float64, device=red_dev)
     dist.all_reduce(bpt, op=dist.ReduceOp.SUM)
     total_tok_s = world * args.steps / multi
+    single_tok_s = args.steps / single
+    # BASELINE.json's metric is SINGLE-STREAM tokens/s at 1 / 2 / 4 / 8 GPUs: that is `value` (total work fixed -> "strong"). A layer
+    # pipeline cannot make one stream faster (layers are sequential, each hop adds latency); what it buys -- `world` independent
+    # streams keeping every stage busy -- is reported beside it, never as the headline.
     result = {
-        "metric": "tokens/sec single-stream decode", "value": total_tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": multi * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "tokens/sec single-stream decode", "value": single_tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": single * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "int8 x int4 dot, f32 accumulate (Q4_0 weights, Q8_0 activations); f16 head", "data": "synthetic",
-        "config": {"workload": f"{spec.name} {args.dtype} greedy decode, layer pipeline over RCCL send/recv, {world} independent decode "
-                               f"streams in flight (one step = one token on every stream), state resident in HBM",
+        "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode through a layer pipeline of {world} GPUs (RCCL send/recv of the "
+                               f"residual stream between stages), state resident in HBM",
                    "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": f"pp{world}", "stage_layers": ranges, "stage_decode_path": path_used},
-        "single_stream": {"tokens_per_s": args.steps / single, "ms_per_token": single * 1e3 / args.steps,
-                          "note": "one stream through the same pipeline: layers are sequential, so this cannot exceed the 1-GPU rate"},
-        "hbm": {"algorithmic_bytes_per_token": int(bpt.item()), "achieved_GBps_aggregate": bpt.item() * total_tok_s / 1e9},
+        "multi_stream": {"streams": world, "tokens_per_s_aggregate": total_tok_s, "ms_per_step": multi * 1e3 / args.steps,
+                         "note": f"{world} independent decode streams in flight through the same pipeline (one step = one token on every stream): "
+                                 "aggregate throughput, weak scaling"},
+        "hbm": {"algorithmic_bytes_per_token": int(bpt.item()), "achieved_GBps_single_stream": bpt.item() * single_tok_s / 1e9,
+                "achieved_GBps_aggregate": bpt.item() * total_tok_s / 1e9},
     }
     ex.close()
     return result

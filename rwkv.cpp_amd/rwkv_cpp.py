@@ -113,6 +113,10 @@ class RWKVSharedLibrary:
         L.rwkv_mi_decode_path.restype = ctypes.c_int
         L.rwkv_mi_decode_healthy.argtypes = [c_ctx]
         L.rwkv_mi_decode_healthy.restype = ctypes.c_bool
+        L.rwkv_mi_sample.argtypes = [c_ctx, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, P_UINT32]
+        L.rwkv_mi_sample.restype = ctypes.c_bool
+        L.rwkv_mi_decode_sample.argtypes = [c_ctx, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, P_UINT32, P_FLOAT]
+        L.rwkv_mi_decode_sample.restype = ctypes.c_bool
         L.rwkv_mi_test_set_tag.argtypes = [c_ctx, ctypes.c_uint32]
         L.rwkv_mi_test_set_tag.restype = ctypes.c_bool
 
@@ -304,6 +308,21 @@ class RWKVModel:
         ms = ctypes.c_float(0.0)
         if not self._library.library.rwkv_mi_decode_greedy(self._ctx.ptr, first_token, n_tokens, ctypes.cast(out.ctypes.data, P_UINT32), ctypes.byref(ms)):
             raise ValueError("rwkv_mi_decode_greedy failed")
+        return out, float(ms.value)
+
+    def sample(self, temperature: float = 1.0, top_p: float = 0.8, u: float = -1.0, seed: int = 0) -> int:
+        """Samples from the logits of the last evaluation on the device (mirror of the reference's sampling.sample_logits)."""
+        tok = ctypes.c_uint32(0)
+        if not self._library.library.rwkv_mi_sample(self._ctx.ptr, temperature, top_p, u, seed, ctypes.byref(tok)):
+            raise ValueError("rwkv_mi_sample failed")
+        return int(tok.value)
+
+    def decode_sample(self, first_token: int, n_tokens: int, temperature: float = 1.0, top_p: float = 0.8, seed: int = 0) -> Tuple[np.ndarray, float]:
+        out = np.empty(n_tokens, dtype=np.uint32)
+        ms = ctypes.c_float(0.0)
+        if not self._library.library.rwkv_mi_decode_sample(self._ctx.ptr, first_token, n_tokens, temperature, top_p, seed,
+                                                           ctypes.cast(out.ctypes.data, P_UINT32), ctypes.byref(ms)):
+            raise ValueError("rwkv_mi_decode_sample failed")
         return out, float(ms.value)
 
     def profile_decode(self, first_token: int, n_tokens: int) -> dict:

@@ -18,7 +18,7 @@ BLOCK_SIZE = {0: 1, 1: 1, 2: 32, 3: 32, 7: 32, 8: 32, 9: 32}
 
 
 def build_oracle(force: bool = False) -> str:
-    src = [os.path.join(ORACLE_DIR, n) for n in ("rwkv_oracle.c", "rwkv_oracle.h", "Makefile")]
+    src = [os.path.join(ORACLE_DIR, n) for n in ("rwkv_oracle.c", "rwkv_oracle_fast.c", "rwkv_oracle.h", "Makefile")]
     stale = (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "librwkv_oracle.so"], stdout=subprocess.DEVNULL)
@@ -43,6 +43,8 @@ def lib():
         L.orc_bytes_per_token.argtypes = [P]
         L.orc_init_state.argtypes = [P, P]
         L.orc_set_threads.argtypes = [ctypes.c_int]
+        L.orc_set_fast.argtypes = [ctypes.c_int]
+        L.orc_fast_uses_vnni.restype = ctypes.c_int
         L.orc_eval.restype = ctypes.c_int
         L.orc_eval.argtypes = [P, ctypes.c_uint32, P, P, P]
         L.orc_eval_sequence.restype = ctypes.c_int

@@ -114,3 +114,41 @@ def test_state_layout_and_init(golden_dir):
     assert (m7.arch_major, m7.head_count, m7.head_size) == (7, 1, 64)
     m6 = O.OracleModel(R.fixture_path(golden_dir, "6v0-3m", "Q5_0"))
     assert (m6.arch_major, m6.head_count, m6.head_size, m6.ffn_size) == (6, 16, 8, 448)
+
+
+def test_simd_row_kernels_are_bit_identical_to_the_scalar_oracle(golden_dir):
+    """oracle/rwkv_oracle_fast.c (AVX2 / AVX-512-VNNI row kernels, used only by bench.py's cpu_baseline leg) against the scalar
+    loops: random rows of every weight type, and whole evaluations of the shipped fixtures."""
+    import glob
+    L = O.lib()
+    rng = np.random.default_rng(5)
+    try:
+        for fmt, t in O.TYPE_IDS.items():
+            for K, N, T in ((64, 7, 2), (2560, 33, 3), (4096, 17, 1)):
+                w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+                if fmt == "FP32":
+                    wb = w.view(np.uint8).reshape(-1)
+                elif fmt == "FP16":
+                    wb = w.astype(np.float16).view(np.uint8).reshape(-1)
+                else:
+                    wb = np.concatenate([O.quantize_row(t, w[n]) for n in range(N)])
+                x = rng.standard_normal((T, K)).astype(np.float32)
+                x[0, :32] *= 50.0
+                L.orc_set_fast(0)
+                ref = O.mul_mat(t, wb, K, N, x)
+                L.orc_set_fast(1)
+                got = O.mul_mat(t, wb, K, N, x)
+                assert np.array_equal(ref, got), (fmt, K, N)
+        for path in sorted(glob.glob(os.path.join(golden_dir, "tiny-rwkv-*.bin"))):
+            outs = []
+            for fast in (0, 1):
+                L.orc_set_fast(fast)
+                m = O.OracleModel(path)
+                st = m.init_state()
+                for tok in (34, 105, 110):
+                    lg, st = m.eval(tok, st)
+                outs.append((lg, st))
+                m.free()
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), path
+    finally:
+        L.orc_set_fast(0)
