@@ -37,6 +37,8 @@ static bool upload_tokens(rwkv_context * ctx, const uint32_t * tokens, size_t n)
     return true;
 }
 
+namespace rwkvmi { bool upload_tokens_for(rwkv_context * ctx, const uint32_t * tokens, size_t n) { return upload_tokens(ctx, tokens, n); } }
+
 // Runs tokens[0..n) from the device-resident state; logits (of the last token) stay in ctx->d_logits.
 static bool run_tokens(rwkv_context * ctx, const uint32_t * tokens, size_t n, bool want_logits) {
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
@@ -78,6 +80,8 @@ RWKV_API struct rwkv_context * rwkv_init_from_file(const char * file_path, const
     (void) n_gpu_layers;  // every layer runs on the GPU; the layer pipeline (rwkv_mi_init_stage) supersedes partial offload
     g_last_error = RWKV_ERROR_NONE;
     RW_CHECK(RWKV_ERROR_ARGS, nullptr, file_path != nullptr, "model_file_path is NULL");
+    // RWKV_MI_DEVICES=0,1,...: a layer pipeline over the listed devices behind this same ABI (pipeline.cpp); supersedes n_gpu_layers
+    if (const char * devs = getenv("RWKV_MI_DEVICES")) { if (devs[0]) return pipeline_create(file_path, n_threads, devs); }
     Model * m = load_model(file_path, 0, UINT32_MAX);
     if (!m) return nullptr;
     rwkv_context * ctx = create_context(m, n_threads);
@@ -86,6 +90,7 @@ RWKV_API struct rwkv_context * rwkv_init_from_file(const char * file_path, const
 
 RWKV_API struct rwkv_context * rwkv_clone_context(struct rwkv_context * ctx, const uint32_t n_threads) {
     RW_CHECK(RWKV_ERROR_ARGS, nullptr, ctx != nullptr, "ctx is NULL");
+    if (!ctx->stages.empty()) return pipeline_clone(ctx, n_threads);
     (void) hipSetDevice(ctx->model->device);
     rwkv_context * clone = create_context(ctx->model, n_threads);
     if (clone) clone->print_errors = ctx->print_errors;
@@ -96,6 +101,7 @@ RWKV_API bool rwkv_eval(struct rwkv_context * ctx, const uint32_t token, const f
     ctx->last_error = RWKV_ERROR_NONE;
     const size_t n_vocab = (size_t) ctx->model->n_vocab();
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, token < n_vocab, "Token (%" PRId32 ") is out of range (0 .. %zu)", (int32_t) token, n_vocab - 1);
+    if (!ctx->stages.empty()) return pipeline_eval(ctx, &token, 1, 1, state_in, state_out, logits_out);
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     if (!state_from_host(ctx, state_in)) return false;
     if (!run_tokens(ctx, &token, 1, logits_out != nullptr)) return false;
@@ -125,6 +131,7 @@ RWKV_API bool rwkv_eval_sequence(struct rwkv_context * ctx, const uint32_t * seq
         // "prepare only": the reference builds and caches the graph for this length; nothing to build here.
         return true;
     }
+    if (!ctx->stages.empty()) return pipeline_eval(ctx, sequence, sequence_len, k_max_tokens_per_pass, state_in, state_out, logits_out);
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     if (!state_from_host(ctx, state_in)) return false;
     if (!run_tokens(ctx, sequence, sequence_len, logits_out != nullptr)) return false;
@@ -142,6 +149,7 @@ RWKV_API bool rwkv_eval_sequence_in_chunks(struct rwkv_context * ctx, const uint
         RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, tokens[i] < n_vocab, "Token at index %zu (%" PRId32 ") is out of range (0 .. %zu)",
                      i, (int32_t) tokens[i], n_vocab - 1);
     }
+    if (!ctx->stages.empty()) return pipeline_eval(ctx, tokens, sequence_len, chunk_size, state_in, state_out, logits_out);
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     if (!state_from_host(ctx, state_in)) return false;
     // The state stays in HBM between chunks; only the final chunk produces logits (reference rwkv_eval.inc:183-218).
@@ -177,6 +185,7 @@ RWKV_API void rwkv_init_state(const struct rwkv_context * ctx, float * state) {
 
 RWKV_API void rwkv_free(struct rwkv_context * ctx) {
     if (!ctx) return;
+    if (!ctx->stages.empty()) { pipeline_destroy(ctx); return; }
     (void) hipSetDevice(ctx->model->device);
     destroy_context(ctx);
 }
@@ -228,8 +237,12 @@ RWKV_API const char * rwkv_get_system_info_string(void) {
 // rwkv_mi_* extensions (include/rwkv_mi355x.h)
 // ---------------------------------------------------------------------------------------------------------------
 
+#define RW_NO_PIPELINE(CTX, RET) RW_CTX_CHECK((CTX), RWKV_ERROR_ARGS | RWKV_ERROR_UNSUPPORTED, RET, (CTX)->stages.empty(), \
+    "this rwkv_mi_* extension works on a single-device context; with RWKV_MI_DEVICES use the rwkv.h entry points")
+
 RWKV_API bool rwkv_mi_state_load(struct rwkv_context * ctx, const float * state_in) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     if (!state_from_host(ctx, state_in)) return false;
     HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
@@ -238,6 +251,7 @@ RWKV_API bool rwkv_mi_state_load(struct rwkv_context * ctx, const float * state_
 
 RWKV_API bool rwkv_mi_state_store(struct rwkv_context * ctx, float * state_out) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, state_out != nullptr, "state_out is NULL");
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     return fetch_outputs(ctx, state_out, nullptr);
@@ -245,6 +259,7 @@ RWKV_API bool rwkv_mi_state_store(struct rwkv_context * ctx, float * state_out) 
 
 RWKV_API bool rwkv_mi_eval_resident(struct rwkv_context * ctx, const uint32_t * tokens, size_t n_tokens, float * logits_out) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, tokens != nullptr && n_tokens > 0, "tokens is NULL or empty");
     const size_t n_vocab = (size_t) ctx->model->n_vocab();
     for (size_t i = 0; i < n_tokens; i++) RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, tokens[i] < n_vocab, "Token at index %zu is out of range", i);
@@ -254,6 +269,7 @@ RWKV_API bool rwkv_mi_eval_resident(struct rwkv_context * ctx, const uint32_t * 
 
 RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, uint32_t * tokens_out, float * elapsed_ms) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     const size_t n_vocab = (size_t) ctx->model->n_vocab();
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, first_token < n_vocab, "Token is out of range");
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, n_tokens > 0, "n_tokens is 0");
@@ -294,6 +310,7 @@ static bool ensure_sampler(rwkv_context * ctx) {
 // the host after downloading the logits). u in [0, 1): the caller's uniform random number; u < 0: the context's generator (seed).
 RWKV_API bool rwkv_mi_sample(struct rwkv_context * ctx, float temperature, float top_p, float u, uint64_t seed, uint32_t * token_out) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, temperature >= 0.0f && top_p >= 0.0f && top_p <= 1.0f && u < 1.0f && token_out, "bad sampling arguments");
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, ctx->model->has_head, "this stage has no head");
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
@@ -309,6 +326,7 @@ RWKV_API bool rwkv_mi_sample(struct rwkv_context * ctx, float temperature, float
 RWKV_API bool rwkv_mi_decode_sample(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, float temperature, float top_p, uint64_t seed,
                                     uint32_t * tokens_out, float * elapsed_ms) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     const size_t n_vocab = (size_t) ctx->model->n_vocab();
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, first_token < n_vocab && n_tokens > 0, "bad arguments");
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, temperature >= 0.0f && top_p >= 0.0f && top_p <= 1.0f, "bad sampling arguments");
@@ -335,6 +353,7 @@ RWKV_API bool rwkv_mi_decode_sample(struct rwkv_context * ctx, uint32_t first_to
 // out[0] = summed kernel time (ms), out[1] = launches, out[2] = summed algorithmic bytes, out[3] = wall ms of the loop.
 RWKV_API bool rwkv_mi_profile_decode(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, double * out) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     const size_t n_vocab = (size_t) ctx->model->n_vocab();
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, first_token < n_vocab && n_tokens > 0 && out, "bad arguments");
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));

@@ -86,6 +86,7 @@ void launch_sample(const float * logits, int n, float temperature, float top_p, 
 // Returns nullptr with the thread-local error set, like the reference loader (rwkv_model_loading.inc:288-419).
 Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end);
 void    release_model(Model * m);
+bool    scan_stage_costs(const char * path, std::vector<uint64_t> & per_layer, uint64_t & head_bytes);
 
 }  // namespace rwkvmi
 
@@ -130,6 +131,12 @@ struct rwkv_context {
     // captured single-token graphs: [cur][with_logits]
     hipGraphExec_t graph_exec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool use_graph = true;
+
+    // Layer pipeline inside ONE process (RWKV_MI_DEVICES, pipeline.cpp): this context is then only the front of a chain of stage
+    // contexts, one per listed device; every rwkv.h entry point walks the chain.
+    std::vector<rwkv_context *> stages;
+    hipEvent_t handoff_ev = nullptr;   // (stage contexts) residual stream handed to the next stage
+    hipEvent_t consumed_ev = nullptr;  // (stage contexts) this stage is done with the pass whose input it was handed
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t mega_done = nullptr;   // completion of this context's latest persistent-kernel launch (engine.hip: launches are chained per device)
@@ -190,6 +197,12 @@ bool     mega_v6_clear_abort(void * h, hipStream_t st);
 bool     mega_v6_set_tag(void * h, unsigned base, hipStream_t st);
 uint64_t mega_v6_bytes(void * h);
 bool     mega_v6_trace(void * h, int layer, long long * out, bool fetch);
+// ---- layer pipeline in one process (pipeline.cpp) ----
+bool upload_tokens_for(rwkv_context * ctx, const uint32_t * tokens, size_t n);   // api.cpp: pinned staging + async copy into ctx->d_tokens
+rwkv_context * pipeline_create(const char * path, uint32_t n_threads, const char * devices);
+void pipeline_destroy(rwkv_context * front);
+bool pipeline_eval(rwkv_context * front, const uint32_t * tokens, size_t n, size_t chunk, const float * state_in, float * state_out, float * logits_out);
+rwkv_context * pipeline_clone(rwkv_context * front, uint32_t n_threads);
 // after a poll time-out of the persistent kernel: drain, clear, drop the persistent path (see engine.hip)
 void recover_from_abort(rwkv_context * ctx);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)

@@ -202,6 +202,28 @@ static bool validate_shapes(Model & m) {
     return ok;
 }
 
+// Bytes a decoded token streams per layer / for the head, from the file's tensor directory alone (used to balance pipeline stages).
+bool scan_stage_costs(const char * path, std::vector<uint64_t> & per_layer, uint64_t & head_bytes) {
+    FILE * f = fopen(path, "rb");
+    RW_CHECK(RWKV_ERROR_FILE | RWKV_ERROR_FILE_OPEN, false, f != nullptr, "Failed to open file %s", path);
+    std::unique_ptr<FILE, int (*)(FILE *)> fguard(f, fclose);
+    struct stat st;
+    RW_CHECK(RWKV_ERROR_FILE | RWKV_ERROR_FILE_STAT, false, fstat(fileno(f), &st) == 0, "Failed to stat file %s", path);
+    FileHeader h;
+    if (!read_file_header(f, h)) { global_fail(RWKV_ERROR_FILE, __FILE__, __LINE__, "read_file_header", "Invalid file header"); return false; }
+    per_layer.assign(h.n_layer, 0);
+    head_bytes = 0;
+    while ((uint64_t) ftello(f) < (uint64_t) st.st_size) {
+        TensorInfo ti;
+        if (!read_tensor_info(f, ti)) { global_fail(RWKV_ERROR_MODEL_PARAMS, __FILE__, __LINE__, "read_tensor_info", "Failed to read a model parameter"); return false; }
+        uint32_t li;
+        if (layer_of(ti.name, li)) { if (li < h.n_layer) per_layer[li] += ti.nbytes; }
+        else if (ti.name != "emb.weight") head_bytes += ti.nbytes;
+        RW_CHECK(RWKV_ERROR_MODEL_PARAMS | RWKV_ERROR_FILE_READ, false, fseeko(f, (off_t) ti.nbytes, SEEK_CUR) == 0, "Failed to seek past parameter %s", ti.name.c_str());
+    }
+    return true;
+}
+
 Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end) {
     FILE * f = fopen(path, "rb");
     RW_CHECK(RWKV_ERROR_FILE | RWKV_ERROR_FILE_OPEN, nullptr, f != nullptr, "Failed to open file %s", path);
