@@ -1,4 +1,4 @@
-// fused_v7.hip -- the RWKV-7 single-token (decode) layer as SIX launches instead of ~30 graph-op kernels
+// fused_v7.hip -- the RWKV-7 single-token (decode) layer as FIVE launches instead of ~30 graph-op kernels
 // (rwkv_att_v7, rwkv_graph.inc:387-482; rwkv_wkv_v7_impl, rwkv_operators_wkv_v7.inc:37-107; rwkv_ffn_v7, rwkv_graph.inc:533-543):
 //
 //   A  k7_att_in    LN1 + token shift + the ONE static mix this workgroup's matrix consumes (x_rwkvag) -> quantised image or f16-rounded

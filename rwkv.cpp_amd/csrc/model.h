@@ -178,7 +178,7 @@ bool forward(rwkv_context * ctx, int64_t T, bool want_logits);
 bool   fused_v6_supported(const Model & m);
 size_t fused_v6_scratch_bytes(const Model & m);
 void   fused_v6_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf);
-// fused RWKV-7 decode layer (fused_v7.hip): six launches per layer
+// fused RWKV-7 decode layer (fused_v7.hip): five launches per layer
 bool   fused_v7_supported(const Model & m);
 size_t fused_v7_scratch_bytes(const Model & m);
 void   fused_v7_layer(const Model & m, const LayerW & L, int layer, float * x, float * v_first, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf);
