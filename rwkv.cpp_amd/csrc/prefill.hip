@@ -237,17 +237,6 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
     // ---- the walk: leaves in bit-reversed order, 8 per iteration of the outer loop (the merges are compile-time code) ----
     float s0[16], s1[16], s2[16], S3[16], S4[16], S5[16], V[16];
     int sigma = 0;
-    // operands of the NEXT step are read from LDS while the current block is folded (inside a chunk; the first step of a chunk reads its own)
-    int4 braw_n = make_int4(0, 0, 0, 0);
-    unsigned scw_n = 0u, qhw_n = 0u;
-    v4i aop_n = {0, 0, 0, 0};
-    auto read_ops = [&](int slot, int4 & br, unsigned & sc, unsigned & qh, v4i & ao) {
-        const unsigned char * S2 = lds + (size_t) slot * M::SLOT;
-        br = *reinterpret_cast<const int4 *>(S2 + M::OFF_WC + (M::Q8 ? (rg * 64 + h * 32 + nn) : (rg * 32 + nn)) * 16);
-        sc = *reinterpret_cast<const unsigned *>(S2 + M::OFF_WSC + (rg * 32 + nn) * 4);
-        if constexpr (M::QH) qh = *reinterpret_cast<const unsigned *>(S2 + M::OFF_WQH + (rg * 32 + nn) * 4);
-        ao = *reinterpret_cast<const v4i *>(S2 + M::OFF_XQ + (tg * 64 + lane) * 16);
-    };
     constexpr int REV3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
 #pragma unroll 1
     for (int a = 0; a < 8; a++) {
@@ -268,15 +257,12 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (k + 1 < n_chunks) issue(k + 1);
-                    read_ops(sigma & 15, braw_n, scw_n, qhw_n, aop_n);
                 }
                 const unsigned char * S = lds + (size_t) (sigma & 15) * M::SLOT;
-                // operands (prefetched)
-                const int4 braw = braw_n;
-                const unsigned scw = scw_n;
-                const unsigned qhw_cur = qhw_n;
-                const v4i aop = aop_n;
-                (void) qhw_cur;
+                // operands
+                const int4 braw = *reinterpret_cast<const int4 *>(S + M::OFF_WC + (M::Q8 ? (rg * 64 + h * 32 + nn) : (rg * 32 + nn)) * 16);
+                const unsigned scw = *reinterpret_cast<const unsigned *>(S + M::OFF_WSC + (rg * 32 + nn) * 4);
+                const v4i aop = *reinterpret_cast<const v4i *>(S + M::OFF_XQ + (tg * 64 + lane) * 16);
                 v4i bop;
                 const int raw[4] = {braw.x, braw.y, braw.z, braw.w};
                 if constexpr (FMT == T_Q8_0) {
@@ -289,7 +275,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
 #pragma unroll
                     for (int i = 0; i < 4; i++) bop[i] = (raw[i] >> (4 * h)) & 0x0F0F0F0F;
                 } else {
-                    const unsigned qhw = qhw_cur;
+                    const unsigned qhw = *reinterpret_cast<const unsigned *>(S + M::OFF_WQH + (rg * 32 + nn) * 4);
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const unsigned nl = (qhw >> (16 * h + 4 * i)) & 0xFu;
@@ -302,8 +288,6 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[r] = 0;
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop, bop, acc, 0, 0, 0);
-                // the next step's operands (same chunk: already landed) are fetched behind the MFMA
-                if (((sigma + 1) & 7) != 0) read_ops((sigma + 1) & 15, braw_n, scw_n, qhw_n, aop_n);
                 // fold the block: tokens of register r: (r & 3) + 8 (r >> 2) + 4 h
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
