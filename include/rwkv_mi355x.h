@@ -43,6 +43,10 @@ RWKV_API bool rwkv_mi_decode_sample(struct rwkv_context * ctx, uint32_t first_to
  * out[2] = summed algorithmic bytes (weight rows + quantised activation + outputs), out[3] = wall ms of the loop. */
 RWKV_API bool rwkv_mi_profile_decode(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, double * out);
 
+/* The same for sequence mode: one pass over `tokens` (at most 1024) from the resident state, HIP events around every launch of the int8
+ * MFMA GEMM. out[0] = summed kernel ms, out[1] = launches, out[2] = summed integer operations (2 T N K per launch), out[3] = wall ms of the pass. */
+RWKV_API bool rwkv_mi_profile_prefill(struct rwkv_context * ctx, const uint32_t * tokens, size_t n_tokens, double * out);
+
 /* Algorithmic HBM bytes one decoded token must move on this context's layers: every parameter once (file dtype), one
  * embedding row, state read + write, logits write. */
 RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx);

@@ -383,6 +383,35 @@ RWKV_API bool rwkv_mi_profile_decode(struct rwkv_context * ctx, uint32_t first_t
     return true;
 }
 
+// One sequence pass over `tokens` from the resident state with a HIP-event pair (on the context's stream) around every launch of the
+// sequence-mode GEMM (k_mmq_mfma). out[0] = summed kernel ms, out[1] = launches, out[2] = summed integer operations (2 T N K), out[3] = wall ms.
+RWKV_API bool rwkv_mi_profile_prefill(struct rwkv_context * ctx, const uint32_t * tokens, size_t n_tokens, double * out) {
+    ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
+    RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, tokens && n_tokens > 0 && n_tokens <= k_max_tokens_per_pass && out, "bad arguments");
+    HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    if (!upload_tokens(ctx, tokens, n_tokens)) return false;
+    auto & pf = ctx->prof;
+    pf.total_ms = 0.0; pf.launches = 0; pf.total_bytes = 0;
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_CTX_OK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    pf.on = true; pf.used = 0;
+    const bool ok = forward(ctx, (int64_t) n_tokens, true);
+    pf.on = false;
+    if (!ok) return false;
+    HIP_CTX_OK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < pf.used; k++) {
+        float ms = 0.0f;
+        HIP_CTX_OK(ctx, hipEventElapsedTime(&ms, pf.events[2 * k], pf.events[2 * k + 1]));
+        pf.total_ms += ms; pf.launches++; pf.total_bytes += pf.bytes[k];
+    }
+    float wall = 0.0f;
+    HIP_CTX_OK(ctx, hipEventElapsedTime(&wall, ctx->ev0, ctx->ev1));
+    out[0] = pf.total_ms; out[1] = (double) pf.launches; out[2] = (double) pf.total_bytes; out[3] = wall;
+    return true;
+}
+
 RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx) { return ctx->model->bytes_per_token; }
 RWKV_API uint64_t rwkv_mi_weight_bytes(const struct rwkv_context * ctx) { return ctx->model->weight_bytes; }
 

@@ -279,7 +279,18 @@ struct Runner {
             // sequence mode: int8 GEMM on the matrix cores (prefill.hip), bit-identical to the single-token kernel per (row, token)
             const TileAct ta = tile_act_at(b.tile, T, K);
             launch_quantize_act_tiles(x, T, K, W->type, ta, st);
+            auto & pf = ctx->prof;
+            if (pf.on) {   // live per-launch timing of the GEMM (rwkv_mi_profile_prefill): `bytes` carries the launch's integer operations
+                if (pf.used * 2 + 2 > pf.events.size()) {
+                    hipEvent_t a = nullptr, c = nullptr;
+                    (void) hipEventCreate(&a); (void) hipEventCreate(&c);
+                    pf.events.push_back(a); pf.events.push_back(c); pf.bytes.push_back(0);
+                }
+                pf.bytes[pf.used] = 2ull * (uint64_t) T * (uint64_t) N * (uint64_t) K;
+                (void) hipEventRecord(pf.events[pf.used * 2], st);
+            }
             if (!launch_mmq_mfma(*W, ta, T, y, N, epi, st)) ctx->last_error |= RWKV_ERROR_GRAPH | RWKV_ERROR_ALLOC;
+            if (pf.on) { (void) hipEventRecord(pf.events[pf.used * 2 + 1], st); pf.used++; }
         } else if (dtype_quantized(W->type)) {
             launch_quantize_act(x, T, K, b.qa, st);
             auto & pf = ctx->prof;

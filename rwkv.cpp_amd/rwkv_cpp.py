@@ -87,6 +87,8 @@ class RWKVSharedLibrary:
         L.rwkv_mi_decode_greedy.restype = ctypes.c_bool
         L.rwkv_mi_profile_decode.argtypes = [c_ctx, ctypes.c_uint32, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double)]
         L.rwkv_mi_profile_decode.restype = ctypes.c_bool
+        L.rwkv_mi_profile_prefill.argtypes = [c_ctx, P_UINT32, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double)]
+        L.rwkv_mi_profile_prefill.restype = ctypes.c_bool
         L.rwkv_mi_bytes_per_token.argtypes = [c_ctx]
         L.rwkv_mi_bytes_per_token.restype = ctypes.c_uint64
         L.rwkv_mi_weight_bytes.argtypes = [c_ctx]
@@ -330,6 +332,13 @@ class RWKVModel:
         if not self._library.library.rwkv_mi_profile_decode(self._ctx.ptr, first_token, n_tokens, out):
             raise ValueError("rwkv_mi_profile_decode failed")
         return {"kernel_ms": out[0], "launches": int(out[1]), "bytes": int(out[2]), "wall_ms": out[3]}
+
+    def profile_prefill(self, tokens: List[int]) -> dict:
+        arr = (ctypes.c_uint32 * len(tokens))(*tokens)
+        out = (ctypes.c_double * 4)()
+        if not self._library.library.rwkv_mi_profile_prefill(self._ctx.ptr, arr, len(tokens), out):
+            raise ValueError("rwkv_mi_profile_prefill failed")
+        return {"kernel_ms": out[0], "launches": int(out[1]), "ops": int(out[2]), "wall_ms": out[3]}
 
     def bytes_per_token(self) -> int:
         return int(self._library.library.rwkv_mi_bytes_per_token(self._ctx.ptr))
