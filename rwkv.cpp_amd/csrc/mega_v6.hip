@@ -652,6 +652,13 @@ struct K6 {
 #pragma unroll
                 for (int b = 0; b < NBD; b++) load_raw<FMT>(w2[b], dw2.qs, dw2.qh, dw2.sc, (long long) c * NBD + b);
                 const float td = ar.f(L.time_decay)[c], uu = ar.f(L.faaaa)[c], lnw = ar.f(L.lnx_w)[c], lnb = ar.f(L.lnx_b)[c];
+                // the head's state column goes in flight together with the decay-W2 blocks, BEFORE the dl poll: one memory round trip
+                // for both instead of two on this chain (the exp routine's constants live in scalar registers now, so the 64 extra live
+                // registers no longer push them into scratch)
+                float s[S];
+                const float * st = sin_l + 2 * D + (long long) d_head * S * S;
+#pragma unroll
+                for (int i = 0; i < S; i++) s[i] = st[i * S + lane];
                 __builtin_amdgcn_sched_barrier(0);
                 // dl arrives first (the decay rows are the first thing the workers finish): one unit per value
                 unsigned dq[6];
@@ -661,6 +668,13 @@ struct K6 {
                     v4u dv[2];
                     poll_ptrs<2>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
                     dq[4] = dv[0].x; dq[5] = dv[1].x;
+                }
+                // speculative first read of this channel's r / k / v / g units: in flight while the decay is computed
+                v4u early[4];
+                {
+                    asm volatile("" ::: "memory");
+                    early[0] = tg_load(xr, p.rkvg + (c >> 1)); early[1] = tg_load(xr, p.rkvg + ((D + c) >> 1));
+                    early[2] = tg_load(xr, p.rkvg + ((2 * D + c) >> 1)); early[3] = tg_load(xr, p.rkvg + ((3 * D + c) >> 1));
                 }
                 // 1. quantise dl (DR = 32 NBD elements) into LDS: half-wave = block
                 const QVec ldl = qvec_at(l.dl, NBD * 32);
@@ -688,19 +702,17 @@ struct K6 {
 #pragma unroll
                     for (int i = 0; i < o; i++) P[i] += P[i + o];
                 const float wdec = det_expf(-det_expf(P[0] + td));
-                // the head's state column goes in flight now, not before the decay: 64 more live registers pushed the
-                // double-precision exp's constants into scratch, and a scratch reload is a memory round trip on this chain
-                float s[S];
-                const float * st = sin_l + 2 * D + (long long) d_head * S * S;
-#pragma unroll
-                for (int i = 0; i < S; i++) s[i] = st[i * S + lane];
-                __builtin_amdgcn_sched_barrier(0);
-                // r,k,v,g of channel c: one unit per 2-row set
+                // r,k,v,g of channel c: one unit per 2-row set. A first read was put in flight before the decay was computed (see above): when
+                // the four producers were done by then -- the usual case, the gate rows' silu aside -- its result is used and the chain saves a
+                // memory round trip; otherwise the ordinary poll takes over.
                 {
                     const int ptr[4] = {p.rkvg + (c >> 1), p.rkvg + ((D + c) >> 1), p.rkvg + ((2 * D + c) >> 1), p.rkvg + ((3 * D + c) >> 1)};
                     const bool valid[4] = {true, true, true, true};
-                    v4u dv[4];
-                    poll_ptrs<4>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
+                    v4u dv[4] = {early[0], early[1], early[2], early[3]};
+                    bool ok = true;
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) ok = ok && tg_ok(dv[q], tagL + SLOT_RKVG);
+                    if (!__all(ok)) poll_ptrs<4>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
     #pragma unroll
                     for (int q = 0; q < 4; q++) dq[q] = (c & 1) ? dv[q].y : dv[q].x;
                 }
@@ -723,7 +735,7 @@ struct K6 {
                         const float prev = s[i];
                         const float temp = kv * b8[u].y + prev;
                         o += temp * b8[u].z;
-                        so[i * S + lane] = prev * b8[u].w + kv;
+                        so[i * S + lane] = prev * b8[u].w + kv;   // (deferring these 64 stores behind the yq hand-over was tried: the comm wave's next polls then queue behind them)
                     }
                 }
                 // 4. GroupNorm over the head, * ln_x, gate

@@ -3,8 +3,9 @@ sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT','/root/repo'),'
 import torch; torch.cuda.init()
 from gpu_lib import library, model, synth
 lib=library()
-p='/tmp/synthetic-rwkv6-7b-Q4_0-seed42.bin'
-if not os.path.exists(p): synth.write_model(p, synth.CONFIGS['rwkv6-7b'], 'Q4_0', seed=42)
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'rwkv6-7b'
+p='/tmp/synthetic-%s-Q4_0-seed42.bin' % cfg
+if not os.path.exists(p): synth.write_model(p, synth.CONFIGS[cfg], 'Q4_0', seed=42)
 m=model(p); m.state_load(None)
 L=lib.library; L.rwkv_mi_trace_phases.argtypes=[ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]; L.rwkv_mi_trace_phases.restype=ctypes.c_bool
 NB=256
