@@ -428,10 +428,15 @@ struct K6 {
     static __device__ __forceinline__ int c_mat() { return ((int) blockIdx.x * RPB_C) / D; }
     static __device__ __forceinline__ int c_base() { return ((int) blockIdx.x * RPB_C) % D; }
 
-    static __device__ __forceinline__ void issue_C(Rows & r, const M6Arena & ar, const M6Layer & L, int own, int lane) {
+    // part 0: the first half of the owner's row sets, part 1: the second half (issued once the activation image has been staged: the
+    // comm wave's polls for it then queue behind half the burst; the second half lands under the first half's arithmetic); part 2: all
+    static __device__ __forceinline__ void issue_C(Rows & r, const M6Arena & ar, const M6Layer & L, int own, int lane, int part = 2) {
         const WPl w = ar.w(L.rkvg[c_mat()]);
 #pragma unroll
-        for (int si = 0; si < NSC; si++) batch_issue<FMT, 2, UD>(r.wC[si], w.qs, w.qh, w.sc, c_base() + 2 * (own + si * NOWN), D, nb, 0, lane);
+        for (int si = 0; si < NSC; si++) {
+            if (part == 2 || (part == 0) == (si < NSC / 2))
+                batch_issue<FMT, 2, UD>(r.wC[si], w.qs, w.qh, w.sc, c_base() + 2 * (own + si * NOWN), D, nb, 0, lane);
+        }
     }
     static __device__ __forceinline__ void compute_C(Rows & r, const Lds & l, xrsrc xr, const M6P & p, unsigned tagL, int own, int lane) {
         const QVec la = qvec_at(l.act, D);
@@ -503,14 +508,17 @@ struct K6 {
         }
         x_store(xr, p.rr, rrow, own, lane, tagL + SLOT_KQ);
     }
-    static __device__ __forceinline__ void issue_G(Rows & r, const M6P & p, const M6Arena & ar, const M6Layer & L, int own, int lane) {
+    // part 0: the first four block-steps of every row, part 1: the rest. Part 1 goes out only after the k hand-over has been staged: the
+    // comm wave's polls for k then queue behind half the burst in the CU's memory pipe, and the second half lands under the first
+    // half's arithmetic.
+    static __device__ __forceinline__ void issue_G(Rows & r, const M6P & p, const M6Arena & ar, const M6Layer & L, int own, int lane, int part) {
         const WPl w = ar.w(L.fv);
         const int nbF = p.F / 32;
 #pragma unroll
         for (int si = 0; si < NSE; si++) {
             const int row = (int) blockIdx.x * RPB_E + own * NSE + si;
-            batch_issue<FMT, 1, 4>(r.wG[si][0], w.qs, w.qh, w.sc, row, D, nbF, 0, lane);
-            batch_issue_opt<FMT, 1, 4>(nbF > 256, r.wG[si][1], w, row, D, nbF, 256, lane);
+            if (part == 0) batch_issue<FMT, 1, 4>(r.wG[si][0], w.qs, w.qh, w.sc, row, D, nbF, 0, lane);
+            else batch_issue_opt<FMT, 1, 4>(nbF > 256, r.wG[si][1], w, row, D, nbF, 256, lane);
         }
     }
     static __device__ __forceinline__ void compute_G(Rows & r, const Lds & l, xrsrc xr, const M6P & p, unsigned tagL, int own, int lane) {
@@ -791,12 +799,13 @@ struct K6 {
                 const int nl = li + 1 < p.n_layers ? li + 1 : li;
                 issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, lane0);
             }
-            issue_G(r, p, ar, L, own, lane);
+            issue_G(r, p, ar, L, own, lane, 0);
             __syncthreads();   // releases the workers' value-projection stream
             stage_qvec<KQU, 64>(pl, xr, p.kq, F, tagL + SLOT_KQ, l.kq, lane);
             poll_units<1, 64>(pl, xr, p.rr + blk * NOWN, NOWN, tagL + SLOT_KQ, lane, [&](int i, const v4u & v) { x_sink(l.rr, i, v); });
             STAMP(11); RSTAMP(27);
             __syncthreads();
+            issue_G(r, p, ar, L, own, lane, 1);
             compute_G(r, l, xr, p, tagL, own, lane);
             RSTAMP(28);
             STAMP(12);
@@ -851,7 +860,7 @@ struct K6 {
                 }
                 STAMP(4); RSTAMP(17);
                 __syncthreads();   // the r/k/v/g stream starts once the comm wave has polled tl (+1.7 %: its polls are not behind the stream)
-                issue_C(r, ar, L, own, lane);
+                issue_C(r, ar, L, own, lane, 0);
                 batch_issue_opt<FMT, 1, UD>(x_has, wCx, ar.w(L.dw1), x_row, DR, nb, 0, lane);
                 STAMP(5);
             }
@@ -863,6 +872,7 @@ struct K6 {
                 STAMP(6);
                 __syncthreads();                       // activation image(s) staged
                 STAMP(7);
+                issue_C(r, ar, L, own, lane, 1);
                 if (x_has) {
                     float res[1];
                     rows_finish<FMT, 1, UD>(wCx, nullptr, nullptr, nullptr, 0, DR, nb, qvec_at(l.actw, D), lane, res);
@@ -903,7 +913,7 @@ struct K6 {
                 // the stream below fills the CU's memory pipe for ~6 us: the comm wave's k stores and own loads go in first
                 // (second barrier; +4 % over issuing straight after the first one)
                 __syncthreads();
-                issue_G(r, p, ar, L, own, lane);
+                issue_G(r, p, ar, L, own, lane, 0);
             }
             // ---- G; then the next layer's prologue parameters and W1 row ----
             {
@@ -911,6 +921,10 @@ struct K6 {
                 STAMP(14);
                 __syncthreads();                       // kq and rr staged
                 STAMP(15);
+                {
+                    const M6Layer & L = p.layers[opq_s(li)];
+                    issue_G(r, p, ar, L, own, tid & 63, 1);
+                }
                 compute_G(r, l, xr, p, tagL, own, lane);
                 STAMP(16); RSTAMP(28);
                 const int nl = li + 1 < p.n_layers ? li + 1 : li;
