@@ -36,11 +36,13 @@
 #include "model.h"
 
 #include <mutex>
+#include <type_traits>
 
 namespace rwkvmi {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------------
 // tile-major images
@@ -151,13 +153,20 @@ template <int FMT> struct MF {
     // (512 threads, 128 x 64 tile, one workgroup per CU) 36.6 us; RGN = 2 (256 threads, 64 x 64 tile, two workgroups per CU covering
     // each other's barrier / DMA stalls) 44.0 us -- the larger tile's operand reuse is worth more than the second workgroup.
     static constexpr int  RGN = 4, NT = RGN * 2 * 64, ROWS = RGN * 32;
-    static constexpr int  WC = ROWS * (Q8 ? 32 : 16);           // LDS bytes per step
-    static constexpr int  OFF_WC = 0, OFF_WSC = WC, OFF_WQH = OFF_WSC + ROWS * 4, OFF_XQ = OFF_WQH + (QH ? ROWS * 4 : 0), OFF_XD = OFF_XQ + 2048,
+    // One step's operands in LDS = a sequence of 1-KiB "DMA rows" (one global_load_lds_dwordx4 of a wave each):
+    //   NW rows of weight codes | 2 rows of token codes (one per 32-token tile) | tail: 16-byte pieces of the small arrays, in the order
+    //   weight scales (32) [fifth bits (32)] token scales d (16) [s (16)] [o (16)]
+    static constexpr int  WC = ROWS * (Q8 ? 32 : 16);           // LDS bytes of weight codes per step
+    static constexpr int  NW = WC / 1024;
+    static constexpr int  OFF_WC = 0, OFF_XQ = WC, OFF_WSC = OFF_XQ + 2048, OFF_WQH = OFF_WSC + ROWS * 4, OFF_XD = OFF_WQH + (QH ? ROWS * 4 : 0),
                           OFF_XS = OFF_XD + 256, OFF_XO = OFF_XS + (HM ? 256 : 0), SLOT = OFF_XO + (XO ? 256 : 0);
-    // 16-byte pieces per step
-    static constexpr int P_WC = WC / 16, P_WSC = ROWS / 4, P_WQH = QH ? ROWS / 4 : 0, P_XQ = 128, P_XD = 16, P_XS = HM ? 16 : 0, P_XO = XO ? 16 : 0;
-    static constexpr int PS = P_WC + P_WSC + P_WQH + P_XQ + P_XD + P_XS + P_XO;
-    static constexpr int NLD = (8 * PS + NT - 1) / NT;          // staging loads per thread and chunk
+    static constexpr int  P_WSC = ROWS / 4, P_WQH = QH ? ROWS / 4 : 0, P_XD = 16, P_XS = HM ? 16 : 0, P_XO = XO ? 16 : 0;
+    static constexpr int  P_TAIL = P_WSC + P_WQH + P_XD + P_XS + P_XO, NTR = (P_TAIL + 63) / 64, NR = NW + 2 + NTR;   // rows per step
+    // steps per chunk; stack levels kept in LDS (64 B per thread each) so that two chunks of 8 steps + the levels fit in 160 KiB
+    static constexpr bool OVERLAP = true;                       // the MFMA of step sigma + 1 runs under the fold of step sigma
+    static constexpr int CH = 8, STK_LDS = Q8 ? 1 : 2;
+    static constexpr int LDS_BYTES = 2 * CH * SLOT + STK_LDS * 64 * NT;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 struct PfW { const uint8_t * qs; const uint32_t * sc; const uint32_t * qh; };
@@ -165,7 +174,7 @@ struct PfX { const int8_t * q; const float * d; const float * s; const float * o
 
 template <int FMT>
 __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64_t N, int nb, int64_t T, int RT /* row tiles of 32 */, int C /* token tiles of 64 */,
-                                                  const unsigned short * __restrict__ order, float * __restrict__ y, int64_t ldy, Epi epi) {
+                                                  const int * __restrict__ order, float * __restrict__ y, int64_t ldy, Epi epi) {
     typedef MF<FMT> M;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // XCD-aware tile map: block id -> XCD id % 8; the token tiles of one 128-row panel run on the same XCD and share its L2
@@ -179,64 +188,195 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
     const int nn = lane & 31, h = lane >> 5;
     const int rt0 = rp * M::RGN, tt0 = ct * 2;
 
-    // ---- staging: chunk k = steps [8k, 8k + 8) goes straight from global memory into LDS buffer k & 1 (LDS-DMA, 16 bytes per lane,
-    //      1 KiB per wave-instruction, no staging registers). A chunk is a linear array of 8 * PS pieces: piece p at byte 16 p. ----
+    // ---- staging: chunk k = steps [CH k, CH k + CH) goes straight from global memory into LDS buffer k & 1 (LDS-DMA: 16 bytes per
+    //      lane, 1 KiB per wave-instruction, no staging registers). Wave w stages the rows r = w / CH, + 8 / CH, ... of step CH k + w % CH:
+    //      the block number of its step is wave-uniform, so a row's address is a scalar base (SALU) plus a per-lane offset. ----
     const unsigned lds_base = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) lds;
+    const int st_w = wave % M::CH, sub_w = wave / M::CH;
+    constexpr int NSUB = 8 / M::CH;
+    auto blk_of = [&](int k) { int step = M::CH * k + st_w; step = step < nb ? step : nb - 1; return order[step]; };   // (tail: harmless duplicates)
+    int b_nx = blk_of(0);                        // block of this wave's step in the chunk issued next (read one chunk ahead)
+    auto dma_s = [&](const unsigned char * sbase, unsigned voff, unsigned dst) {
+        // Issued through inline asm on purpose: the compiler cannot prove that an LDS-DMA does not alias the operand reads of the
+        // steps that follow and would put `s_waitcnt vmcnt(0)` in front of every one of them. Completion is waited for by hand.
+        const unsigned long long sb = (unsigned long long) sbase;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) sb), hi = __builtin_amdgcn_readfirstlane((unsigned) (sb >> 32));
+        const unsigned long long sbu = ((unsigned long long) hi << 32) | lo;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbu), "s"(dst) : "memory");
+    };
+    auto dma_v = [&](const unsigned char * src, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
     auto issue = [&](int k) {
+        // (the lane index goes through an opaque copy: the offsets below are recomputed at every chunk boundary instead of being kept
+        //  in registers across the walk, where every register counts)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int64_t b = b_nx;
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned) ((M::CH * (k & 1) + st_w) * M::SLOT));
 #pragma unroll
-        for (int i = 0; i < M::NLD; i++) {
-            const int p = tid + M::NT * i;
-            const int sidx = p / M::PS, qq = p - sidx * M::PS;
-            int step = 8 * k + sidx;
-            if (step >= nb) step = nb - 1;                       // (tail of the last chunk: harmless duplicate)
-            const int64_t b = order[step];
-            const unsigned char * src;
-            if (qq < M::P_WC) {
+        for (int r = 0; r < M::NR; r++) {
+            if (r % NSUB != sub_w) continue;                         // (wave-uniform)
+            const unsigned dst = dst0 + r * 1024;
+            if (r < M::NW) {
                 if constexpr (M::Q8) {
-                    const int r4 = qq >> 6, rest = qq & 63;       // rest = half * 32 + n
-                    int rt = rt0 + r4; rt = rt < RT ? rt : RT - 1;
-                    src = w.qs + (((int64_t) rt * nb + b) * 64 + rest) * 16;
+                    int rt = rt0 + r; rt = rt < RT ? rt : RT - 1;
+                    dma_s(w.qs + ((int64_t) rt * nb + b) * 1024, (unsigned) lane_o * 16, dst);
                 } else {
-                    const int r4 = qq >> 5, n = qq & 31;
-                    int rt = rt0 + r4; rt = rt < RT ? rt : RT - 1;
-                    src = w.qs + (((int64_t) rt * nb + b) * 32 + n) * 16;
+                    int rta = rt0 + 2 * r, rtb = rta + 1;
+                    rta = rta < RT ? rta : RT - 1; rtb = rtb < RT ? rtb : RT - 1;
+                    const unsigned up = (unsigned) (rtb - rta) * (unsigned) nb * 512u;      // 0 when the upper tile is clamped onto the lower one
+                    dma_s(w.qs + ((int64_t) rta * nb + b) * 512, (unsigned) (lane_o & 31) * 16 + ((lane_o >> 5) ? up : 0u), dst);
                 }
-            } else if (qq < M::P_WC + M::P_WSC) {
-                const int q2 = qq - M::P_WC, r4 = q2 >> 3, part = q2 & 7;
-                int rt = rt0 + r4; rt = rt < RT ? rt : RT - 1;
-                src = reinterpret_cast<const unsigned char *>(w.sc) + (((int64_t) rt * nb + b) * 32) * 4 + part * 16;
-            } else if (qq < M::P_WC + M::P_WSC + M::P_WQH) {
-                const int q2 = qq - M::P_WC - M::P_WSC, r4 = q2 >> 3, part = q2 & 7;
-                int rt = rt0 + r4; rt = rt < RT ? rt : RT - 1;
-                src = reinterpret_cast<const unsigned char *>(w.qh) + (((int64_t) rt * nb + b) * 32) * 4 + part * 16;
-            } else if (qq < M::P_WC + M::P_WSC + M::P_WQH + M::P_XQ) {
-                const int q2 = qq - M::P_WC - M::P_WSC - M::P_WQH, t2 = q2 >> 6, rest = q2 & 63;
-                src = reinterpret_cast<const unsigned char *>(x.q) + (((int64_t) (tt0 + t2) * nb + b) * 1024) + rest * 16;
+            } else if (r < M::NW + 2) {
+                const int t2 = r - M::NW;
+                dma_s(reinterpret_cast<const unsigned char *>(x.q) + ((int64_t) (tt0 + t2) * nb + b) * 1024, (unsigned) lane_o * 16, dst);
             } else {
-                const int q2 = qq - M::P_WC - M::P_WSC - M::P_WQH - M::P_XQ;
-                const int which = q2 >> 4, q3 = q2 & 15, t2 = q3 >> 3, part = q3 & 7;   // d, then s (HM) / o (XO)
-                const float * base = which == 0 ? x.d : (M::HM ? x.s : x.o);
-                src = reinterpret_cast<const unsigned char *>(base) + (((int64_t) (tt0 + t2) * nb + b) * 32) * 4 + part * 16;
+                // tail pieces: one masked DMA per array that has pieces in this row (no pointer selects: they become stack objects)
+                const int q = lane_o + 64 * (r - M::NW - 2);
+                const int part = q & 7, lo = 64 * (r - M::NW - 2), hi = lo + 64;
+                auto seg = [&](int first, int count, const void * base, bool weights) {
+                    if (count == 0 || first >= hi || first + count <= lo) return;          // (compile-time after unrolling)
+                    if (q >= first && q < first + count) {
+                        const int e = (q - first) >> 3;                                    // row tile / token tile within the step
+                        int64_t tile;
+                        if (weights) { int rt = rt0 + e; rt = rt < RT ? rt : RT - 1; tile = rt; } else tile = tt0 + e;
+                        dma_v(reinterpret_cast<const unsigned char *>(base) + (tile * nb + b) * 128 + part * 16, dst);
+                    }
+                };
+                seg(0, M::P_WSC, w.sc, true);
+                seg(M::P_WSC, M::P_WQH, w.qh, true);
+                seg(M::P_WSC + M::P_WQH, M::P_XD, x.d, false);
+                seg(M::P_WSC + M::P_WQH + M::P_XD, M::P_XS, x.s, false);
+                seg(M::P_WSC + M::P_WQH + M::P_XD + M::P_XS, M::P_XO, x.o, false);
             }
-            // Issued through inline asm on purpose: the compiler cannot prove that an LDS-DMA does not alias the operand reads
-            // of the steps that follow and would put `s_waitcnt vmcnt(0)` in front of every one of them (measured: the whole DMA
-            // latency exposed once per chunk, 3.4x on the kernel). Its completion is waited for by hand at the chunk boundary.
-            if (wave * 64 + M::NT * i < 8 * M::PS && p < 8 * M::PS) {   // (first test is wave-uniform: a wave without pieces issues nothing)
-                const unsigned dst = lds_base + (unsigned) ((8 * (k & 1)) * M::SLOT + (wave * 64 + M::NT * i) * 16);
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+        b_nx = blk_of(k + 1);
+    };
+
+    // two chunk buffers (a third one in flight was measured: no gain)
+    const int n_chunks = (nb + M::CH - 1) / M::CH;
+    issue(0);
+
+    // ---- software pipeline. Step sigma = one quantisation block of the walk. While the f32 fold of step sigma runs on the VALU,
+    //      the MFMA of step sigma + 1 runs on the matrix pipe and the LDS reads of step sigma + 2 are in flight:
+    //        n_*   operands of the step after the one in `acc` (LDS -> registers, read by load_ops)
+    //        acc   integer block sums of the current step (written by launch)
+    //        dd    d_w * d_x of the current step (16 tokens of this lane's row), aux: its s / o values
+    int4 n_braw = make_int4(0, 0, 0, 0);
+    v4i n_aop = {0, 0, 0, 0};
+    unsigned n_scw = 0, n_qhw = 0;
+    v16i acc;
+    v2f dd[8], aux[8];
+    float dw_l = 0.0f, mw_l = 0.0f;            // scales of the step in `acc`
+    int sg_l = 0;                                // next step to read from LDS
+    auto load_ops = [&]() {
+        if ((sg_l & (M::CH - 1)) == 0 && sg_l < nb) {
+            // chunk boundary: this wave's part of chunk k has landed (issued one chunk ago); after the barrier everybody's has, and
+            // every wave has finished reading the buffer the next chunk goes into (its last reads are two stages back)
+            const int k = sg_l / M::CH;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (k + 1 < n_chunks) issue(k + 1);
+        }
+        const unsigned char * S = lds + (size_t) (sg_l & (2 * M::CH - 1)) * M::SLOT;
+        n_braw = *reinterpret_cast<const int4 *>(S + M::OFF_WC + (M::Q8 ? (rg * 64 + h * 32 + nn) : (rg * 32 + nn)) * 16);
+        n_scw = *reinterpret_cast<const unsigned *>(S + M::OFF_WSC + (rg * 32 + nn) * 4);
+        n_aop = *reinterpret_cast<const v4i *>(S + M::OFF_XQ + (tg * 64 + lane) * 16);
+        if constexpr (M::QH) n_qhw = *reinterpret_cast<const unsigned *>(S + M::OFF_WQH + (rg * 32 + nn) * 4);
+        sg_l++;
+    };
+    auto launch = [&]() {
+        v4i bop;
+        const int raw[4] = {n_braw.x, n_braw.y, n_braw.z, n_braw.w};
+        if constexpr (FMT == T_Q8_0) {
+            bop[0] = raw[0]; bop[1] = raw[1]; bop[2] = raw[2]; bop[3] = raw[3];
+        } else if constexpr (FMT == T_Q4_0) {
+            // signed (q - 8) placed in the HIGH nibble: the MFMA returns 16 x the block sum, the token scales carry 1/16
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int t = h ? raw[i] : (raw[i] << 4); bop[i] = (t & (int) 0xF0F0F0F0) ^ (int) 0x80808080; }
+        } else if constexpr (FMT == T_Q4_1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) bop[i] = (raw[i] >> (4 * h)) & 0x0F0F0F0F;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned nl = (n_qhw >> (16 * h + 4 * i)) & 0xFu;
+                bop[i] = ((raw[i] >> (4 * h)) & 0x0F0F0F0F) | (int) (((nl * 0x00204081u) & 0x01010101u) << 4);
+            }
+        }
+        dw_l = h2f_bits((uint16_t) (n_scw & 0xFFFFu));
+        if constexpr (M::HM) mw_l = h2f_bits((uint16_t) (n_scw >> 16));
+        asm volatile("" : "+v"(dw_l), "+v"(mw_l));     // (converted here, while n_scw is live: not sunk to the next step's fold)
+        v16i z;
+#pragma unroll
+        for (int r = 0; r < 16; r++) z[r] = 0;
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(n_aop, bop, z, 0, 0, 0);
+    };
+    // token scales of step sg -> dd (raw d_x: multiplied by d_w in place just before the fold), aux = s (HM) / o (XO).
+    // Tokens of register r: (r & 3) + 8 (r >> 2) + 4 h.
+    auto read_scales = [&](int sg) {
+        const unsigned char * S = lds + (size_t) (sg & (2 * M::CH - 1)) * M::SLOT;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 dx4 = *reinterpret_cast<const float4 *>(S + M::OFF_XD + (tg * 32 + 8 * g + 4 * h) * 4);
+            dd[2 * g] = (v2f){dx4.x, dx4.y};
+            dd[2 * g + 1] = (v2f){dx4.z, dx4.w};
+            if constexpr (M::HM || M::XO) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(S + (M::HM ? M::OFF_XS : M::OFF_XO) + (tg * 32 + 8 * g + 4 * h) * 4);
+                aux[2 * g] = (v2f){a4.x, a4.y}; aux[2 * g + 1] = (v2f){a4.z, a4.w};
             }
         }
     };
-
-    // two chunk buffers (a third one in flight was measured: no gain -- the kernel is bound by its VALU work, not by the DMA)
-    const int n_chunks = (nb + 7) / 8;
-    issue(0);
+    int sigma = 0;
+    // One step: fold block sigma into cur (FIRST: the leaf's first block, cur = fma(.., .., +0)), start block sigma + 1, read block
+    // sigma + 2. Every LDS read is issued a stage before its use: the eight waves of the workgroup run in lock-step between the chunk
+    // barriers, so a read that is waited for right away queues behind everybody else's (measured: 46 % of the wave cycles in waits).
+    auto step = [&](v2f (&cur)[8], auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        v2f sf[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            sf[j] = (v2f){(float) acc[2 * j], (float) acc[2 * j + 1]};
+            if constexpr (M::XO) sf[j] = sf[j] - aux[j];            // exact: integers below 2^24
+        }
+        const float mw_c = mw_l, dw_c = dw_l;
+        // (opaque uses pin the order: the sums leave `acc` before the next MFMA is issued into the same registers, and the fold
+        //  releases dd / aux before the next step's scales are read into them -- otherwise the compiler pipelines by rotating
+        //  16 + 16 registers with copies at the end of every step)
+#define PIN8(A) asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]))
+        PIN8(sf);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (M::OVERLAP) launch();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const v2f zero = {0.0f, 0.0f};
+            const v2f ddj = (v2f){dw_c, dw_c} * dd[j];
+            cur[j] = __builtin_elementwise_fma(ddj, sf[j], FIRST ? zero : cur[j]);
+            if constexpr (M::HM) cur[j] = __builtin_elementwise_fma((v2f){mw_c, mw_c}, aux[j], cur[j]);
+        }
+        PIN8(cur);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!M::OVERLAP) launch();
+        read_scales(sigma + 1);                 // into the registers the fold has just released
+        load_ops();
+        __builtin_amdgcn_sched_barrier(0);
+#undef PIN8
+        sigma++;
+    };
+    load_ops();          // operands of step 0
+    launch();            // block sums of step 0 under way
+    read_scales(0);
+    load_ops();          // operands of step 1
 
     // ---- the walk: leaves in bit-reversed order, 8 per iteration of the outer loop (the merges are compile-time code) ----
-    float s0[16], s1[16], s2[16], S3[16], S4[16], S5[16], V[16];
-    int sigma = 0;
+    v2f s0[8], s1[8], s2[8], S3[8], S4[8], S5[8], V[8];
+    v2f * stk = reinterpret_cast<v2f *>(lds + 2 * M::CH * M::SLOT);   // [level][j][thread]
     constexpr int REV3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
 #pragma unroll 1
     for (int a = 0; a < 8; a++) {
@@ -245,96 +385,54 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
         for (int u = 0; u < 8; u++) {
             const int l = 8 * REV3[u] + ra;
             // A leaf whose value starts a new subtree (even u) accumulates straight into s0: no copy. Other leaves use `tmp`.
-            float tmp[16];
-            float (&cur)[16] = (u & 1) ? tmp : s0;
+            v2f tmp[8];
+            v2f (&cur)[8] = (u & 1) ? tmp : s0;
+#if 1
+            if (l < nb) {
+                step(cur, std::true_type{});
+                for (int b = l + 64; b < nb; b += 64) step(cur, std::false_type{});
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++) cur[r] = 0.0f;
-            for (int b = l; b < nb; b += 64) {
-                if ((sigma & 7) == 0) {
-                    // chunk boundary: this wave's part of chunk k has landed (issued one chunk ago); after the barrier everybody's
-                    // has, and every wave has left the buffer the next chunk goes into
-                    const int k = sigma >> 3;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (k + 1 < n_chunks) issue(k + 1);
-                }
-                const unsigned char * S = lds + (size_t) (sigma & 15) * M::SLOT;
-                // operands
-                const int4 braw = *reinterpret_cast<const int4 *>(S + M::OFF_WC + (M::Q8 ? (rg * 64 + h * 32 + nn) : (rg * 32 + nn)) * 16);
-                const unsigned scw = *reinterpret_cast<const unsigned *>(S + M::OFF_WSC + (rg * 32 + nn) * 4);
-                const v4i aop = *reinterpret_cast<const v4i *>(S + M::OFF_XQ + (tg * 64 + lane) * 16);
-                v4i bop;
-                const int raw[4] = {braw.x, braw.y, braw.z, braw.w};
-                if constexpr (FMT == T_Q8_0) {
-                    bop[0] = raw[0]; bop[1] = raw[1]; bop[2] = raw[2]; bop[3] = raw[3];
-                } else if constexpr (FMT == T_Q4_0) {
-                    // signed (q - 8) placed in the HIGH nibble: the MFMA returns 16 x the block sum, the token scales carry 1/16
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { const int t = h ? raw[i] : (raw[i] << 4); bop[i] = (t & (int) 0xF0F0F0F0) ^ (int) 0x80808080; }
-                } else if constexpr (FMT == T_Q4_1) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) bop[i] = (raw[i] >> (4 * h)) & 0x0F0F0F0F;
-                } else {
-                    const unsigned qhw = *reinterpret_cast<const unsigned *>(S + M::OFF_WQH + (rg * 32 + nn) * 4);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const unsigned nl = (qhw >> (16 * h + 4 * i)) & 0xFu;
-                        bop[i] = ((raw[i] >> (4 * h)) & 0x0F0F0F0F) | (int) (((nl * 0x00204081u) & 0x01010101u) << 4);
-                    }
-                }
-                const float dw = h2f_bits((uint16_t) (scw & 0xFFFFu));
-                const float mw = M::HM ? h2f_bits((uint16_t) (scw >> 16)) : 0.0f;
-                v16i acc;
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[r] = 0;
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop, bop, acc, 0, 0, 0);
-                // fold the block: tokens of register r: (r & 3) + 8 (r >> 2) + 4 h
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const float4 dx4 = *reinterpret_cast<const float4 *>(S + M::OFF_XD + (tg * 32 + 8 * g + 4 * h) * 4);
-                    const float dxv[4] = {dx4.x, dx4.y, dx4.z, dx4.w};
-                    float aux[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if constexpr (M::HM || M::XO) {
-                        const float4 a4 = *reinterpret_cast<const float4 *>(S + (M::HM ? M::OFF_XS : M::OFF_XO) + (tg * 32 + 8 * g + 4 * h) * 4);
-                        aux[0] = a4.x; aux[1] = a4.y; aux[2] = a4.z; aux[3] = a4.w;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int r = 4 * g + q;
-                        float sf = (float) acc[r];
-                        if constexpr (M::XO) sf = sf - aux[q];        // exact: integers below 2^24
-                        const float dd = dw * dxv[q];
-                        cur[r] = fmaf(dd, sf, cur[r]);
-                        if constexpr (M::HM) cur[r] = fmaf(mw, aux[q], cur[r]);
-                    }
-                }
-                sigma++;
+                for (int j = 0; j < 8; j++) cur[j] = (v2f){0.0f, 0.0f};
             }
+#else
+#pragma unroll
+            for (int j = 0; j < 8; j++) cur[j] = (v2f){0.0f, 0.0f};
+            for (int b = l; b < nb; b += 64) step(cur, std::false_type{});
+#endif
             // merges after leaf c = 8 a + u: one per trailing one bit of c
             if (u == 1 || u == 5) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) s1[r] = s0[r] + cur[r];
+                for (int j = 0; j < 8; j++) s1[j] = s0[j] + cur[j];
             } else if (u == 3) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) { const float t = s0[r] + cur[r]; s2[r] = s1[r] + t; }
+                for (int j = 0; j < 8; j++) { const v2f t = s0[j] + cur[j]; s2[j] = s1[j] + t; }
             } else if (u == 7) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) { const float t = s0[r] + cur[r]; const float t2 = s1[r] + t; V[r] = s2[r] + t2; }
+                for (int j = 0; j < 8; j++) { const v2f t = s0[j] + cur[j]; const v2f t2 = s1[j] + t; V[j] = s2[j] + t2; }
             }
         }
+        // the upper levels of the stack are touched once per 8 / 16 / 32 leaves: STK_LDS of them (from the top) live in LDS
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));        // (addresses recomputed here, not kept across the walk)
+        v2f * const stk_t = stk + tid_o;
+#define STK_GET(LV, REG) (M::STK_LDS > (LV) ? stk_t[((LV) * 8 + j) * M::NT] : REG[j])
+#define STK_PUT(LV, REG, VAL) do { if constexpr (M::STK_LDS > (LV)) stk_t[((LV) * 8 + j) * M::NT] = (VAL); else REG[j] = (VAL); } while (0)
         if ((a & 1) == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) S3[r] = V[r];
+            for (int j = 0; j < 8; j++) STK_PUT(2, S3, V[j]);
         } else if ((a & 2) == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) S4[r] = S3[r] + V[r];
+            for (int j = 0; j < 8; j++) { const v2f t = STK_GET(2, S3) + V[j]; STK_PUT(1, S4, t); }
         } else if ((a & 4) == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) { const float t = S3[r] + V[r]; S5[r] = S4[r] + t; }
+            for (int j = 0; j < 8; j++) { const v2f t = STK_GET(2, S3) + V[j]; const v2f t2 = STK_GET(1, S4) + t; STK_PUT(0, S5, t2); }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++) { const float t = S3[r] + V[r]; const float t2 = S4[r] + t; V[r] = S5[r] + t2; }
+            for (int j = 0; j < 8; j++) { const v2f t = STK_GET(2, S3) + V[j]; const v2f t2 = STK_GET(1, S4) + t; V[j] = STK_GET(0, S5) + t2; }
         }
+#undef STK_GET
+#undef STK_PUT
     }
     // ---- epilogue: row n = column of the tile (lane), tokens along the registers ----
     const int64_t n = (int64_t) (rt0 + rg) * 32 + nn;
@@ -342,7 +440,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int64_t t = (int64_t) (tt0 + tg) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (t < T) y[t * ldy + n] = apply_epi(epi, V[r], t, n, ldy);
+            if (t < T) y[t * ldy + n] = apply_epi(epi, V[r >> 1][r & 1], t, n, ldy);
         }
     }
 }
@@ -536,7 +634,7 @@ static void walk_order(int nb, std::vector<unsigned short> & out, std::vector<un
 static std::mutex g_pf_mu;
 
 // device tables per (device, row length): a few hundred bytes each, kept for the life of the process
-struct WalkTab { unsigned short * order; unsigned * walk; int n_walk; };
+struct WalkTab { int * order; };
 static std::unordered_map<long long, WalkTab> g_walk_tables;
 
 static const WalkTab * walk_table(int nb) {
@@ -550,12 +648,11 @@ static const WalkTab * walk_table(int nb) {
     std::vector<unsigned short> o;
     std::vector<unsigned> wk;
     walk_order(nb, o, wk);
-    unsigned char * d = nullptr;
-    const size_t ob = (o.size() * sizeof(unsigned short) + 255) / 256 * 256;
-    if (hipMalloc((void **) &d, ob + wk.size() * sizeof(unsigned) + 64) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, o.data(), o.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d + ob, wk.data(), wk.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(d); return nullptr; }
-    WalkTab wt{(unsigned short *) d, (unsigned *) (d + ob), (int) wk.size()};
+    std::vector<int> o32(o.begin(), o.end());
+    int * d = nullptr;
+    if (hipMalloc((void **) &d, o32.size() * sizeof(int) + 64) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, o32.data(), o32.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(d); return nullptr; }
+    WalkTab wt{d};
     walk_tables[key] = wt;
     return &walk_tables[key];
 }
@@ -621,7 +718,7 @@ static bool launch_mmq_mfma_t(const DevTensor & W, const TileAct & x, int64_t T,
     const WalkTab * wt = walk_table(nb);
     if (!wt || !ensure_pf(W, st)) return false;
     const int RT = (int) ((N + 31) / 32), RP = (RT + M::RGN - 1) / M::RGN, C = (int) ((T + 63) / 64);
-    const size_t lds = (size_t) 16 * M::SLOT;
+    const size_t lds = (size_t) M::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) { (void) hipFuncSetAttribute((const void *) k_mmq_mfma<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr_set = true; }
     const unsigned grid = (unsigned) (((RP + 7) / 8) * 8 * C);
