@@ -274,22 +274,43 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
     v2f dd[8], aux[8];
     float dw_l = 0.0f, mw_l = 0.0f;            // scales of the step in `acc`
     int sg_l = 0;                                // next step to read from LDS
+    int to_bnd = 0;                              // steps until the next chunk boundary
+    unsigned off_l = 0, off_s = 0;               // LDS byte offset of the slot of step sg_l / of the slot before it
+    // per-lane address parts (opaque: kept as one VGPR each, the wave-uniform terms are not split off into scalar adds per step)
+    unsigned a_braw = (unsigned) (M::OFF_WC + (M::Q8 ? (rg * 64 + h * 32 + nn) : (rg * 32 + nn)) * 16);
+    unsigned a_scw = (unsigned) (M::OFF_WSC + (rg * 32 + nn) * 4);
+    unsigned a_aop = (unsigned) (M::OFF_XQ + (tg * 64 + lane) * 16);
+    unsigned a_xd = (unsigned) (M::OFF_XD + (tg * 32 + 4 * h) * 4);
+    asm volatile("" : "+v"(a_braw), "+v"(a_scw), "+v"(a_aop), "+v"(a_xd));
     auto load_ops = [&]() {
-        if ((sg_l & (M::CH - 1)) == 0 && sg_l < nb) {
+        if (to_bnd == 0) {
             // chunk boundary: this wave's part of chunk k has landed (issued one chunk ago); after the barrier everybody's has, and
             // every wave has finished reading the buffer the next chunk goes into (its last reads are two stages back)
             const int k = sg_l / M::CH;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (k + 1 < n_chunks) issue(k + 1);
+            to_bnd = k + 1 < n_chunks ? M::CH : 0x40000000;      // (no boundary behind the last chunk)
         }
-        const unsigned char * S = lds + (size_t) (sg_l & (2 * M::CH - 1)) * M::SLOT;
-        n_braw = *reinterpret_cast<const int4 *>(S + M::OFF_WC + (M::Q8 ? (rg * 64 + h * 32 + nn) : (rg * 32 + nn)) * 16);
-        n_scw = *reinterpret_cast<const unsigned *>(S + M::OFF_WSC + (rg * 32 + nn) * 4);
-        n_aop = *reinterpret_cast<const v4i *>(S + M::OFF_XQ + (tg * 64 + lane) * 16);
-        if constexpr (M::QH) n_qhw = *reinterpret_cast<const unsigned *>(S + M::OFF_WQH + (rg * 32 + nn) * 4);
+        to_bnd--;
+        n_braw = *reinterpret_cast<const int4 *>(lds + (off_l + a_braw));
+        n_scw = *reinterpret_cast<const unsigned *>(lds + (off_l + a_scw));
+        n_aop = *reinterpret_cast<const v4i *>(lds + (off_l + a_aop));
+        if constexpr (M::QH) n_qhw = *reinterpret_cast<const unsigned *>(lds + (off_l + a_scw + (M::OFF_WQH - M::OFF_WSC)));
+        off_s = off_l;
+        off_l = off_l == (2 * M::CH - 1) * M::SLOT ? 0u : off_l + M::SLOT;
         sg_l++;
     };
+    // The MFMA accumulates onto the bit pattern of 1.5 * 2^23: for |sum| < 2^22 the result, read as a float, IS 12582912 + sum exactly,
+    // and one packed subtraction per register pair (exact) replaces two v_cvt_f32_i32. |sum| <= 32 * 128 * 127 < 2^19 for every format.
+    constexpr int   MAGIC_I = 0x4B400000;
+    constexpr float MAGIC_F = 12582912.0f;
+    v16i magic;
+#pragma unroll
+    for (int r = 0; r < 16; r++) magic[r] = MAGIC_I;
+    asm volatile("" : "+v"(magic));              // (kept in 16 registers: not rematerialised in front of every MFMA)
+    int nib_sh = h ? 0 : 4;                      // Q4_0: the lanes of the first half move the low nibbles into the high ones
+    asm volatile("" : "+v"(nib_sh));
     auto launch = [&]() {
         v4i bop;
         const int raw[4] = {n_braw.x, n_braw.y, n_braw.z, n_braw.w};
@@ -298,7 +319,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
         } else if constexpr (FMT == T_Q4_0) {
             // signed (q - 8) placed in the HIGH nibble: the MFMA returns 16 x the block sum, the token scales carry 1/16
 #pragma unroll
-            for (int i = 0; i < 4; i++) { const int t = h ? raw[i] : (raw[i] << 4); bop[i] = (t & (int) 0xF0F0F0F0) ^ (int) 0x80808080; }
+            for (int i = 0; i < 4; i++) { const int t = raw[i] << nib_sh; bop[i] = (t & (int) 0xF0F0F0F0) ^ (int) 0x80808080; }
         } else if constexpr (FMT == T_Q4_1) {
 #pragma unroll
             for (int i = 0; i < 4; i++) bop[i] = (raw[i] >> (4 * h)) & 0x0F0F0F0F;
@@ -312,22 +333,19 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
         dw_l = h2f_bits((uint16_t) (n_scw & 0xFFFFu));
         if constexpr (M::HM) mw_l = h2f_bits((uint16_t) (n_scw >> 16));
         asm volatile("" : "+v"(dw_l), "+v"(mw_l));     // (converted here, while n_scw is live: not sunk to the next step's fold)
-        v16i z;
-#pragma unroll
-        for (int r = 0; r < 16; r++) z[r] = 0;
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(n_aop, bop, z, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(n_aop, bop, magic, 0, 0, 0);
     };
     // token scales of step sg -> dd (raw d_x: multiplied by d_w in place just before the fold), aux = s (HM) / o (XO).
     // Tokens of register r: (r & 3) + 8 (r >> 2) + 4 h.
-    auto read_scales = [&](int sg) {
-        const unsigned char * S = lds + (size_t) (sg & (2 * M::CH - 1)) * M::SLOT;
+    auto read_scales = [&]() {                   // of the step whose codes load_ops read last
+        const unsigned char * S = lds + (off_s + a_xd);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const float4 dx4 = *reinterpret_cast<const float4 *>(S + M::OFF_XD + (tg * 32 + 8 * g + 4 * h) * 4);
+            const float4 dx4 = *reinterpret_cast<const float4 *>(S + 32 * g);
             dd[2 * g] = (v2f){dx4.x, dx4.y};
             dd[2 * g + 1] = (v2f){dx4.z, dx4.w};
             if constexpr (M::HM || M::XO) {
-                const float4 a4 = *reinterpret_cast<const float4 *>(S + (M::HM ? M::OFF_XS : M::OFF_XO) + (tg * 32 + 8 * g + 4 * h) * 4);
+                const float4 a4 = *reinterpret_cast<const float4 *>(S + ((M::HM ? M::OFF_XS : M::OFF_XO) - M::OFF_XD) + 32 * g);
                 aux[2 * g] = (v2f){a4.x, a4.y}; aux[2 * g + 1] = (v2f){a4.z, a4.w};
             }
         }
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
         v2f sf[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            sf[j] = (v2f){(float) acc[2 * j], (float) acc[2 * j + 1]};
+            sf[j] = (v2f){__int_as_float(acc[2 * j]), __int_as_float(acc[2 * j + 1])} - (v2f){MAGIC_F, MAGIC_F};
             if constexpr (M::XO) sf[j] = sf[j] - aux[j];            // exact: integers below 2^24
         }
         const float mw_c = mw_l, dw_c = dw_l;
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!M::OVERLAP) launch();
-        read_scales(sigma + 1);                 // into the registers the fold has just released
+        read_scales();                          // block sigma + 1, into the registers the fold has just released
         load_ops();
         __builtin_amdgcn_sched_barrier(0);
 #undef PIN8
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
     };
     load_ops();          // operands of step 0
     launch();            // block sums of step 0 under way
-    read_scales(0);
+    read_scales();
     load_ops();          // operands of step 1
 
     // ---- the walk: leaves in bit-reversed order, 8 per iteration of the outer loop (the merges are compile-time code) ----
