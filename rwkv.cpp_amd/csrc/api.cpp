@@ -614,14 +614,21 @@ RWKV_API bool rwkv_mi_test_mul_mat(int type, const void * w, int64_t K, int64_t 
                 if (chk(hipMalloc(&d_tile, tile_act_bytes(T, K)))) {
                     const TileAct ta = tile_act_at(d_tile, T, K);
                     launch_quantize_act_tiles((const float *) d_x, T, K, type, ta, st);
-                    if (!launch_mmq_mfma(W, ta, T, (float *) d_y, N, Epi(), st)) ok = false;
+                    // (with the workspace of the split walk, as the engine runs it: few-tile shapes take that path)
+                    MmqWs ws;
+                    void * d_ws = nullptr;
+                    const size_t ws_part = (size_t) 16 << 20;
+                    if (chk(hipMalloc(&d_ws, ws_part + 1024 * sizeof(int))) && chk(hipMemsetAsync((uint8_t *) d_ws + ws_part, 0, 1024 * sizeof(int), st))) {
+                        ws.part = (float *) d_ws; ws.part_bytes = ws_part; ws.counters = (int *) ((uint8_t *) d_ws + ws_part); ws.n_counters = 1024;
+                    }
+                    if (!launch_mmq_mfma(W, ta, T, (float *) d_y, N, Epi(), st, &ws)) ok = false;
                     chk(hipDeviceSynchronize());
                     if (const char * rep = getenv("RWKV_MI_TIME_MM")) {   // kernel timing aid (tools/gemm_bench.py): average of n back-to-back launches
                         const int n = atoi(rep);
                         hipEvent_t e0, e1;
                         if (n > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
                             (void) hipEventRecord(e0, st);
-                            for (int i = 0; i < n; i++) (void) launch_mmq_mfma(W, ta, T, (float *) d_y, N, Epi(), st);
+                            for (int i = 0; i < n; i++) (void) launch_mmq_mfma(W, ta, T, (float *) d_y, N, Epi(), st, &ws);
                             (void) hipEventRecord(e1, st);
                             (void) hipEventSynchronize(e1);
                             float ms = 0.0f;
@@ -632,6 +639,7 @@ RWKV_API bool rwkv_mi_test_mul_mat(int type, const void * w, int64_t K, int64_t 
                         }
                     }
                     (void) hipFree(d_tile);
+                    if (d_ws) (void) hipFree(d_ws);
                     free_pf(W);
                 }
             } else {

@@ -214,7 +214,9 @@ bool ensure_scratch(rwkv_context * ctx, int64_t T) {
     const size_t n_D = 3 + 6 + 6 + 3 + 1 + 1;  // x xn sx | m[6] | r k v g w a | t0 t1 t2 | out | v_first
     size_t total = n_D * fsz(D) + fsz(F) + 2 * fsz(LR) + align_up(D * sizeof(float), 256);
     total += align_up((size_t) T * KQ, 256) + 3 * align_up((size_t) T * (KQ / 32) * 4, 256);
-    if (T >= k_mfma_min_tokens) total += align_up(tile_act_bytes(T, (int64_t) KQ), 256);
+    constexpr size_t k_ws_part = (size_t) 16 << 20;   // split-walk partial sums: up to 64 tiles x 8 parts x 32 KiB
+    constexpr int    k_ws_counters = 1024;
+    if (T >= k_mfma_min_tokens) total += align_up(tile_act_bytes(T, (int64_t) KQ), 256) + 5 * align_up(tile_act_bytes(T, (int64_t) D), 256) + k_ws_part + k_ws_counters * sizeof(int);
     if (ctx->scratch) { HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream)); (void) hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_T = 0; }
     drop_graphs(ctx);
     HIP_CTX_OK(ctx, hipMalloc(&ctx->scratch, total));
@@ -233,7 +235,15 @@ bool ensure_scratch(rwkv_context * ctx, int64_t T) {
     b.qa.s = (float *) p; p += align_up((size_t) T * (KQ / 32) * 4, 256);
     b.qa.isum = (int *) p; p += align_up((size_t) T * (KQ / 32) * 4, 256);
     b.tile = nullptr;
-    if (T >= k_mfma_min_tokens) { b.tile = p; p += align_up(tile_act_bytes(T, (int64_t) KQ), 256); }
+    b.ws = MmqWs();
+    for (int i = 0; i < 5; i++) b.tiles[i] = nullptr;
+    if (T >= k_mfma_min_tokens) {
+        b.tile = p; p += align_up(tile_act_bytes(T, (int64_t) KQ), 256);
+        for (int i = 0; i < 5; i++) { b.tiles[i] = p; p += align_up(tile_act_bytes(T, (int64_t) D), 256); }
+        b.ws.part = (float *) p; b.ws.part_bytes = k_ws_part; p += k_ws_part;
+        b.ws.counters = (int *) p; b.ws.n_counters = k_ws_counters; p += k_ws_counters * sizeof(int);
+        HIP_CTX_OK(ctx, hipMemsetAsync(b.ws.counters, 0, k_ws_counters * sizeof(int), ctx->stream));
+    }
     ctx->scratch_T = T;
     return true;
 }
@@ -270,6 +280,33 @@ struct Runner {
     int64_t T, D, H, S;
     rwkv_context::Buf & b;
 
+    // inputs quantised ahead of their products, several per launch (sequence mode): source pointer -> tile image
+    struct Pre { const float * x = nullptr; int wtype = -1; int64_t K = 0; TileAct ta; } pre[5];
+    void prequant(int n, const float * const * xs, int64_t K, int wtype) {
+        for (auto & e : pre) e = Pre();
+        if (!(dtype_quantized(wtype) && T >= k_mfma_min_tokens && b.tiles[0] && K == D && n <= 5)) return;
+        TileAct tas[5];
+        for (int i = 0; i < n; i++) { tas[i] = tile_act_at(b.tiles[i], T, K); pre[i].x = xs[i]; pre[i].wtype = wtype; pre[i].K = K; pre[i].ta = tas[i]; }
+        launch_quantize_act_tiles_batched(n, xs, T, K, wtype, tas, st);
+    }
+    const TileAct * find_pre(const float * x, int64_t K, int wtype) const {
+        for (auto & e : pre) if (e.x == x && e.K == K && e.wtype == wtype) return &e.ta;
+        return nullptr;
+    }
+    void drop_pre() { for (auto & e : pre) e = Pre(); }
+
+    // y_i[T][N] = epi_i(W_i . x_i[T][K]) for up to 4 matrices of one shape: one launch in sequence mode when every input was quantised ahead
+    void mm_batch(int n, const DevTensor * const * Ws, const float * const * xs, float * const * ys, const Epi * epis) {
+        bool batched = T >= k_mfma_min_tokens && b.tile && !ctx->prof.on;
+        TileAct tas[4];
+        for (int i = 0; i < n && batched; i++) {
+            const TileAct * ta = find_pre(xs[i], Ws[i]->cols(), Ws[i]->type);
+            if (!ta || Ws[i]->type != Ws[0]->type || Ws[i]->rows() != Ws[0]->rows() || Ws[i]->cols() != Ws[0]->cols()) batched = false; else tas[i] = *ta;
+        }
+        if (batched && launch_mmq_mfma_batched(n, Ws, tas, ys, epis, T, Ws[0]->rows(), &b.ws, st)) return;
+        for (int i = 0; i < n; i++) mm(Ws[i], xs[i], ys[i], epis[i]);
+    }
+
     // y[T][N] = epi(W . x[T][K])    (ggml_mul_mat)
     void mm(const DevTensor * W, const float * x, float * y, const Epi & epi = Epi()) {
         const int64_t N = W->rows(), K = W->cols();
@@ -277,8 +314,9 @@ struct Runner {
         //  23.6 ms per 1024-token pass)
         if (dtype_quantized(W->type) && T >= k_mfma_min_tokens && b.tile) {
             // sequence mode: int8 GEMM on the matrix cores (prefill.hip), bit-identical to the single-token kernel per (row, token)
-            const TileAct ta = tile_act_at(b.tile, T, K);
-            launch_quantize_act_tiles(x, T, K, W->type, ta, st);
+            TileAct ta;
+            if (const TileAct * p = find_pre(x, K, W->type)) ta = *p;
+            else { ta = tile_act_at(b.tile, T, K); launch_quantize_act_tiles(x, T, K, W->type, ta, st); }
             auto & pf = ctx->prof;
             if (pf.on) {   // live per-launch timing of the GEMM (rwkv_mi_profile_prefill): `bytes` carries the launch's integer operations
                 if (pf.used * 2 + 2 > pf.events.size()) {
@@ -289,7 +327,7 @@ struct Runner {
                 pf.bytes[pf.used] = 2ull * (uint64_t) T * (uint64_t) N * (uint64_t) K;
                 (void) hipEventRecord(pf.events[pf.used * 2], st);
             }
-            if (!launch_mmq_mfma(*W, ta, T, y, N, epi, st)) ctx->last_error |= RWKV_ERROR_GRAPH | RWKV_ERROR_ALLOC;
+            if (!launch_mmq_mfma(*W, ta, T, y, N, epi, st, &b.ws)) ctx->last_error |= RWKV_ERROR_GRAPH | RWKV_ERROR_ALLOC;
             if (pf.on) { (void) hipEventRecord(pf.events[pf.used * 2 + 1], st); pf.used++; }
         } else if (dtype_quantized(W->type)) {
             launch_quantize_act(x, T, K, b.qa, st);
@@ -331,11 +369,13 @@ struct Runner {
         else { a.mode = 1; a.n_out = 1; a.coef[0] = f(L.ffn_x_k); }
         a.out[0] = b.m[0]; a.out[1] = b.m[1];
         launch_mix(a, T, D, st);
+        if (m.arch_major != 7) { const float * xs[2] = {b.m[0], b.m[1]}; prequant(2, xs, D, L.ffn_key->type); }
         mm(L.ffn_key, b.m[0], b.ffk, epi(EPI_RELU_SQ));
         if (m.arch_major == 7) {
             mm(L.ffn_value, b.ffk, b.x, epi(EPI_ADD_RES, nullptr, b.x));
         } else {
             mm(L.ffn_receptance, b.m[1], b.r);
+            drop_pre();
             mm(L.ffn_value, b.ffk, b.x, epi(EPI_SIGMUL_ADD_RES, nullptr, b.x, b.r));
         }
     }
@@ -387,11 +427,17 @@ struct Runner {
         v.maa[3] = f(L.att_time_maa_r); v.maa[4] = f(L.att_time_maa_g);
         for (int i = 0; i < 5; i++) v.out[i] = b.m[i];  // xw, xk, xv, xr, xg
         if (!(T >= k_mfma_min_tokens && launch_v6_mix2_seq(v, T, D, R, st))) launch_v6_mix2(v, T, D, R, st);
-        mm(L.att_receptance, b.m[3], b.r);
-        mm(L.att_key, b.m[1], b.k);
-        mm(L.att_value, b.m[2], b.v);
-        mm(L.att_gate, b.m[4], b.g, epi(EPI_SILU));
+        {
+            // the five mixed inputs are quantised by one launch, the four D x D projections run as one launch (sequence mode)
+            const float * xs[5] = {b.m[3], b.m[1], b.m[2], b.m[4], b.m[0]};
+            prequant(5, xs, D, L.att_receptance->type);
+            const DevTensor * Ws[4] = {L.att_receptance, L.att_key, L.att_value, L.att_gate};
+            float * ys[4] = {b.r, b.k, b.v, b.g};
+            const Epi es[4] = {Epi(), Epi(), Epi(), epi(EPI_SILU)};
+            mm_batch(4, Ws, xs, ys, es);
+        }
         mm(L.att_time_decay_w1, b.m[0], b.lr2, epi(EPI_TANH));
+        drop_pre();
         // decay_w2 consumes [T][DR] rows of lr2
         mm(L.att_time_decay_w2, b.lr2, b.w, epi(EPI_V6_DECAY, f(L.att_time_decay)));
         wkv6(b.r, b.k, b.v, f(L.att_time_faaaa), 1, b.w, 2, sin + 2 * D, sout + 2 * D, b.out);

@@ -69,7 +69,14 @@ struct TileAct {   // quantised activations of T tokens in the tile-major image 
 size_t  tile_act_bytes(int64_t T, int64_t K);
 TileAct tile_act_at(void * base, int64_t T, int64_t K);
 void launch_quantize_act_tiles(const float * x, int64_t T, int64_t K, int wtype, const TileAct & out, hipStream_t st);
-bool launch_mmq_mfma(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st);
+// up to 5 inputs of the same shape in one launch
+void launch_quantize_act_tiles_batched(int n, const float * const * xs, int64_t T, int64_t K, int wtype, const TileAct * outs, hipStream_t st);
+// workspace of the split walk (GEMMs with too few output tiles for the chip): partial sums + one zeroed counter per tile
+struct MmqWs { float * part = nullptr; size_t part_bytes = 0; int * counters = nullptr; int n_counters = 0; };
+bool launch_mmq_mfma(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st, const MmqWs * ws = nullptr);
+// up to 4 products of the same shape and type in one launch (y_i = epi_i(W_i . x_i))
+bool launch_mmq_mfma_batched(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy,
+                             const MmqWs * ws, hipStream_t st);
 bool ensure_pf(const DevTensor & W, hipStream_t st);
 void free_pf(const DevTensor & W);
 bool launch_wkv6_seq(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
@@ -115,6 +122,8 @@ struct rwkv_context {
         float *x, *xn, *sx, *m[6], *r, *k, *v, *g, *w, *a, *t0, *t1, *t2, *out, *ffk, *lr1, *lr2, *v_first, *xlast;
         rwkvmi::QAct qa;
         void * tile = nullptr;   // tile-major quantised activations (T >= k_mfma_min_tokens)
+        void * tiles[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the same for inputs quantised ahead, several per launch (row length D)
+        rwkvmi::MmqWs ws;         // workspace of the split walk (prefill.hip)
     } b{};
 
     uint32_t * d_tokens = nullptr;

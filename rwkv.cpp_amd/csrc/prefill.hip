@@ -91,8 +91,14 @@ __global__ __launch_bounds__(256) void k_pf_repack(int type, const uint8_t * __r
 // One wave = one (token tile, block): lane = half * 32 + i owns the 16 elements of its half of token i's block -- exactly its
 // 16 bytes of the A-operand image, so the wave reads 32 full 128-byte lines and writes one contiguous KiB. The block's amax and
 // code sum combine the two halves through one permlane32 swap (max and integer sum are order-free: same result as k_quant_act).
-__global__ __launch_bounds__(256) void k_quant_act_tiles(const float * __restrict__ x, int64_t T, int64_t T_pad, int nb, float dscale, float off,
-                                                         int8_t * __restrict__ q, float * __restrict__ d, float * __restrict__ s, float * __restrict__ o) {
+constexpr int QUANT_BATCH = 5;                // inputs per launch (blockIdx.y): e.g. the five mixed inputs of an RWKV-6 time-mixing block
+struct QuantBatch { const float * x[QUANT_BATCH]; int8_t * q[QUANT_BATCH]; float * d[QUANT_BATCH]; float * s[QUANT_BATCH]; float * o[QUANT_BATCH]; };
+__global__ __launch_bounds__(256) void k_quant_act_tiles(QuantBatch qb, int64_t T, int64_t T_pad, int nb, float dscale, float off) {
+    const float * __restrict__ const x = qb.x[blockIdx.y];
+    int8_t * __restrict__ const q = qb.q[blockIdx.y];
+    float * __restrict__ const d = qb.d[blockIdx.y];
+    float * __restrict__ const s = qb.s[blockIdx.y];
+    float * __restrict__ const o = qb.o[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int64_t wv = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);   // (tt, b)
     const int64_t n_tiles = (T_pad >> 5) * nb;
@@ -163,7 +169,7 @@ template <int FMT> struct MF {
     static constexpr int  P_WSC = ROWS / 4, P_WQH = QH ? ROWS / 4 : 0, P_XD = 16, P_XS = HM ? 16 : 0, P_XO = XO ? 16 : 0;
     static constexpr int  P_TAIL = P_WSC + P_WQH + P_XD + P_XS + P_XO, NTR = (P_TAIL + 63) / 64, NR = NW + 2 + NTR;   // rows per step
     // steps per chunk; stack levels kept in LDS (64 B per thread each) so that two chunks of 8 steps + the levels fit in 160 KiB
-    static constexpr bool OVERLAP = true;                       // the MFMA of step sigma + 1 runs under the fold of step sigma
+    static constexpr bool OVERLAP = !(QH && HM);                // the MFMA of step sigma + 1 runs under the fold of step sigma (Q5_1: no registers for it)
     static constexpr int CH = 8, STK_LDS = Q8 ? 1 : 2;
     static constexpr int LDS_BYTES = 2 * CH * SLOT + STK_LDS * 64 * NT;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -172,16 +178,44 @@ template <int FMT> struct MF {
 struct PfW { const uint8_t * qs; const uint32_t * sc; const uint32_t * qh; };
 struct PfX { const int8_t * q; const float * d; const float * s; const float * o; };
 
+// One launch = up to MMQ_BATCH products of the same shape (blockIdx.y: e.g. the r / k / v / g projections of a layer), each cut
+// along the walk into `split` parts (blockIdx.z) when the output has too few tiles to fill the chip: the outer iterations a of the
+// walk are the 8 subtrees below level 3 of the reduction tree, so part z walks a in [8 z / split, 8 (z + 1) / split) and ends with
+// the sum of its subtree; the workgroup that arrives last on the tile's counter adds the parts in tree order -- the same additions.
+constexpr int MMQ_BATCH = 4;
+struct MmqArgs {
+    PfW w[MMQ_BATCH]; PfX x[MMQ_BATCH]; float * y[MMQ_BATCH]; Epi epi[MMQ_BATCH];
+    int64_t N, T, ldy;
+    int nb, RT /* row tiles of 32 */, C /* token tiles of 64 */, split;
+    const int * order;       // walk order of the blocks
+    int a_start[9];          // steps of the walk before outer iteration a = 0 .. 8
+    float * part;            // [split][tile][thread][16] partial sums (split > 1)
+    int * counters;          // [tile], zero between launches
+};
+
 template <int FMT>
-__global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64_t N, int nb, int64_t T, int RT /* row tiles of 32 */, int C /* token tiles of 64 */,
-                                                  const int * __restrict__ order, float * __restrict__ y, int64_t ldy, Epi epi) {
+__global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
     typedef MF<FMT> M;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int64_t N = A.N, T = A.T, ldy = A.ldy;
+    const int nb = A.nb, RT = A.RT, C = A.C;
     // XCD-aware tile map: block id -> XCD id % 8; the token tiles of one 128-row panel run on the same XCD and share its L2
+    // (with fewer than 8 row panels that map would leave whole XCDs idle: dense map, consecutive blocks = different XCDs)
+    const int RP = (RT + M::RGN - 1) / M::RGN;
     const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
-    const int rp = (kk / C) * 8 + xcd;          // row panel (RGN row tiles)
-    const int ct = kk % C;                       // token tile of 64
+    const int rp = RP < 8 ? (int) blockIdx.x % RP : (kk / C) * 8 + xcd;          // row panel (RGN row tiles)
+    const int ct = RP < 8 ? (int) blockIdx.x / RP : kk % C;                       // token tile of 64
     if (rp * M::RGN >= RT) return;               // (whole workgroup: before any barrier)
+    const int bz = blockIdx.y;
+    const PfW w = A.w[bz];
+    const PfX x = A.x[bz];
+    float * __restrict__ const y = A.y[bz];
+    const Epi epi = A.epi[bz];
+    const int a0 = (int) blockIdx.z * (8 / A.split), a1 = a0 + 8 / A.split;
+    const int s_base = A.a_start[a0], n_steps = A.a_start[a1] - s_base;            // this part's steps of the walk
+    // (constant address space: the block numbers are read with scalar loads -- a vector load here would share vmcnt with the DMAs)
+    typedef const int __attribute__((address_space(4))) * cint_p;
+    const cint_p order = (cint_p) (uintptr_t) A.order + s_base;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave % M::RGN, tg = wave / M::RGN;
@@ -194,7 +228,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
     const unsigned lds_base = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) lds;
     const int st_w = wave % M::CH, sub_w = wave / M::CH;
     constexpr int NSUB = 8 / M::CH;
-    auto blk_of = [&](int k) { int step = M::CH * k + st_w; step = step < nb ? step : nb - 1; return order[step]; };   // (tail: harmless duplicates)
+    auto blk_of = [&](int k) { int step = M::CH * k + st_w; step = step < n_steps ? step : n_steps - 1; return order[step]; };   // (tail: harmless duplicates)
     int b_nx = blk_of(0);                        // block of this wave's step in the chunk issued next (read one chunk ahead)
     auto dma_s = [&](const unsigned char * sbase, unsigned voff, unsigned dst) {
         // Issued through inline asm on purpose: the compiler cannot prove that an LDS-DMA does not alias the operand reads of the
@@ -259,7 +293,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
     };
 
     // two chunk buffers (a third one in flight was measured: no gain)
-    const int n_chunks = (nb + M::CH - 1) / M::CH;
+    const int n_chunks = (n_steps + M::CH - 1) / M::CH;
     issue(0);
 
     // ---- software pipeline. Step sigma = one quantisation block of the walk. While the f32 fold of step sigma runs on the VALU,
@@ -396,8 +430,9 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
     v2f s0[8], s1[8], s2[8], S3[8], S4[8], S5[8], V[8];
     v2f * stk = reinterpret_cast<v2f *>(lds + 2 * M::CH * M::SLOT);   // [level][j][thread]
     constexpr int REV3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    const int rng = a1 - a0;                     // 8, or 4 / 2 / 1 for a part of a split walk: the merges stop at the part's own root
 #pragma unroll 1
-    for (int a = 0; a < 8; a++) {
+    for (int a = a0; a < a1; a++) {
         const int ra = ((a & 1) << 2) | (a & 2) | (a >> 2);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -436,21 +471,36 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
         v2f * const stk_t = stk + tid_o;
 #define STK_GET(LV, REG) (M::STK_LDS > (LV) ? stk_t[((LV) * 8 + j) * M::NT] : REG[j])
 #define STK_PUT(LV, REG, VAL) do { if constexpr (M::STK_LDS > (LV)) stk_t[((LV) * 8 + j) * M::NT] = (VAL); else REG[j] = (VAL); } while (0)
-        if ((a & 1) == 0) {
+        const int al = a - a0;                   // (a0 is a multiple of rng: al < rng)
+        if ((al & 1) == 0) {
+            if (rng > 1) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) STK_PUT(2, S3, V[j]);
-        } else if ((a & 2) == 0) {
+                for (int j = 0; j < 8; j++) STK_PUT(2, S3, V[j]);
+            }
+        } else if ((al & 2) == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) { const v2f t = STK_GET(2, S3) + V[j]; STK_PUT(1, S4, t); }
-        } else if ((a & 4) == 0) {
+            for (int j = 0; j < 8; j++) { const v2f t = STK_GET(2, S3) + V[j]; if (rng == 2) V[j] = t; else STK_PUT(1, S4, t); }
+        } else if ((al & 4) == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) { const v2f t = STK_GET(2, S3) + V[j]; const v2f t2 = STK_GET(1, S4) + t; STK_PUT(0, S5, t2); }
+            for (int j = 0; j < 8; j++) {
+                const v2f t = STK_GET(2, S3) + V[j]; const v2f t2 = STK_GET(1, S4) + t;
+                if (rng == 4) V[j] = t2; else STK_PUT(0, S5, t2);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; j++) { const v2f t = STK_GET(2, S3) + V[j]; const v2f t2 = STK_GET(1, S4) + t; V[j] = STK_GET(0, S5) + t2; }
         }
 #undef STK_GET
 #undef STK_PUT
+    }
+    // ---- split walk: V is this part's subtree sum; k_mmq_combine adds the parts in tree order and applies the epilogue ----
+    if (A.split > 1) {
+        const int64_t n_tiles = (int64_t) gridDim.y * ((RT + M::RGN - 1) / M::RGN) * C;
+        const int64_t tile = ((int64_t) bz * ((RT + M::RGN - 1) / M::RGN) + rp) * C + ct;
+        v2f * const mine = reinterpret_cast<v2f *>(A.part) + ((blockIdx.z * n_tiles + tile) * M::NT + tid) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; j++) mine[j] = V[j];
+        return;
     }
     // ---- epilogue: row n = column of the tile (lane), tokens along the registers ----
     const int64_t n = (int64_t) (rt0 + rg) * 32 + nn;
@@ -459,6 +509,43 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(PfW w, PfX x, int64
         for (int r = 0; r < 16; r++) {
             const int64_t t = (int64_t) (tt0 + tg) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (t < T) y[t * ldy + n] = apply_epi(epi, V[r >> 1][r & 1], t, n, ldy);
+        }
+    }
+}
+
+
+// Second half of a split walk: thread (tile, tid) owns the same 16 outputs as in k_mmq_mfma; the parts are added pairwise in tree
+// order -- ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)) -- which are exactly the additions of the unsplit walk above level 3.
+template <int SPLIT>
+__global__ __launch_bounds__(512) void k_mmq_combine(MmqArgs A) {
+    constexpr int RGN = 4, NT = 512;
+    const int RP = (A.RT + RGN - 1) / RGN, C = A.C;
+    const int64_t n_tiles = (int64_t) gridDim.y * RP * C;
+    const int bz = blockIdx.y, rp = blockIdx.x / C, ct = blockIdx.x % C;
+    const int64_t tile = ((int64_t) bz * RP + rp) * C + ct;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = wave % RGN, tg = wave / RGN, nn = lane & 31, h = lane >> 5;
+    v2f R[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        v2f P[SPLIT];
+#pragma unroll
+        for (int z = 0; z < SPLIT; z++) P[z] = (reinterpret_cast<const v2f *>(A.part) + ((z * n_tiles + tile) * NT + tid) * 8)[j];
+#pragma unroll
+        for (int wd = 1; wd < SPLIT; wd <<= 1) {
+#pragma unroll
+            for (int z = 0; z < SPLIT; z += 2 * wd) P[z] = P[z] + P[z + wd];
+        }
+        R[j] = P[0];
+    }
+    const Epi epi = A.epi[bz];
+    float * __restrict__ const y = A.y[bz];
+    const int64_t n = (int64_t) (rp * RGN + rg) * 32 + nn;
+    if (n < A.N) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t t = (int64_t) (ct * 2 + tg) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (t < A.T) y[t * A.ldy + n] = apply_epi(epi, R[r >> 1][r & 1], t, n, A.ldy);
         }
     }
 }
@@ -652,7 +739,7 @@ static void walk_order(int nb, std::vector<unsigned short> & out, std::vector<un
 static std::mutex g_pf_mu;
 
 // device tables per (device, row length): a few hundred bytes each, kept for the life of the process
-struct WalkTab { int * order; };
+struct WalkTab { int * order; int a_start[9]; };
 static std::unordered_map<long long, WalkTab> g_walk_tables;
 
 static const WalkTab * walk_table(int nb) {
@@ -667,10 +754,25 @@ static const WalkTab * walk_table(int nb) {
     std::vector<unsigned> wk;
     walk_order(nb, o, wk);
     std::vector<int> o32(o.begin(), o.end());
+    // steps before outer iteration a (8 leaves each, in visiting order): where a part of a split walk starts
+    WalkTab wt{nullptr, {0}};
+    {
+        int steps = 0;
+        for (int a = 0; a <= 8; a++) {
+            wt.a_start[a] = steps;
+            if (a == 8) break;
+            for (int u = 0; u < 8; u++) {
+                const int c = 8 * a + u;
+                int l = 0;
+                for (int k = 0; k < 6; k++) if (c & (1 << k)) l |= 1 << (5 - k);
+                for (int b = l; b < nb; b += 64) steps++;
+            }
+        }
+    }
     int * d = nullptr;
     if (hipMalloc((void **) &d, o32.size() * sizeof(int) + 64) != hipSuccess) return nullptr;
     if (hipMemcpy(d, o32.data(), o32.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(d); return nullptr; }
-    WalkTab wt{d};
+    wt.order = d;
     walk_tables[key] = wt;
     return &walk_tables[key];
 }
@@ -719,42 +821,81 @@ TileAct tile_act_at(void * base, int64_t T, int64_t K) {
     return a;
 }
 
-void launch_quantize_act_tiles(const float * x, int64_t T, int64_t K, int wtype, const TileAct & out, hipStream_t st) {
+void launch_quantize_act_tiles_batched(int n, const float * const * xs, int64_t T, int64_t K, int wtype, const TileAct * outs, hipStream_t st) {
     const int nb = (int) (K / 32);
-    const int64_t n_tiles = (out.T_pad / 32) * nb;
+    const int64_t n_tiles = (outs[0].T_pad / 32) * nb;
     const float dscale = wtype == T_Q4_0 ? 0.0625f : 1.0f;
     const bool hm = wtype == T_Q4_1 || wtype == T_Q5_1, xo = wtype == T_Q5_0;
-    hipLaunchKernelGGL(k_quant_act_tiles, dim3((unsigned) ((n_tiles + 3) / 4)), dim3(256), 0, st, x, T, out.T_pad, nb, dscale, 16.0f,
-                       out.q, out.d, hm ? out.s : nullptr, xo ? out.o : nullptr);
+    QuantBatch qb;
+    for (int i = 0; i < QUANT_BATCH; i++) {
+        const int j = i < n ? i : 0;
+        qb.x[i] = xs[j]; qb.q[i] = outs[j].q; qb.d[i] = outs[j].d; qb.s[i] = hm ? outs[j].s : nullptr; qb.o[i] = xo ? outs[j].o : nullptr;
+    }
+    hipLaunchKernelGGL(k_quant_act_tiles, dim3((unsigned) ((n_tiles + 3) / 4), (unsigned) n), dim3(256), 0, st, qb, T, outs[0].T_pad, nb, dscale, 16.0f);
+}
+
+void launch_quantize_act_tiles(const float * x, int64_t T, int64_t K, int wtype, const TileAct & out, hipStream_t st) {
+    launch_quantize_act_tiles_batched(1, &x, T, K, wtype, &out, st);
 }
 
 template <int FMT>
-static bool launch_mmq_mfma_t(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
+static bool launch_mmq_mfma_t(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy,
+                              const MmqWs * ws, hipStream_t st) {
     typedef MF<FMT> M;
-    const int64_t N = W.rows();
-    const int nb = (int) (W.cols() / 32);
+    const DevTensor & W0 = *Ws[0];
+    const int64_t N = W0.rows();
+    const int nb = (int) (W0.cols() / 32);
     const WalkTab * wt = walk_table(nb);
-    if (!wt || !ensure_pf(W, st)) return false;
+    if (!wt) return false;
+    MmqArgs A;
+    for (int i = 0; i < n; i++) if (!Ws[i]->pf_qs && !ensure_pf(*Ws[i], st)) return false;
+    for (int i = 0; i < MMQ_BATCH; i++) {
+        const int j = i < n ? i : 0;
+        A.w[i] = PfW{Ws[j]->pf_qs, Ws[j]->pf_sc, Ws[j]->pf_qh};
+        A.x[i] = PfX{xs[j].q, xs[j].d, xs[j].s, xs[j].o};
+        A.y[i] = ys[j];
+        A.epi[i] = epis[j];
+    }
     const int RT = (int) ((N + 31) / 32), RP = (RT + M::RGN - 1) / M::RGN, C = (int) ((T + 63) / 64);
+    // too few tiles for the chip and every leaf of the walk has a block: cut the walk (see MmqArgs)
+    int split = 1;
+    const int64_t tiles = (int64_t) n * RP * C;
+    if (ws && ws->part && nb >= 64) {
+        while (split < 8 && tiles * split * 2 <= 256) split *= 2;
+        while (split > 1 && (size_t) split * tiles * M::NT * 64 > ws->part_bytes) split /= 2;
+    }
+    A.N = N; A.T = T; A.ldy = ldy; A.nb = nb; A.RT = RT; A.C = C; A.split = split;
+    A.order = wt->order; for (int a = 0; a < 9; a++) A.a_start[a] = wt->a_start[a];
+    A.part = ws ? ws->part : nullptr; A.counters = ws ? ws->counters : nullptr;
     const size_t lds = (size_t) M::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) { (void) hipFuncSetAttribute((const void *) k_mmq_mfma<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr_set = true; }
-    const unsigned grid = (unsigned) (((RP + 7) / 8) * 8 * C);
-    PfW pw{W.pf_qs, W.pf_sc, W.pf_qh};
-    PfX px{x.q, x.d, x.s, x.o};
-    hipLaunchKernelGGL((k_mmq_mfma<FMT>), dim3(grid), dim3(M::NT), lds, st, pw, px, N, nb, T, RT, C, wt->order, y, ldy, epi);
+    const dim3 grid((unsigned) (RP < 8 ? RP * C : ((RP + 7) / 8) * 8 * C), (unsigned) n, (unsigned) split);
+    hipLaunchKernelGGL((k_mmq_mfma<FMT>), grid, dim3(M::NT), lds, st, A);
+    const dim3 cgrid((unsigned) (RP * C), (unsigned) n);
+    if (split == 2) hipLaunchKernelGGL(k_mmq_combine<2>, cgrid, dim3(512), 0, st, A);
+    else if (split == 4) hipLaunchKernelGGL(k_mmq_combine<4>, cgrid, dim3(512), 0, st, A);
+    else if (split == 8) hipLaunchKernelGGL(k_mmq_combine<8>, cgrid, dim3(512), 0, st, A);
     return true;
 }
 
-bool launch_mmq_mfma(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
-    switch (W.type) {
-        case T_Q4_0: return launch_mmq_mfma_t<T_Q4_0>(W, x, T, y, ldy, epi, st);
-        case T_Q4_1: return launch_mmq_mfma_t<T_Q4_1>(W, x, T, y, ldy, epi, st);
-        case T_Q5_0: return launch_mmq_mfma_t<T_Q5_0>(W, x, T, y, ldy, epi, st);
-        case T_Q5_1: return launch_mmq_mfma_t<T_Q5_1>(W, x, T, y, ldy, epi, st);
-        case T_Q8_0: return launch_mmq_mfma_t<T_Q8_0>(W, x, T, y, ldy, epi, st);
+bool launch_mmq_mfma_batched(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy,
+                             const MmqWs * ws, hipStream_t st) {
+    if (n < 1 || n > MMQ_BATCH) return false;
+    for (int i = 1; i < n; i++) if (Ws[i]->type != Ws[0]->type || Ws[i]->rows() != Ws[0]->rows() || Ws[i]->cols() != Ws[0]->cols()) return false;
+    switch (Ws[0]->type) {
+        case T_Q4_0: return launch_mmq_mfma_t<T_Q4_0>(n, Ws, xs, ys, epis, T, ldy, ws, st);
+        case T_Q4_1: return launch_mmq_mfma_t<T_Q4_1>(n, Ws, xs, ys, epis, T, ldy, ws, st);
+        case T_Q5_0: return launch_mmq_mfma_t<T_Q5_0>(n, Ws, xs, ys, epis, T, ldy, ws, st);
+        case T_Q5_1: return launch_mmq_mfma_t<T_Q5_1>(n, Ws, xs, ys, epis, T, ldy, ws, st);
+        case T_Q8_0: return launch_mmq_mfma_t<T_Q8_0>(n, Ws, xs, ys, epis, T, ldy, ws, st);
         default: return false;
     }
+}
+
+bool launch_mmq_mfma(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st, const MmqWs * ws) {
+    const DevTensor * Wp = &W;
+    return launch_mmq_mfma_batched(1, &Wp, &x, &y, &epi, T, ldy, ws, st);
 }
 
 }  // namespace rwkvmi
