@@ -525,27 +525,25 @@ __global__ __launch_bounds__(512) void k_mmq_combine(MmqArgs A) {
     const int64_t tile = ((int64_t) bz * RP + rp) * C + ct;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rg = wave % RGN, tg = wave / RGN, nn = lane & 31, h = lane >> 5;
-    v2f R[8];
+    // (blockIdx.z = register pair j of the thread's 16 outputs: eight times the workgroups, an eighth of the dependent loads each)
+    const int j = blockIdx.z;
+    v2f P[SPLIT];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        v2f P[SPLIT];
+    for (int z = 0; z < SPLIT; z++) P[z] = (reinterpret_cast<const v2f *>(A.part) + ((z * n_tiles + tile) * NT + tid) * 8)[j];
 #pragma unroll
-        for (int z = 0; z < SPLIT; z++) P[z] = (reinterpret_cast<const v2f *>(A.part) + ((z * n_tiles + tile) * NT + tid) * 8)[j];
+    for (int wd = 1; wd < SPLIT; wd <<= 1) {
 #pragma unroll
-        for (int wd = 1; wd < SPLIT; wd <<= 1) {
-#pragma unroll
-            for (int z = 0; z < SPLIT; z += 2 * wd) P[z] = P[z] + P[z + wd];
-        }
-        R[j] = P[0];
+        for (int z = 0; z < SPLIT; z += 2 * wd) P[z] = P[z] + P[z + wd];
     }
     const Epi epi = A.epi[bz];
     float * __restrict__ const y = A.y[bz];
     const int64_t n = (int64_t) (rp * RGN + rg) * 32 + nn;
     if (n < A.N) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int q = 0; q < 2; q++) {
+            const int r = 2 * j + q;
             const int64_t t = (int64_t) (ct * 2 + tg) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (t < A.T) y[t * A.ldy + n] = apply_epi(epi, R[r >> 1][r & 1], t, n, A.ldy);
+            if (t < A.T) y[t * A.ldy + n] = apply_epi(epi, P[0][q], t, n, A.ldy);
         }
     }
 }
@@ -564,91 +562,139 @@ __global__ __launch_bounds__(512) void k_mmq_combine(MmqArgs A) {
 // ring of 128 tokens (lane i reads row (sigma - i) mod 128, column i: conflict-free), refilled 64 tokens at a time through
 // registers, one pair of workgroup barriers per 64 steps. The workgroup = 8 waves = 8 adjacent columns of one head.
 // ---------------------------------------------------------------------------------------------------------------
+// Layout of the workgroup: 4 waves (one per SIMD), wave = TWO adjacent value columns j, j + 1 as the halves of packed-f32
+// registers (v_pk_mul / v_pk_add: one instruction per operation of both columns), 8 columns of one head per workgroup. The rings
+// hold RINGP = 128 + 3 rows: rows 128 .. 130 mirror rows 0 .. 2, so the four steps of a group read rows a, a + 1, a + 2, a + 3 of
+// one per-lane address with immediate offsets (no wrap inside a group). The reads of group g + 1 are issued before the arithmetic
+// of group g. Chunks whose 64 steps are valid for every lane (all but the first and the last ones) skip the validity selects.
 template <int WMODE>
-__global__ __launch_bounds__(512) void k_wkv6_seq(const float * __restrict__ r, const float * __restrict__ k, const float * __restrict__ v,
+__global__ __launch_bounds__(256, 1) void k_wkv6_seq(const float * __restrict__ r, const float * __restrict__ k, const float * __restrict__ v,
                                                   const float * __restrict__ u, int u_per_chan, const float * __restrict__ w,
                                                   const float * __restrict__ state_in, float * __restrict__ state_out, float * __restrict__ out,
                                                   int T, int H) {
-    constexpr int S = 64, RING = 128;
+    constexpr int S = 64, RING = 128, RINGP = RING + 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float * l_k = reinterpret_cast<float *>(lds_raw);            // [RING][64]; l_r at +RING*64 floats, l_w at +2*RING*64 (immediate offsets of one address)
-    float * l_v = l_k + 3 * RING * 64;                            // [8][RING]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float * l_k = reinterpret_cast<float *>(lds_raw);            // [RINGP][k 64 | r 64 | w 64]: one per-lane address, immediate offsets
+    v2f * l_v = reinterpret_cast<v2f *>(l_k + 3 * RINGP * 64);   // [4 column pairs][RINGP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t h = blockIdx.x >> 3;
-    const int j = (int) (blockIdx.x & 7) * 8 + wave;
+    const int cb = (int) (blockIdx.x & 7) * 8, j = cb + wave * 2;
     const int64_t D = (int64_t) H * S;
-    float s = state_in[h * S * S + (int64_t) lane * S + j];
+    v2f s = *reinterpret_cast<const v2f *>(state_in + h * S * S + (int64_t) lane * S + j);
     const float ui = u_per_chan ? u[h * S + lane] : u[h];
     const float wconst = WMODE == 2 ? 0.0f : (WMODE == 1 ? w[h * S + lane] : w[h]);
     const int n_chunks = (T + 63 + 63) / 64;   // steps 0 .. T + 62
 
-    // staging registers: chunk c = tokens [64 c, 64 c + 64): 64 x 16 float4 per array, two per thread
-    float4 gk0, gk1, gr0, gr1, gw0 = make_float4(0.f, 0.f, 0.f, 0.f), gw1 = gw0;
-    float gv;
-    auto issue = [&](int c) {
-        int t0 = 64 * c + (tid >> 4), t1 = t0 + 32;
-        t0 = t0 < T ? t0 : T - 1;                     // (clamped rows are never used: their steps are masked)
-        t1 = t1 < T ? t1 : T - 1;
-        const int64_t o0 = (int64_t) t0 * D + h * S + (tid & 15) * 4, o1 = (int64_t) t1 * D + h * S + (tid & 15) * 4;
-        gk0 = *reinterpret_cast<const float4 *>(k + o0); gk1 = *reinterpret_cast<const float4 *>(k + o1);
-        gr0 = *reinterpret_cast<const float4 *>(r + o0); gr1 = *reinterpret_cast<const float4 *>(r + o1);
-        if (WMODE == 2) { gw0 = *reinterpret_cast<const float4 *>(w + o0); gw1 = *reinterpret_cast<const float4 *>(w + o1); }
-        int t = 64 * c + lane;
-        t = t < T ? t : T - 1;
-        gv = v[(int64_t) t * D + h * S + j];
+    // staging registers: chunk c = tokens [64 c, 64 c + 64): 64 x 16 float4 per array, four per thread; 64 x 4 column pairs of v
+    float4 gk0, gk1, gk2, gk3, gr0, gr1, gr2, gr3, gw0, gw1, gw2, gw3;
+    gw0 = gw1 = gw2 = gw3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    v2f gv;
+    auto issue1 = [&](int c, int i, float4 & ak, float4 & ar, float4 & aw) __attribute__((always_inline)) {
+        int t = 64 * c + 16 * i + (tid >> 4);
+        t = t < T ? t : T - 1;                         // (clamped rows are never used: their steps are masked)
+        const int64_t o = (int64_t) t * D + h * S + (tid & 15) * 4;
+        ak = *reinterpret_cast<const float4 *>(k + o);
+        ar = *reinterpret_cast<const float4 *>(r + o);
+        if (WMODE == 2) aw = *reinterpret_cast<const float4 *>(w + o);
     };
-    auto commit = [&](int c) {
-        const int base = (c & 1) * 64;
-        const int row0 = base + (tid >> 4), row1 = row0 + 32, col = (tid & 15) * 4;
-        *reinterpret_cast<float4 *>(l_k + row0 * 64 + col) = gk0; *reinterpret_cast<float4 *>(l_k + row1 * 64 + col) = gk1;
-        *reinterpret_cast<float4 *>(l_k + RING * 64 + row0 * 64 + col) = gr0; *reinterpret_cast<float4 *>(l_k + RING * 64 + row1 * 64 + col) = gr1;
-        if (WMODE == 2) { *reinterpret_cast<float4 *>(l_k + 2 * RING * 64 + row0 * 64 + col) = gw0; *reinterpret_cast<float4 *>(l_k + 2 * RING * 64 + row1 * 64 + col) = gw1; }
-        l_v[wave * RING + base + lane] = gv;
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        issue1(c, 0, gk0, gr0, gw0); issue1(c, 1, gk1, gr1, gw1); issue1(c, 2, gk2, gr2, gw2); issue1(c, 3, gk3, gr3, gw3);
+        int t = 64 * c + (tid >> 2);
+        t = t < T ? t : T - 1;
+        gv = *reinterpret_cast<const v2f *>(v + (int64_t) t * D + h * S + cb + (tid & 3) * 2);
+    };
+    auto commit1 = [&](int c, int i, const float4 & ak, const float4 & ar, const float4 & aw) __attribute__((always_inline)) {
+        const int row = (c & 1) * 64 + 16 * i + (tid >> 4), col = (tid & 15) * 4;
+        *reinterpret_cast<float4 *>(l_k + row * 192 + col) = ak;
+        *reinterpret_cast<float4 *>(l_k + row * 192 + 64 + col) = ar;
+        if (WMODE == 2) *reinterpret_cast<float4 *>(l_k + row * 192 + 128 + col) = aw;
+        if (row < 3) {
+            *reinterpret_cast<float4 *>(l_k + (row + RING) * 192 + col) = ak;
+            *reinterpret_cast<float4 *>(l_k + (row + RING) * 192 + 64 + col) = ar;
+            if (WMODE == 2) *reinterpret_cast<float4 *>(l_k + (row + RING) * 192 + 128 + col) = aw;
+        }
+    };
+    auto commit = [&](int c) __attribute__((always_inline)) {
+        commit1(c, 0, gk0, gr0, gw0); commit1(c, 1, gk1, gr1, gw1); commit1(c, 2, gk2, gr2, gw2); commit1(c, 3, gk3, gr3, gw3);
+        const int row = (c & 1) * 64 + (tid >> 2);
+        l_v[(tid & 3) * RINGP + row] = gv;
+        if (row < 3) l_v[(tid & 3) * RINGP + row + RING] = gv;
     };
 
+    float kk0[4], rr0[4], ww0[4], kk1[4], rr1[4], ww1[4];     // two register sets: the group being read and the group being computed
+    v2f vv0[4], vv1[4];
+    auto read_group = [&](int c, int g, float (&kk)[4], float (&rr)[4], float (&ww)[4], v2f (&vv)[4]) __attribute__((always_inline)) {
+        const int a = (64 * c + 4 * g - lane) & (RING - 1);
+        const float * pk = l_k + a * 192 + lane;
+        const v2f * pv = l_v + wave * RINGP + a;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            kk[e] = pk[e * 192];
+            rr[e] = pk[e * 192 + 64];
+            ww[e] = WMODE == 2 ? pk[e * 192 + 128] : wconst;
+            vv[e] = pv[e];
+        }
+    };
+    float o_a = 0.0f, o_b = 0.0f, cap_a = 0.0f, cap_b = 0.0f;
+    // One step (macros: the capture lane must be an assembly-time constant). Running sums come from lane i - 1 (same token, previous
+    // step); lane 0 starts from 0.0f like the reference's `o = 0`. Lane q = 4 G + E keeps what lane 63 emits at step 64 c + q:
+    // out[64 c + q - 63][j], [j + 1] (v_readlane -> SGPR -> v_writelane; this clang has no writelane builtin).
+#define WKV_STEP(G, E, CHECKED, KK, RR, WW, VV)                                                                                  \
+    {                                                                                                                            \
+        const v2f kv = VV[E] * (v2f){KK[E], KK[E]};                                                                            \
+        const v2f ku = kv * (v2f){ui, ui};                                                                                       \
+        const v2f temp = ku + s;                                                                                                 \
+        const v2f p = temp * (v2f){RR[E], RR[E]};                                                                                  \
+        const v2f sw = s * (v2f){WW[E], WW[E]};                                                                                    \
+        const v2f sn = sw + kv;                                                                                                  \
+        const float in_a = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o_a), 0x138 /* wave_shr:1 */, 0xF, 0xF, false)); \
+        const float in_b = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o_b), 0x138, 0xF, 0xF, false));          \
+        o_a = in_a + p[0];                                                                                                       \
+        o_b = in_b + p[1];                                                                                                       \
+        if (CHECKED) {                                                                                                           \
+            const int t = 64 * c + 4 * (G) + (E) - lane;                                                                         \
+            s = (t >= 0 && t < T) ? sn : s;                                                                                      \
+        } else {                                                                                                                 \
+            s = sn;                                                                                                              \
+        }                                                                                                                        \
+        int sa, sb;                                                                                                              \
+        asm("v_readlane_b32 %0, %1, 63" : "=s"(sa) : "v"(o_a));                                                                  \
+        asm("v_readlane_b32 %0, %1, 63" : "=s"(sb) : "v"(o_b));                                                                  \
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(cap_a) : "s"(sa), "n"(4 * (G) + (E)));                                           \
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(cap_b) : "s"(sb), "n"(4 * (G) + (E)));                                           \
+    }
+#define WKV_GROUP_E(G, CHECKED)   /* even group: computes set 0 while set 1 is read */                                            \
+    read_group(c, (G) + 1, kk1, rr1, ww1, vv1);                                                                                  \
+    WKV_STEP(G, 0, CHECKED, kk0, rr0, ww0, vv0) WKV_STEP(G, 1, CHECKED, kk0, rr0, ww0, vv0)                                       \
+    WKV_STEP(G, 2, CHECKED, kk0, rr0, ww0, vv0) WKV_STEP(G, 3, CHECKED, kk0, rr0, ww0, vv0)
+#define WKV_GROUP_O(G, CHECKED)   /* odd group */                                                                                \
+    if ((G) + 1 < 16) read_group(c, (G) + 1, kk0, rr0, ww0, vv0);                                                                \
+    WKV_STEP(G, 0, CHECKED, kk1, rr1, ww1, vv1) WKV_STEP(G, 1, CHECKED, kk1, rr1, ww1, vv1)                                       \
+    WKV_STEP(G, 2, CHECKED, kk1, rr1, ww1, vv1) WKV_STEP(G, 3, CHECKED, kk1, rr1, ww1, vv1)
+#define WKV_CHUNK(CHECKED)                                                                                                       \
+    WKV_GROUP_E(0, CHECKED) WKV_GROUP_O(1, CHECKED) WKV_GROUP_E(2, CHECKED) WKV_GROUP_O(3, CHECKED) WKV_GROUP_E(4, CHECKED)       \
+    WKV_GROUP_O(5, CHECKED) WKV_GROUP_E(6, CHECKED) WKV_GROUP_O(7, CHECKED) WKV_GROUP_E(8, CHECKED) WKV_GROUP_O(9, CHECKED)       \
+    WKV_GROUP_E(10, CHECKED) WKV_GROUP_O(11, CHECKED) WKV_GROUP_E(12, CHECKED) WKV_GROUP_O(13, CHECKED) WKV_GROUP_E(14, CHECKED)  \
+    WKV_GROUP_O(15, CHECKED)
+
     issue(0);
-    float o_prev = 0.0f;
     for (int c = 0; c < n_chunks; c++) {
         __syncthreads();                 // every wave is done with the steps of chunk c - 1 (which still read chunk c - 2's half)
         commit(c);
         __syncthreads();
         if (c + 1 < n_chunks) issue(c + 1);
-        float cap = 0.0f;                // lane q captures what lane 63 emits at step 64 c + q: out[64 c + q - 63][j]
-#pragma unroll 1
-        for (int q0 = 0; q0 < 64; q0 += 4) {
-            // the LDS reads of four steps go out together; the dependent chain runs behind them
-            float kk[4], rr[4], ww[4], vv[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int t = 64 * c + q0 + e - lane;
-                const int slot = t & (RING - 1);
-                kk[e] = l_k[slot * 64 + lane];
-                rr[e] = l_k[RING * 64 + slot * 64 + lane];
-                ww[e] = WMODE == 2 ? l_k[2 * RING * 64 + slot * 64 + lane] : wconst;
-                vv[e] = l_v[wave * RING + slot];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int t = 64 * c + q0 + e - lane;
-                const bool valid = t >= 0 && t < T;
-                const float kv = vv[e] * kk[e];
-                const float ku = kv * ui;
-                const float temp = ku + s;
-                const float p = temp * rr[e];
-                const float sw = s * ww[e];
-                const float sn = sw + kv;
-                // running sum from lane i - 1 (same token, previous step); lane 0 starts from 0.0f like the reference's `o = 0`
-                const float o_in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o_prev), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
-                o_prev = o_in + p;
-                s = valid ? sn : s;
-                const float emitted = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o_prev), 63));
-                cap = lane == q0 + e ? emitted : cap;
-            }
-        }
+        const bool interior = c >= 1 && 64 * c + 64 <= T;      // every (step, lane) of the chunk is a real token
+        read_group(c, 0, kk0, rr0, ww0, vv0);
+        if (interior) { WKV_CHUNK(false) } else { WKV_CHUNK(true) }
         const int t_out = 64 * c + lane - 63;
-        if (t_out >= 0 && t_out < T) out[(int64_t) t_out * D + h * S + j] = cap;
+        if (t_out >= 0 && t_out < T) *reinterpret_cast<v2f *>(out + (int64_t) t_out * D + h * S + j) = (v2f){cap_a, cap_b};
     }
-    state_out[h * S * S + (int64_t) lane * S + j] = s;
+    *reinterpret_cast<v2f *>(state_out + h * S * S + (int64_t) lane * S + j) = s;
+#undef WKV_STEP
+#undef WKV_GROUP_E
+#undef WKV_GROUP_O
+#undef WKV_CHUNK
 }
 
 // RWKV-6 data-dependent mixes over a sequence (rwkv_graph.inc:323-346; same statement order as k_v6_mix2): thread = (f, d) keeps
@@ -699,7 +745,7 @@ bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, h
 
 bool launch_wkv6_seq(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
                      const float * state_in, float * state_out, float * out, int64_t T, int64_t H, hipStream_t st) {
-    const size_t lds = (size_t) (3 * 128 * 64 + 8 * 128) * sizeof(float);
+    const size_t lds = (size_t) (3 * 131 * 64 + 2 * 4 * 131) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void) hipFuncSetAttribute((const void *) k_wkv6_seq<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -709,9 +755,9 @@ bool launch_wkv6_seq(const float * r, const float * k, const float * v, const fl
     }
     const dim3 grid((unsigned) (H * 8));
     switch (w_mode) {
-        case 0: hipLaunchKernelGGL((k_wkv6_seq<0>), grid, dim3(512), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
-        case 1: hipLaunchKernelGGL((k_wkv6_seq<1>), grid, dim3(512), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
-        default: hipLaunchKernelGGL((k_wkv6_seq<2>), grid, dim3(512), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
+        case 0: hipLaunchKernelGGL((k_wkv6_seq<0>), grid, dim3(256), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
+        case 1: hipLaunchKernelGGL((k_wkv6_seq<1>), grid, dim3(256), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
+        default: hipLaunchKernelGGL((k_wkv6_seq<2>), grid, dim3(256), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
     }
     return true;
 }
@@ -872,7 +918,7 @@ static bool launch_mmq_mfma_t(int n, const DevTensor * const * Ws, const TileAct
     if (!attr_set) { (void) hipFuncSetAttribute((const void *) k_mmq_mfma<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr_set = true; }
     const dim3 grid((unsigned) (RP < 8 ? RP * C : ((RP + 7) / 8) * 8 * C), (unsigned) n, (unsigned) split);
     hipLaunchKernelGGL((k_mmq_mfma<FMT>), grid, dim3(M::NT), lds, st, A);
-    const dim3 cgrid((unsigned) (RP * C), (unsigned) n);
+    const dim3 cgrid((unsigned) (RP * C), (unsigned) n, 8);
     if (split == 2) hipLaunchKernelGGL(k_mmq_combine<2>, cgrid, dim3(512), 0, st, A);
     else if (split == 4) hipLaunchKernelGGL(k_mmq_combine<4>, cgrid, dim3(512), 0, st, A);
     else if (split == 8) hipLaunchKernelGGL(k_mmq_combine<8>, cgrid, dim3(512), 0, st, A);
