@@ -294,6 +294,13 @@ struct Runner {
         return nullptr;
     }
     void drop_pre() { for (auto & e : pre) e = Pre(); }
+    // tile images for n outputs of a fused mix (sequence mode, all consumers quantised with `wtype`): registered like prequant's
+    bool fused_outs(int n, float * const * keys, int wtype, TileAct * tas) {
+        if (!(dtype_quantized(wtype) && T >= k_mfma_min_tokens && b.tiles[0] && D % 256 == 0 && n <= 5)) return false;
+        for (auto & e : pre) e = Pre();
+        for (int i = 0; i < n; i++) { tas[i] = tile_act_at(b.tiles[i], T, D); pre[i].x = keys[i]; pre[i].wtype = wtype; pre[i].K = D; pre[i].ta = tas[i]; }
+        return true;
+    }
 
     // y_i[T][N] = epi_i(W_i . x_i[T][K]) for up to 4 matrices of one shape: one launch in sequence mode when every input was quantised ahead
     void mm_batch(int n, const DevTensor * const * Ws, const float * const * xs, float * const * ys, const Epi * epis) {
@@ -368,8 +375,15 @@ struct Runner {
         else if (m.arch_major == 6) { a.mode = 1; a.n_out = 2; a.coef[0] = f(L.ffn_time_maa_k); a.coef[1] = f(L.ffn_time_maa_r); }
         else { a.mode = 1; a.n_out = 1; a.coef[0] = f(L.ffn_x_k); }
         a.out[0] = b.m[0]; a.out[1] = b.m[1];
-        launch_mix(a, T, D, st);
-        if (m.arch_major != 7) { const float * xs[2] = {b.m[0], b.m[1]}; prequant(2, xs, D, L.ffn_key->type); }
+        TileAct tas[5];
+        if (m.arch_major != 7 && L.ffn_receptance->type == L.ffn_key->type && L.ffn_key->cols() == D && fused_outs(2, a.out, L.ffn_key->type, tas)) {
+            // sequence mode: the mix writes its two outputs as quantised tile images (their only consumers are the two products below)
+            a.out[0] = nullptr; a.out[1] = nullptr;
+            launch_mix_seq_q(a, T, D, st, tas, L.ffn_key->type);
+        } else {
+            launch_mix(a, T, D, st);
+            if (m.arch_major != 7) { const float * xs[2] = {b.m[0], b.m[1]}; prequant(2, xs, D, L.ffn_key->type); }
+        }
         mm(L.ffn_key, b.m[0], b.ffk, epi(EPI_RELU_SQ));
         if (m.arch_major == 7) {
             mm(L.ffn_value, b.ffk, b.x, epi(EPI_ADD_RES, nullptr, b.x));
@@ -426,11 +440,23 @@ struct Runner {
         v.maa[0] = f(L.att_time_maa_w); v.maa[1] = f(L.att_time_maa_k); v.maa[2] = f(L.att_time_maa_v);
         v.maa[3] = f(L.att_time_maa_r); v.maa[4] = f(L.att_time_maa_g);
         for (int i = 0; i < 5; i++) v.out[i] = b.m[i];  // xw, xk, xv, xr, xg
-        if (!(T >= k_mfma_min_tokens && launch_v6_mix2_seq(v, T, D, R, st))) launch_v6_mix2(v, T, D, R, st);
+        bool fused_q = false;
+        {
+            const int wt = L.att_receptance->type;
+            TileAct tas[5];
+            if (L.att_key->type == wt && L.att_value->type == wt && L.att_gate->type == wt && L.att_time_decay_w1->type == wt &&
+                (R == 32 || R == 64) && fused_outs(5, v.out, wt, tas)) {
+                // sequence mode: the five mixed inputs leave the kernel as quantised tile images (their only consumers are products)
+                for (int i = 0; i < 5; i++) v.out[i] = nullptr;
+                fused_q = launch_v6_mix2_seq(v, T, D, R, st, tas, wt);
+                if (!fused_q) { drop_pre(); for (int i = 0; i < 5; i++) v.out[i] = b.m[i]; }
+            }
+        }
+        if (!fused_q && !(T >= k_mfma_min_tokens && launch_v6_mix2_seq(v, T, D, R, st))) launch_v6_mix2(v, T, D, R, st);
         {
             // the five mixed inputs are quantised by one launch, the four D x D projections run as one launch (sequence mode)
             const float * xs[5] = {b.m[3], b.m[1], b.m[2], b.m[4], b.m[0]};
-            prequant(5, xs, D, L.att_receptance->type);
+            if (!fused_q) prequant(5, xs, D, L.att_receptance->type);
             const DevTensor * Ws[4] = {L.att_receptance, L.att_key, L.att_value, L.att_gate};
             float * ys[4] = {b.r, b.k, b.v, b.g};
             const Epi es[4] = {Epi(), Epi(), Epi(), epi(EPI_SILU)};

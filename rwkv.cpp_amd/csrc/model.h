@@ -71,6 +71,9 @@ TileAct tile_act_at(void * base, int64_t T, int64_t K);
 void launch_quantize_act_tiles(const float * x, int64_t T, int64_t K, int wtype, const TileAct & out, hipStream_t st);
 // up to 5 inputs of the same shape in one launch
 void launch_quantize_act_tiles_batched(int n, const float * const * xs, int64_t T, int64_t K, int wtype, const TileAct * outs, hipStream_t st);
+// sequence-mode mixes writing their outputs as tile images (prefill.hip); `outs` = one image per output
+bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, hipStream_t st, const TileAct * outs = nullptr, int wtype = 0);
+bool launch_mix_seq_q(const MixArgs & a, int64_t T, int64_t D, hipStream_t st, const TileAct * outs, int wtype);
 // workspace of the split walk (GEMMs with too few output tiles for the chip): partial sums + one zeroed counter per tile
 struct MmqWs { float * part = nullptr; size_t part_bytes = 0; int * counters = nullptr; int n_counters = 0; };
 bool launch_mmq_mfma(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st, const MmqWs * ws = nullptr);
@@ -81,7 +84,6 @@ bool ensure_pf(const DevTensor & W, hipStream_t st);
 void free_pf(const DevTensor & W);
 bool launch_wkv6_seq(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
                      const float * state_in, float * state_out, float * out, int64_t T, int64_t H, hipStream_t st);
-bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, hipStream_t st);
 constexpr int64_t k_mfma_min_tokens = 32;   // sequence calls of at least this many tokens per pass take the GEMM path
 
 // temperature / top-p sampling on the logits in HBM (sampling.hip). u < 0: draw from the counter-based generator (seed, *counter; the

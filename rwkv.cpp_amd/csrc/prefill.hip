@@ -91,6 +91,62 @@ __global__ __launch_bounds__(256) void k_pf_repack(int type, const uint8_t * __r
 // One wave = one (token tile, block): lane = half * 32 + i owns the 16 elements of its half of token i's block -- exactly its
 // 16 bytes of the A-operand image, so the wave reads 32 full 128-byte lines and writes one contiguous KiB. The block's amax and
 // code sum combine the two halves through one permlane32 swap (max and integer sum are order-free: same result as k_quant_act).
+// The quantiser of one wave = one (token tile, block): lane = half * 32 + i holds the 16 elements v of its half of token i's block.
+// Writes the wave's KiB of codes and (lanes of the first half) the token's scales at index tb = token tile * nb + block.
+static __device__ __forceinline__ void quantize_tile_unit(const float (&v)[16], int lane, int64_t tb, float dscale, float off,
+                                                          int8_t * __restrict__ q, float * __restrict__ d, float * __restrict__ s, float * __restrict__ o) {
+    const int i = lane & 31, h = lane >> 5;
+    float amax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) amax = fmaxf(amax, fabsf(v[j]));
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+        amax = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    const float dd = amax / 127.0f;
+    const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+    int sum = 0;
+    int w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const int qi = (int) roundf(v[4 * j + e] * id); sum += qi; w |= (qi & 0xFF) << (8 * e); }
+        w4[j] = w;
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned) sum, (unsigned) sum, false, false);
+        sum = (int) r[0] + (int) r[1];
+    }
+    *reinterpret_cast<int4 *>(q + tb * 1024 + lane * 16) = make_int4(w4[0], w4[1], w4[2], w4[3]);
+    if (h == 0) {
+        const float d16 = round_f16(dd);
+        d[tb * 32 + i] = d16 * dscale;   // a power of two: exact
+        if (s) s[tb * 32 + i] = round_f16((float) sum * dd);
+        if (o) o[tb * 32 + i] = off * (float) sum;
+    }
+}
+
+// The same from an f32 tile of 32 tokens x 256 channels staged in LDS (row stride QT_LD floats: 16-byte reads of 32 different rows
+// spread over all banks): the 256-thread workgroup that produced the tile quantises its 8 blocks, two (token tile, block) units per
+// wave. Used by the producers whose only consumers are quantised products (the sequence-mode mixes): the f32 activations never
+// travel to HBM and back.
+constexpr int QT_LD = 260;
+static __device__ __forceinline__ void quantize_lds_tile(const float * __restrict__ l_tile, int tid, int64_t tt, int b0, int nb, float dscale, float off,
+                                                         int8_t * __restrict__ q, float * __restrict__ d, float * __restrict__ s, float * __restrict__ o) {
+    const int lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int bl = wave + 4 * k;
+        float v[16];
+        const float4 * src = reinterpret_cast<const float4 *>(l_tile + i * QT_LD + bl * 32 + h * 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const float4 f = src[j]; v[4 * j] = f.x; v[4 * j + 1] = f.y; v[4 * j + 2] = f.z; v[4 * j + 3] = f.w; }
+        quantize_tile_unit(v, lane, tt * nb + b0 + bl, dscale, off, q, d, s, o);
+    }
+}
+
+struct TileOut { int8_t * q[6]; float * d[6]; float * s[6]; float * o[6]; float dscale, off; int nb, on; };
 constexpr int QUANT_BATCH = 5;                // inputs per launch (blockIdx.y): e.g. the five mixed inputs of an RWKV-6 time-mixing block
 struct QuantBatch { const float * x[QUANT_BATCH]; int8_t * q[QUANT_BATCH]; float * d[QUANT_BATCH]; float * s[QUANT_BATCH]; float * o[QUANT_BATCH]; };
 __global__ __launch_bounds__(256) void k_quant_act_tiles(QuantBatch qb, int64_t T, int64_t T_pad, int nb, float dscale, float off) {
@@ -115,36 +171,7 @@ __global__ __launch_bounds__(256) void k_quant_act_tiles(QuantBatch qb, int64_t 
         const float4 f = live ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         v[4 * j] = f.x; v[4 * j + 1] = f.y; v[4 * j + 2] = f.z; v[4 * j + 3] = f.w;
     }
-    float amax = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 16; j++) amax = fmaxf(amax, fabsf(v[j]));
-    {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
-        amax = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    }
-    const float dd = amax / 127.0f;
-    const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
-    int sum = 0;
-    int w4[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int w = 0;
-#pragma unroll
-        for (int e = 0; e < 4; e++) { const int qi = (int) roundf(v[4 * j + e] * id); sum += qi; w |= (qi & 0xFF) << (8 * e); }
-        w4[j] = w;
-    }
-    {
-        const auto r = __builtin_amdgcn_permlane32_swap((unsigned) sum, (unsigned) sum, false, false);
-        sum = (int) r[0] + (int) r[1];
-    }
-    const int64_t tb = tt * nb + b;
-    *reinterpret_cast<int4 *>(q + tb * 1024 + lane * 16) = make_int4(w4[0], w4[1], w4[2], w4[3]);
-    if (h == 0) {
-        const float d16 = round_f16(dd);
-        d[tb * 32 + i] = d16 * dscale;   // a power of two: exact
-        if (s) s[tb * 32 + i] = round_f16((float) sum * dd);
-        if (o) o[tb * 32 + i] = off * (float) sum;
-    }
+    quantize_tile_unit(v, lane, tt * nb + b, dscale, off, q, d, s, o);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -700,8 +727,10 @@ __global__ __launch_bounds__(256, 1) void k_wkv6_seq(const float * __restrict__ 
 // RWKV-6 data-dependent mixes over a sequence (rwkv_graph.inc:323-346; same statement order as k_v6_mix2): thread = (f, d) keeps
 // its R columns of W2 in registers across a tile of tokens; the tokens' tanh'ed low-rank vectors sit in LDS (broadcast reads).
 template <int R, int TT>
-__global__ __launch_bounds__(256) void k_v6_mix2_seq(V6Mix2Args a, int T, int D) {
+__global__ __launch_bounds__(256) void k_v6_mix2_seq(V6Mix2Args a, TileOut qo, int T, int D) {
+    static_assert(TT == 32, "one token tile of the quantised image per workgroup");
     __shared__ __attribute__((aligned(16))) float l_tl[TT * R];
+    __shared__ __attribute__((aligned(16))) float l_out[TT * QT_LD];
     const int dblocks = D / 256;
     const int f = blockIdx.x / dblocks, d = (blockIdx.x % dblocks) * 256 + threadIdx.x;
     const int t0 = blockIdx.y * TT;
@@ -715,31 +744,103 @@ __global__ __launch_bounds__(256) void k_v6_mix2_seq(V6Mix2Args a, int T, int D)
         l_tl[i] = t0 + tt < T ? a.tl[(int64_t) (t0 + tt) * 5 * R + f * R + m] : 0.0f;
     }
     __syncthreads();
-    const int tn = T - t0 < TT ? T - t0 : TT;
-    for (int tt = 0; tt < tn; tt++) {
-        const float4 * tl4 = reinterpret_cast<const float4 *>(l_tl + tt * R);
-        float acc = 0.0f;
+    float * const of = a.out[f];
+    for (int tt = 0; tt < TT; tt++) {
+        float val = 0.0f;                        // (tokens beyond T: zeros in the quantised image)
+        if (t0 + tt < T) {
+            const float4 * tl4 = reinterpret_cast<const float4 *>(l_tl + tt * R);
+            float acc = 0.0f;
 #pragma unroll
-        for (int m4 = 0; m4 < R / 4; m4++) {
-            const float4 t4 = tl4[m4];
-            float pr;
-            pr = wc[4 * m4] * t4.x; acc += pr;
-            pr = wc[4 * m4 + 1] * t4.y; acc += pr;
-            pr = wc[4 * m4 + 2] * t4.z; acc += pr;
-            pr = wc[4 * m4 + 3] * t4.w; acc += pr;
+            for (int m4 = 0; m4 < R / 4; m4++) {
+                const float4 t4 = tl4[m4];
+                float pr;
+                pr = wc[4 * m4] * t4.x; acc += pr;
+                pr = wc[4 * m4 + 1] * t4.y; acc += pr;
+                pr = wc[4 * m4 + 2] * t4.z; acc += pr;
+                pr = wc[4 * m4 + 3] * t4.w; acc += pr;
+            }
+            const int64_t o = (int64_t) (t0 + tt) * D + d;
+            const float mm = (acc + maa) * a.sx[o];
+            val = mm + a.xn[o];
+            if (of) of[o] = val;
         }
-        const int64_t o = (int64_t) (t0 + tt) * D + d;
-        const float mm = (acc + maa) * a.sx[o];
-        a.out[f][o] = mm + a.xn[o];
+        if (qo.on) l_out[tt * QT_LD + threadIdx.x] = val;
+    }
+    if (qo.on) {
+        __syncthreads();
+        quantize_lds_tile(l_out, threadIdx.x, blockIdx.y, (blockIdx.x % dblocks) * 8, qo.nb, qo.dscale, qo.off, qo.q[f], qo.d[f], qo.s[f], qo.o[f]);
     }
 }
 
-bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, hipStream_t st) {
+// Token-shift mixes of a sequence (k_mix) with quantised outputs: thread = channel d keeps the 32 tokens of its tile (and the one in
+// front) in registers; per output the tile goes through LDS into the quantiser. Same statements as k_mix (rwkv_graph.inc:204-215).
+__global__ __launch_bounds__(256) void k_mix_seq_q(MixArgs a, TileOut qo, int T, int D) {
+    constexpr int TT = 32;
+    __shared__ __attribute__((aligned(16))) float l_out[TT * QT_LD];
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * TT;
+    float xs[TT + 1];
+    xs[0] = t0 == 0 ? a.carry_in[d] : (t0 - 1 < T ? a.xn[(int64_t) (t0 - 1) * D + d] : 0.0f);
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++) xs[tt + 1] = t0 + tt < T ? a.xn[(int64_t) (t0 + tt) * D + d] : 0.0f;
+    if (a.mode != 0 && a.sx) {
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) if (t0 + tt < T) a.sx[(int64_t) (t0 + tt) * D + d] = xs[tt] - xs[tt + 1];
+    }
+    if (T - 1 >= t0 && T - 1 < t0 + TT) {
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) if (t0 + tt == T - 1) a.carry_out[d] = xs[tt + 1];
+    }
+    for (int f = 0; f < a.n_out; f++) {
+        const float c = a.coef[f][d];
+        float * const of = a.out[f];
+        if (f) __syncthreads();                  // the quantiser is done with the previous output's tile
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) {
+            float val = 0.0f;
+            if (t0 + tt < T) {
+                const float x = xs[tt + 1], xp = xs[tt];
+                if (a.mode == 0) { const float xc = x * c, pc = xp * c; val = xc + (xp - pc); }
+                else { const float sx = xp - x; const float sc = sx * c; val = sc + x; }
+                if (of) of[(int64_t) (t0 + tt) * D + d] = val;
+            }
+            l_out[tt * QT_LD + threadIdx.x] = val;
+        }
+        __syncthreads();
+        quantize_lds_tile(l_out, threadIdx.x, blockIdx.y, blockIdx.x * 8, qo.nb, qo.dscale, qo.off, qo.q[f], qo.d[f], qo.s[f], qo.o[f]);
+    }
+}
+
+static TileOut tile_out_of(int n, const TileAct * outs, int wtype, int64_t K) {
+    TileOut qo;
+    const bool hm = wtype == T_Q4_1 || wtype == T_Q5_1, xo = wtype == T_Q5_0;
+    for (int i = 0; i < 6; i++) {
+        const int j = i < n ? i : 0;
+        qo.q[i] = n ? outs[j].q : nullptr; qo.d[i] = n ? outs[j].d : nullptr;
+        qo.s[i] = n && hm ? outs[j].s : nullptr; qo.o[i] = n && xo ? outs[j].o : nullptr;
+    }
+    qo.dscale = wtype == T_Q4_0 ? 0.0625f : 1.0f; qo.off = 16.0f; qo.nb = (int) (K / 32); qo.on = n > 0;
+    return qo;
+}
+
+// `outs` (5 tile images, or nullptr): the quantised outputs for products with weights of type `wtype`; a.out[f] may then be null
+bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, hipStream_t st, const TileAct * outs, int wtype) {
     constexpr int TT = 32;
     if (D % 256 != 0 || !(R == 32 || R == 64)) return false;
-    const dim3 grid((unsigned) (5 * D / 256), (unsigned) ((T + TT - 1) / TT));
-    if (R == 32) hipLaunchKernelGGL((k_v6_mix2_seq<32, TT>), grid, dim3(256), 0, st, a, (int) T, (int) D);
-    else hipLaunchKernelGGL((k_v6_mix2_seq<64, TT>), grid, dim3(256), 0, st, a, (int) T, (int) D);
+    const TileOut qo = tile_out_of(outs ? 5 : 0, outs, wtype, D);
+    const int64_t rows = outs ? outs[0].T_pad : T;
+    const dim3 grid((unsigned) (5 * D / 256), (unsigned) ((rows + TT - 1) / TT));
+    if (R == 32) hipLaunchKernelGGL((k_v6_mix2_seq<32, TT>), grid, dim3(256), 0, st, a, qo, (int) T, (int) D);
+    else hipLaunchKernelGGL((k_v6_mix2_seq<64, TT>), grid, dim3(256), 0, st, a, qo, (int) T, (int) D);
+    return true;
+}
+
+// token-shift mix with n_out <= 6 quantised outputs (a.out[f] may be null)
+bool launch_mix_seq_q(const MixArgs & a, int64_t T, int64_t D, hipStream_t st, const TileAct * outs, int wtype) {
+    if (D % 256 != 0 || a.n_out < 1 || a.n_out > 6) return false;
+    const TileOut qo = tile_out_of(a.n_out, outs, wtype, D);
+    const dim3 grid((unsigned) (D / 256), (unsigned) (outs[0].T_pad / 32));
+    hipLaunchKernelGGL(k_mix_seq_q, grid, dim3(256), 0, st, a, qo, (int) T, (int) D);
     return true;
 }
 
