@@ -467,7 +467,6 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
             // A leaf whose value starts a new subtree (even u) accumulates straight into s0: no copy. Other leaves use `tmp`.
             v2f tmp[8];
             v2f (&cur)[8] = (u & 1) ? tmp : s0;
-#if 1
             if (l < nb) {
                 step(cur, std::true_type{});
                 for (int b = l + 64; b < nb; b += 64) step(cur, std::false_type{});
@@ -475,11 +474,6 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) cur[j] = (v2f){0.0f, 0.0f};
             }
-#else
-#pragma unroll
-            for (int j = 0; j < 8; j++) cur[j] = (v2f){0.0f, 0.0f};
-            for (int b = l; b < nb; b += 64) step(cur, std::false_type{});
-#endif
             // merges after leaf c = 8 a + u: one per trailing one bit of c
             if (u == 1 || u == 5) {
 #pragma unroll
