@@ -23,6 +23,7 @@ $B --config rwkv4-169m --dtype Q5_1 --steps 256 --cpu-seconds 5 > $O/bench_4_169
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_v7 -o decode -- python $R/bench.py --config rwkv7-2b9 --dtype Q5_1 --steps 48 --warmup 8 --cpu-seconds 0 --abi-tokens 0 --no-profile > /dev/null 2> $R/$O/rocprof_v7.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_v4 -o decode -- python $R/bench.py --config rwkv4-169m --dtype Q5_1 --steps 48 --warmup 8 --cpu-seconds 0 --abi-tokens 0 --no-profile > /dev/null 2> $R/$O/rocprof_v4.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_prefill -o prefill -- python $R/bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2> $R/$O/rocprof_prefill.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_1b6 -o decode -- python $R/bench.py --config rwkv6-1b6 --dtype Q4_0 --steps 48 --warmup 8 --cpu-seconds 0 --abi-tokens 0 --no-profile > /dev/null 2> $R/$O/rocprof_1b6.err
 cd $R
 rm -f /tmp/synthetic-rwkv6-1b6* /tmp/synthetic-rwkv7* /tmp/synthetic-rwkv4*
