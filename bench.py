@@ -289,6 +289,9 @@ def bench_prefill(args, pkg, lib, path, spec, torch):
 
 def main():
     args = parse_args()
+    # watchdog: a device call that never returns must end the process (with the Python stacks on stderr), not hang the box
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("RWKV_BENCH_WATCHDOG_S", "1500")), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
