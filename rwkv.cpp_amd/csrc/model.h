@@ -81,6 +81,7 @@ bool launch_mmq_mfma(const DevTensor & W, const TileAct & x, int64_t T, float * 
 bool launch_mmq_mfma_batched(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy,
                              const MmqWs * ws, hipStream_t st);
 bool ensure_pf(const DevTensor & W, hipStream_t st);
+void prefill_prepare_current_device();   // per-device kernel attributes of the sequence-mode kernels (multi-device processes)
 void free_pf(const DevTensor & W);
 bool launch_wkv6_seq(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
                      const float * state_in, float * state_out, float * out, int64_t T, int64_t H, hipStream_t st);

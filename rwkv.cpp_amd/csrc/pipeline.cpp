@@ -96,12 +96,15 @@ rwkv_context * pipeline_create(const char * path, uint32_t n_threads, const char
     RW_CHECK(RWKV_ERROR_CTX | RWKV_ERROR_ALLOC, nullptr, front != nullptr, "Failed to allocate rwkv_context");
     int prev_dev = 0;
     (void) hipGetDevice(&prev_dev);
+    bool multi_device = false;
+    for (size_t s = 1; s < devs.size(); s++) multi_device = multi_device || devs[s] != devs[0];
     for (size_t s = 0; s < ranges.size(); s++) {
         if (hipSetDevice(devs[s]) != hipSuccess) { pipeline_destroy(front); global_fail(RWKV_ERROR_CTX, __FILE__, __LINE__, "hipSetDevice", "cannot select device %d", devs[s]); return nullptr; }
         Model * m = load_model(path, ranges[s].first, ranges[s].second);
         rwkv_context * c = m ? create_context(m, n_threads) : nullptr;
         if (!c || !finish_stage(c)) { if (c) front->stages.push_back(c); pipeline_destroy(front); (void) hipSetDevice(prev_dev); return nullptr; }
         front->stages.push_back(c);
+        if (multi_device) prefill_prepare_current_device();   // (kernel attributes are per device; the launchers set them once per process)
         // direct peer copies where the topology allows them (otherwise the runtime stages the copy)
         if (s > 0 && devs[s] != devs[s - 1]) {
             int can = 0;

@@ -1020,6 +1020,22 @@ static bool launch_mmq_mfma_t(int n, const DevTensor * const * Ws, const TileAct
     return true;
 }
 
+// hipFuncSetAttribute acts on the CURRENT device, and the launchers above raise the dynamic-LDS limit once per process (on the device
+// of the first launch). A process that runs stages on several devices (RWKV_MI_DEVICES, pipeline.cpp) calls this once per stage
+// device at start-up.
+void prefill_prepare_current_device() {
+    (void) hipFuncSetAttribute((const void *) k_mmq_mfma<T_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MF<T_Q4_0>::LDS_BYTES);
+    (void) hipFuncSetAttribute((const void *) k_mmq_mfma<T_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, MF<T_Q4_1>::LDS_BYTES);
+    (void) hipFuncSetAttribute((const void *) k_mmq_mfma<T_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MF<T_Q5_0>::LDS_BYTES);
+    (void) hipFuncSetAttribute((const void *) k_mmq_mfma<T_Q5_1>, hipFuncAttributeMaxDynamicSharedMemorySize, MF<T_Q5_1>::LDS_BYTES);
+    (void) hipFuncSetAttribute((const void *) k_mmq_mfma<T_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MF<T_Q8_0>::LDS_BYTES);
+    const int wkv_lds = (int) ((3 * 131 * 64 + 2 * 4 * 131) * sizeof(float));
+    (void) hipFuncSetAttribute((const void *) k_wkv6_seq<0>, hipFuncAttributeMaxDynamicSharedMemorySize, wkv_lds);
+    (void) hipFuncSetAttribute((const void *) k_wkv6_seq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wkv_lds);
+    (void) hipFuncSetAttribute((const void *) k_wkv6_seq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wkv_lds);
+    (void) hipGetLastError();
+}
+
 bool launch_mmq_mfma_batched(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy,
                              const MmqWs * ws, hipStream_t st) {
     if (n < 1 || n > MMQ_BATCH) return false;
