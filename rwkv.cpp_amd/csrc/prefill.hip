@@ -217,7 +217,7 @@ struct MmqArgs {
     const int * order;       // walk order of the blocks
     int a_start[9];          // steps of the walk before outer iteration a = 0 .. 8
     float * part;            // [split][tile][thread][16] partial sums (split > 1)
-    int * counters;          // [tile], zero between launches
+    int * counters;          // (not read: the parts are added by k_mmq_combine; reserved for a last-arriver variant in one kernel)
 };
 
 template <int FMT>
