@@ -8,6 +8,8 @@
 //
 // Protocol (all words in LDS, monotonic counters, no resets):
 //   landed    number of fills whose data is in LDS (written by the loader after s_waitcnt vmcnt(16 * (DEPTH - 1)): fills land in order)
+//   (relaxed LDS accesses everywhere: LDS operations of a wave execute in order, the DMA's completion is what vmcnt counts, and a
+//    release / acquire pair would make the compiler wait for EVERY outstanding fill)
 //   released  [NSLOT] number of consumer waves that are done with the slot, summed over generations; the loader may refill slot s
 //             for fill f (generation g = f / NSLOT) once released[s] == NCONS * g
 #include <hip/hip_runtime.h>
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(NT) k_ring(const unsigned char * __restrict__ 
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                if (lane == 0) __hip_atomic_store(&landed, (unsigned) (f < n_fills ? done + 1 : n_fills), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_store(&landed, (unsigned) (f < n_fills ? done + 1 : n_fills), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (f >= n_fills) break;          // (everything has landed)
             }
         }
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(NT) k_ring(const unsigned char * __restrict__ 
     const int ones = 0x01010101;
     for (int f = 0; f < n_fills; f++) {
         const int s = f % NSLOT;
-        for (long spin = 0; spin < 100000000 && __hip_atomic_load(&landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= (unsigned) f; spin++) __builtin_amdgcn_s_sleep(1);
+        for (long spin = 0; spin < 100000000 && __hip_atomic_load(&landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (unsigned) f; spin++) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             if (r % NCONS != wave - 1) continue;                  // (wave-uniform)
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(NT) k_ring(const unsigned char * __restrict__ 
             acc = __builtin_amdgcn_sdot4(w[3], ones, acc, false);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot's reads are done before it is handed back
-        if (lane == 0) __hip_atomic_fetch_add(&released[s], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_fetch_add(&released[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     long long tot = acc;
     for (int sh = 32; sh; sh >>= 1) tot += __shfl_xor(tot, sh);
