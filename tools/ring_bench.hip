@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(NT) k_ring(const unsigned char * __restrict__ 
     for (int f = 0; f < n_fills; f++) {
         const int s = f % NSLOT;
         for (long spin = 0; spin < 100000000 && __hip_atomic_load(&landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (unsigned) f; spin++) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");                          // (compiler: the slot is read after the flag)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             if (r % NCONS != wave - 1) continue;                  // (wave-uniform)
