@@ -5,10 +5,13 @@
 //                      instruction is exactly one quantisation block, so an MFMA returns the EXACT integer block sums of a
 //                      32-token x 32-row tile; the block is then folded into the f32 accumulators with the same statement
 //                      as the single-token kernel (kdev.h blk_fma):  P = fma(d_w * d_x, isum, P) [+ fma(m_w, s_x, P)].
-//   k_quant_act_tiles  the activation quantiser of ggml's mul_mat (Q8_0 / Q8_1) writing the tile-major image the GEMM reads.
+//   k_mmq_combine      second half of a GEMM whose walk was cut into parts (too few output tiles for 256 CUs): adds the parts in
+//                      tree order and applies the epilogue.
+//   k_quant_act_tiles  the activation quantiser of ggml's mul_mat (Q8_0 / Q8_1) writing the tile-major image the GEMM reads (up to
+//                      five inputs per launch); k_v6_mix2_seq / k_mix_seq_q: the RWKV-6 mixes with that quantiser fused in.
 //   k_pf_repack        load-/first-use-time copy of a quantised matrix into the tile-major image the GEMM reads.
-//   k_wkv6_seq         the WKV-5/6 recurrence with the T loop pipelined across the 64 lanes of a wave (one wave per value
-//                      column instead of one wave per head).
+//   k_wkv6_seq         the WKV-5/6 recurrence with the T loop pipelined across the 64 lanes of a wave (one wave = two value
+//                      columns in packed-f32 registers instead of one wave per head).
 //
 // Bit-exactness with the single-token path (the reference guarantees serial == sequence and tests it with memcmp,
 // tests/test_eval_sequence_in_chunks.c:54; here it holds for every format). A row sum of k_mvq_t1 is a fixed expression:
@@ -27,11 +30,12 @@
 // block 1 KiB of codes in MFMA operand order + 128 bytes of scales).
 //
 // Work decomposition: a 512-thread workgroup (8 waves, two per SIMD) owns a 128-row x 64-token output tile; wave (rg, tg)
-// owns rows [32 rg, +32) x tokens [32 tg, +32). The K walk is cut into chunks of 8 steps (blocks); a chunk's operands (4.8 KB
-// per step for Q4_0) are staged by all threads into one of two LDS buffers while the previous chunk is computed, one
-// workgroup barrier per chunk. Per step and wave: four 16-byte LDS reads of operands + four of token scales, one MFMA,
-// ~60 VALU instructions of unpack and scale-accumulate -- the kernel is bound by that VALU work (the f32 fold per block
-// is what ggml's arithmetic prescribes), the MFMA itself is ~1/4 of the step.
+// owns rows [32 rg, +32) x tokens [32 tg, +32). The K walk is cut into chunks of 8 steps (blocks); wave w stages step w of a chunk
+// with LDS-DMA (scalar base + per-lane offset per 1-KiB row) into one of two LDS buffers while the previous chunk is computed, one
+// workgroup barrier per chunk. Per step and wave: the sums of the previous MFMA leave the accumulator as floats (the MFMA
+// accumulates onto 1.5 * 2^23: one packed subtract per pair), the next MFMA is issued under the fold of the current block, LDS
+// reads run a stage ahead: ~52 VALU + ~18 SALU + 7 LDS instructions per MFMA -- the kernel is bound by instruction issue (the f32
+// fold per block is what ggml's arithmetic prescribes). DESIGN.md section 6.5 has the measurements and what was tried.
 #include "kdev.h"
 #include "model.h"
 
