@@ -65,6 +65,10 @@ RWKV_API void rwkv_mi_set_graph_enabled(struct rwkv_context * ctx, bool enabled)
  * at context creation from the model geometry, the weight format and the environment (RWKV_MI_NO_FUSED / RWKV_MI_NO_MEGA). */
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx);
 
+/* Which persistent kernel serves decode path 2: 2 = weights streamed through an LDS ring by a loader wave (LDS-DMA; the default where the
+ * model qualifies), 1 = weights prefetched into the registers of the waves that use them (RWKV_MI_PERSIST=regs), 0 = path 2 not active. */
+RWKV_API int rwkv_mi_persist_kind(const struct rwkv_context * ctx);
+
 /* Waits for the context's stream and reports whether every persistent-kernel step so far completed (false: a poll timed out
  * because not all workgroups could be resident -- the device is shared, or other kernels held CUs for seconds; results since
  * then are invalid and the context should be re-created with RWKV_MI_NO_MEGA=1). Always true on paths 0 and 1. */

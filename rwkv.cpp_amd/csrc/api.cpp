@@ -445,6 +445,7 @@ RWKV_API bool rwkv_mi_decode_healthy(struct rwkv_context * ctx) {
 }
 
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx) { return ctx->mega ? 2 : ((ctx->fused_v6 || ctx->fused_v7 || ctx->fused_v4) ? 1 : 0); }
+RWKV_API int rwkv_mi_persist_kind(const struct rwkv_context * ctx) { return mega_v6_kind(ctx->mega); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Layer pipeline (one process per GPU; the hand-off itself is done by the caller with RCCL send/recv)

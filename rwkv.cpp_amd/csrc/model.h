@@ -209,6 +209,17 @@ bool     mega_v6_clear_abort(void * h, hipStream_t st);
 bool     mega_v6_set_tag(void * h, unsigned base, hipStream_t st);
 uint64_t mega_v6_bytes(void * h);
 bool     mega_v6_trace(void * h, int layer, long long * out, bool fetch);
+int      mega_v6_kind(void * h);            // 1: register prefetch (mega_v6.hip), 2: LDS-DMA weight ring (ring_v6.hip)
+// the same persistent launch on the LDS-DMA weight ring (ring_v6.hip); reached through the mega_v6_* entry points
+void *   ring_v6_create(const Model & m);
+void     ring_v6_destroy(void * h);
+void     ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf);
+bool     ring_v6_ctl_fetch(void * h, hipStream_t st);
+bool     ring_v6_aborted_cached(void * h);
+bool     ring_v6_clear_abort(void * h, hipStream_t st);
+bool     ring_v6_set_tag(void * h, unsigned base, hipStream_t st);
+uint64_t ring_v6_bytes(void * h);
+bool     ring_v6_trace(void * h, int layer, long long * out, bool fetch);
 // ---- layer pipeline in one process (pipeline.cpp) ----
 bool upload_tokens_for(rwkv_context * ctx, const uint32_t * tokens, size_t n);   // api.cpp: pinned staging + async copy into ctx->d_tokens
 rwkv_context * pipeline_create(const char * path, uint32_t n_threads, const char * devices);

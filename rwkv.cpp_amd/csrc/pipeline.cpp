@@ -191,12 +191,18 @@ bool pipeline_eval(rwkv_context * front, const uint32_t * tokens, size_t n, size
                 if (hipMemcpyPeerAsync(c->b.x, m.device, p->b.x, p->model->device, T * D * sizeof(float), p->stream) != hipSuccess) return fail(c);
                 if (m.arch_major == 7 && hipMemcpyPeerAsync(c->b.v_first, m.device, p->b.v_first, p->model->device, T * D * sizeof(float), p->stream) != hipSuccess) return fail(c);
                 if (hipEventRecord(p->handoff_ev, p->stream) != hipSuccess) return fail(p);
+                // A MIDDLE stage is done with its x (input, running residual stream AND source of the copy above) only now: behind its
+                // outgoing copy, not behind its layers. (Recorded after forward(), the stage before it could overwrite p's x in the next
+                // pass while this copy -- itself held back by the wait on c->consumed_ev -- was still pending: the next stage then
+                // received rows of the next chunk. Seen as a rare mismatch of eval_sequence_in_chunks on a three-stage chain.)
+                if (s - 1 > 0 && !last && hipEventRecord(p->consumed_ev, p->stream) != hipSuccess) return fail(p);
                 if (hipSetDevice(m.device) != hipSuccess || hipStreamWaitEvent(c->stream, p->handoff_ev, 0) != hipSuccess) return fail(c);
             }
             const bool want = last && m.has_head && logits_out != nullptr;
             const bool ok = T == 1 ? forward_decode(c, want) : forward(c, (int64_t) T, want);
             if (!ok) return fail(c);
-            if (s > 0 && !last && hipEventRecord(c->consumed_ev, c->stream) != hipSuccess) return fail(c);
+            // the LAST stage has no outgoing copy: done with its x behind its layers
+            if (s > 0 && s + 1 == S && !last && hipEventRecord(c->consumed_ev, c->stream) != hipSuccess) return fail(c);
         }
         done += T;
     }

@@ -1,0 +1,124 @@
+// ring_geom.h -- layout of the per-workgroup weight stream of the persistent RWKV-6 decode kernel on the LDS-DMA ring (ring_v6.hip).
+//
+// The file format fixes the bytes of a quantised block, not where they sit in HBM. The persistent kernel gives every workgroup (= CU) the
+// same rows of every matrix in every layer and consumes them in a fixed order, so at context creation the rows of a workgroup are copied
+// (k_ring_pack) into ONE contiguous stream per workgroup, in consumption order. A loader wave then moves that stream through a ring in
+// LDS with 1-KiB LDS-DMA instructions (global_load_lds_dwordx4: 64 lanes x 16 bytes, no registers), and the consumer waves read whole
+// "records" out of the ring. Host (stream builder, tests) and device (loader, consumers) compute every offset with the functions below.
+//
+// Record = R rows x U steps of one matrix (a step = 64 consecutive 32-weight blocks of a row; lane l of the consuming wave owns block
+// 64 u + l of each row, the accumulation order of DESIGN.md section 4):
+//     codes       [u][r][half][lane] 16 bytes      half = 0 (Q4 / Q5: the block's 16 code bytes), 0..1 (Q8_0: bytes 0..15, 16..31)
+//     scales      [u][r][lane]       2 bytes (fp16 d) or 4 bytes (fp16 d, fp16 m)
+//     fifth bits  [u][r][lane]       4 bytes (Q5 only)
+// Every ds_read of a consumer is lane-linear (conflict-free). Blocks past the end of a row are zero bytes in the stream.
+//
+// Layer block of workgroup b (phases in consumption order; record j of a phase goes to consumer wave (j + rot) % 6):
+//     W1    time_maa_w1 rows b, b + 256, ...              (R = 1, K = D)     -> tanh -> tl
+//     DW1   time_decay_w1 row b                           (R = 1, K = D)     -> tanh -> dl
+//     C     two-row sets of ONE of receptance/key/value/gate (R = 2, K = D)  -> r, k, v, g
+//     E     output rows                                   (R = 1, K = D)     -> x += ...
+//     FK    two-row sets of ffn.key                       (R = 2, K = D)     -> relu^2 -> k
+//     FR    ffn.receptance rows                           (R = 1, K = D)
+//     G     ffn.value rows                                (R = 1, K = F)     -> x += sigmoid(r) * ...
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RG_HD __host__ __device__ inline
+#else
+#define RG_HD inline
+#endif
+
+namespace rwkvmi {
+
+constexpr int RG_NBLK = 256;   // workgroups = CUs of an MI355X
+constexpr int RG_NC = 6;       // consumer waves per workgroup
+constexpr int RG_CHUNK = 1024; // bytes of one LDS-DMA instruction
+
+enum { RG_W1 = 0, RG_DW1 = 1, RG_C = 2, RG_E = 3, RG_FK = 4, RG_FR = 5, RG_G = 6, RG_NPHASE = 7 };
+
+struct RingShape {
+    int D, F, R5, DR;        // n_embed, ffn size, 5 x mix rank (rows of time_maa_w1), decay rank (rows of time_decay_w1)
+    int qs, scb, qhb;        // bytes per block: codes (16 | 32), scales (2 | 4), fifth bits (0 | 4)
+};
+
+RG_HD int rg_steps(int K) { return (K / 32 + 63) / 64; }
+RG_HD uint32_t rg_rec_bytes(const RingShape & s, int R, int K) { return (uint32_t) (rg_steps(K) * R * 64 * (s.qs + s.scb + s.qhb)); }
+// offsets inside a record (lane 0)
+RG_HD uint32_t rg_code_off(const RingShape & s, int R, int u, int r, int half) { return (uint32_t) (((u * R + r) * (s.qs / 16) + half) * 1024); }
+RG_HD uint32_t rg_sc_off(const RingShape & s, int R, int U, int u, int r) { return (uint32_t) (U * R * 64 * s.qs + (u * R + r) * 64 * s.scb); }
+RG_HD uint32_t rg_qh_off(const RingShape & s, int R, int U, int u, int r) { return (uint32_t) (U * R * 64 * (s.qs + s.scb) + (u * R + r) * 256); }
+
+RG_HD int rg_rows_c(const RingShape & s) { return 4 * s.D / RG_NBLK; }                 // r/k/v/g rows per workgroup (all of one matrix)
+RG_HD int rg_rows_e(const RingShape & s) { return s.D / RG_NBLK; }                     // output / receptance / value rows per workgroup
+RG_HD int rg_gpb(const RingShape & s) { return (s.F / 32 + RG_NBLK - 1) / RG_NBLK; }   // 32-row groups of ffn.key per workgroup
+
+// rows of a record: phase-specific matrix (RG_C: the matrix index 0..3 = r, k, v, g), first row, rows per record, row length
+struct RingRec { int mat, row0, R, K; };
+
+struct RingCu {
+    uint32_t n[RG_NPHASE];     // records per phase
+    uint32_t rec[RG_NPHASE];   // bytes per record
+    uint32_t off[RG_NPHASE];   // offset of the phase's first record in the layer block
+    uint32_t rot[RG_NPHASE];   // record j -> consumer (j + rot) % RG_NC
+    uint32_t layer_bytes;
+};
+
+RG_HD RingCu rg_cu(const RingShape & s, int b) {
+    RingCu c;
+    const int gpb = rg_gpb(s);
+    const int key0 = b * gpb * 32;
+    c.n[RG_W1] = (uint32_t) (s.R5 > b ? (s.R5 - b + RG_NBLK - 1) / RG_NBLK : 0);
+    c.n[RG_DW1] = (uint32_t) (b < s.DR ? 1 : 0);
+    c.n[RG_C] = (uint32_t) (rg_rows_c(s) / 2);
+    c.n[RG_E] = (uint32_t) rg_rows_e(s);
+    c.n[RG_FK] = (uint32_t) (key0 < s.F ? ((s.F - key0 < gpb * 32 ? s.F - key0 : gpb * 32) / 2) : 0);
+    c.n[RG_FR] = (uint32_t) rg_rows_e(s);
+    c.n[RG_G] = (uint32_t) rg_rows_e(s);
+    const uint32_t d1 = rg_rec_bytes(s, 1, s.D), d2 = rg_rec_bytes(s, 2, s.D), f1 = rg_rec_bytes(s, 1, s.F);
+    c.rec[RG_W1] = d1; c.rec[RG_DW1] = d1; c.rec[RG_C] = d2; c.rec[RG_E] = d1; c.rec[RG_FK] = d2; c.rec[RG_FR] = d1; c.rec[RG_G] = f1;
+    // E, FR and G share one mapping (a wave keeps the residual and the receptance of its rows in registers across the three phases);
+    // the decay row goes to the wave with the fewest r/k/v/g sets, the extra key sets to the waves with the fewest receptance rows
+    c.rot[RG_W1] = 0; c.rot[RG_DW1] = RG_NC - 1; c.rot[RG_C] = 0; c.rot[RG_E] = 0; c.rot[RG_FK] = 4; c.rot[RG_FR] = 0; c.rot[RG_G] = 0;
+    uint32_t p = 0;
+    for (int ph = 0; ph < RG_NPHASE; ph++) { c.off[ph] = p; p += c.n[ph] * c.rec[ph]; }
+    c.layer_bytes = p;
+    return c;
+}
+
+RG_HD RingRec rg_rec(const RingShape & s, int b, int phase, int j) {
+    RingRec r;
+    r.mat = 0; r.R = 1; r.K = s.D; r.row0 = 0;
+    switch (phase) {
+        case RG_W1:  r.row0 = b + RG_NBLK * j; break;
+        case RG_DW1: r.row0 = b; break;
+        case RG_C:   { const int rpb = rg_rows_c(s); r.mat = (b * rpb) / s.D; r.row0 = (b * rpb) % s.D + 2 * j; r.R = 2; } break;
+        case RG_E:   r.row0 = b * rg_rows_e(s) + j; break;
+        case RG_FK:  r.row0 = b * rg_gpb(s) * 32 + 2 * j; r.R = 2; break;
+        case RG_FR:  r.row0 = b * rg_rows_e(s) + j; break;
+        default:     r.row0 = b * rg_rows_e(s) + j; r.K = s.F; break;
+    }
+    return r;
+}
+
+// first record of consumer c in a phase (its records are j0, j0 + RG_NC, ... < n)
+RG_HD uint32_t rg_first_j(const RingCu & c, int phase, int cons) { return (uint32_t) ((cons + RG_NC - (int) c.rot[phase] % RG_NC) % RG_NC); }
+
+// Offset (in the layer block; >= layer_bytes: in the next layer's block) of the first record consumer `cons` owns in phase `from` or
+// later. This is how far the ring may be refilled once the consumer has read its last record before `from`.
+RG_HD uint32_t rg_next_own(const RingCu & c, int cons, int from) {
+    for (int k = 0; k < 2 * RG_NPHASE; k++) {
+        const int ph = from + k;
+        const int p = ph % RG_NPHASE;
+        const uint32_t j0 = rg_first_j(c, p, cons);
+        if (j0 < c.n[p]) return (ph >= RG_NPHASE ? c.layer_bytes : 0u) + c.off[p] + j0 * c.rec[p];
+    }
+    return 0xFFFFFFFFu;   // (a consumer without any record: cannot happen, E always has one per wave)
+}
+
+// a consumer wave's rows of an x-like vector (E / FR / G mapping): unit (b, c) carries rows b * rows_e + c + RG_NC * t, t < 3
+RG_HD int rg_x_rows(const RingShape & s, int cons) { const int n = rg_rows_e(s); return cons < n ? (n - cons + RG_NC - 1) / RG_NC : 0; }
+
+}  // namespace rwkvmi

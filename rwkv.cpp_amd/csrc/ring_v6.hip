@@ -1,0 +1,1186 @@
+// ring_v6.hip -- the RWKV-6 single-token (decode) step over ALL layers of a stage as ONE persistent launch, with the weights
+// streamed through an LDS ring by a dedicated loader wave (LDS-DMA, no registers).
+//
+// mega_v6.hip keeps the next phase's weights in REGISTERS of the waves that will use them. That couples the stream to the
+// compute waves: a wave that has a prefetch in flight cannot poll (vector-memory results return in order per wave), every
+// hand-over poll of the workgroup queues behind the bursts in the CU's memory pipe, and nothing streams while the owner
+// is in a prologue or a hand-over. DESIGN.md section 7.2 measured the result: ~30 us of hand-over chain per layer and a
+// ~19 us weight stream that is NOT hidden behind it (49 us per 7B layer).
+//
+// Here the stream is decoupled (MI355X_MICROARCH.md, rows ldsdma-fill / prefetch-credit / engine-vs-launches):
+//   wave 0      loader: walks the workgroup's private, contiguous weight stream (ring_geom.h: every matrix row this workgroup
+//               ever needs, packed once at context creation in the order of use) with 1-KiB global_load_lds_dwordx4 ... nt
+//               instructions into a ring in LDS, as far ahead as the ring allows -- through prologues, hand-overs and the WKV
+//               phase. It never waits for anything but ring space; while the workgroup gathers a hand-over it keeps fewer
+//               fills in flight (row gather-pass).
+//   wave 1      comm: the small serial jobs -- the data-dependent mixes of this workgroup's chunk (phase B), the WKV head (phase D,
+//               workgroups 0..H-1), quantising the channel-mixing keys.
+//   waves 2..7  consumers: row sums out of ring records (ds_read, lane-linear), results published as tagged units.
+// No wave holds weight registers, so EVERY non-loader wave can poll: each hand-over is gathered by all seven waves at once
+// (a seventh of the units each) instead of by one wave with 32 loads per lane in flight.
+// There is no s_barrier after the start-up: waves meet through monotonic counters in LDS (LDS operations of a wave execute in
+// order, so a counter bumped after a wave's stores covers them).
+//
+// Arithmetic, reduction orders and epilogues are those of fused_v6.hip / mega_v6.hip: bit-identical to
+// the CPU oracle. Residency / abort rules as for mega_v6.hip: one workgroup per CU, all resident; every wait is bounded.
+#include "persist.h"
+#include "ring_geom.h"
+
+namespace rwkvmi {
+
+struct R6Cu { unsigned long long base; unsigned chunks; unsigned layer_bytes; };   // per workgroup: stream offset, 1-KiB chunks, bytes per layer
+
+struct R6P {
+    const M6Layer * layers; int n_layers;
+    const unsigned char * arena;
+    const float * w2b;                                 // W2 of every layer in the chunk-blocked layout (k_block_w2, mega_v6.hip)
+    float * x;                                         // plain residual stream: input of the first layer, output of the last
+    const float * sin; float * sout; long long state_stride;
+    void * xch; unsigned xch_bytes;                     // the exchange arena ...
+    int tl, act5, rkvg, dl, yq, xatt, kq, xffn;         // ... buffers at these unit (16-byte) offsets
+    int act_stride;                                    // units between the five mix images
+    unsigned * ctl;                                    // [0] tag generation, [1] abort
+    const unsigned char * stream; const R6Cu * cus;     // the per-workgroup weight streams
+    int F, DR, R, H;
+    unsigned ring_bytes;                               // LDS ring (multiple of 1 KiB)
+    int inflight, thin;                                // loader: DMA instructions in flight (normal / while the workgroup gathers)
+    long long * trace; int trace_layer;
+};
+
+// monotonic words in LDS
+enum { FL_LANDED = 0, FL_THIN = 1, FL_DONE = 4 /* [8], 16-byte aligned */, FL_GX = 12, FL_GACT = 13, FL_GYQ = 14, FL_GKQ = 15,
+       FL_RED1 = 16, FL_RED2 = 17, FL_PRO = 18, FL_KEYS = 19, FL_WORDS = 32 };
+
+struct R6Lds { size_t x, q1, q2, u, tl, bc, red, out, dl, misc, fl, ring, fixed; };
+__host__ __device__ inline R6Lds r6_lds(int D, int F) {
+    R6Lds o; size_t p = 0;
+    auto take = [&](size_t n) { const size_t r = p; p += (n + 15) / 16 * 16; return r; };
+    o.x = take((size_t) D * 4); o.q1 = take(qvec_bytes(D)); o.q2 = take(qvec_bytes(D));
+    const size_t ua = 3 * ((qvec_bytes(D) + 15) / 16 * 16), ub = qvec_bytes(F);   // {act, actw, yq} (C..E) share their space with kq (G)
+    o.u = take(ua > ub ? ua : ub);
+    o.tl = take(5 * 64 * 4); o.bc = take(64 * 16); o.red = take(2 * 256 * 8); o.out = take(64 * 4); o.dl = take(qvec_bytes(256)); o.misc = take(64);
+    o.fl = take(FL_WORDS * 4);
+    p = (p + 1023) / 1024 * 1024;
+    o.ring = p; o.fixed = p;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS words shared by the waves of a workgroup. Relaxed accesses: LDS operations of one wave execute in order, which is all the
+// ordering the protocols below need; the compiler is kept from moving other accesses across with empty asm statements.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned fl_ld(unsigned * f) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ void fl_st(unsigned * f, unsigned v) { asm volatile("" ::: "memory"); if ((threadIdx.x & 63) == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void fl_add(unsigned * f, unsigned v) { asm volatile("" ::: "memory"); if ((threadIdx.x & 63) == 0) (void) __hip_atomic_fetch_add(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ bool lds_backoff(Poll & pl, unsigned spin) {
+    if ((spin & 1023u) == 1023u) {
+        if (__hip_atomic_load(pl.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) pl.dead = true;
+        else if (spin > 60000000u) { __hip_atomic_store(pl.ctl + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pl.dead = true; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+    return pl.dead;
+}
+// waits until *f >= want (bounded: the abort word ends every wait of the grid)
+__device__ __forceinline__ void fl_wait(Poll & pl, unsigned * f, unsigned want) {
+    for (unsigned spin = 0;; spin++) {
+        if (fl_ld(f) >= want || pl.dead) break;
+        if (lds_backoff(pl, spin)) break;
+    }
+    asm volatile("" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ring records -> row sums
+// ---------------------------------------------------------------------------------------------------------------
+template <int FMT, int R, int U> struct RawRec { RawBlk<FMT> raw[U][R]; };
+
+// byte `rel` of the record at ring offset `off`, for this lane (the ring wraps inside records)
+__device__ __forceinline__ unsigned ring_at(unsigned off, unsigned rel, unsigned RB) { const unsigned a = off + rel, a2 = a - RB; return a < a2 ? a : a2; }
+
+template <int FMT, int R, int U>
+__device__ __forceinline__ void rec_load(RawRec<FMT, R, U> & w, const unsigned char * ring, unsigned RB, unsigned off, int lane) {
+    constexpr unsigned QS = QF<FMT>::QS, SCB = QF<FMT>::HM ? 4 : 2;
+    constexpr unsigned SC0 = U * R * 64 * QS, QH0 = SC0 + U * R * 64 * SCB;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            RawBlk<FMT> & o = w.raw[u][r];
+            const unsigned c0 = (unsigned) ((u * R + r) * (QS / 16)) * 1024u + (unsigned) lane * 16u;
+            o.q[0] = *reinterpret_cast<const int4 *>(ring + ring_at(off, c0, RB));
+            if constexpr (QS == 32) o.q[1] = *reinterpret_cast<const int4 *>(ring + ring_at(off, c0 + 1024u, RB));
+            if constexpr (QF<FMT>::HM) o.sc = *reinterpret_cast<const uint32_t *>(ring + ring_at(off, SC0 + (unsigned) (u * R + r) * 256u + (unsigned) lane * 4u, RB));
+            else o.sc = (unsigned) *reinterpret_cast<const uint16_t *>(ring + ring_at(off, SC0 + (unsigned) (u * R + r) * 128u + (unsigned) lane * 2u, RB));
+            if constexpr (QF<FMT>::QH) o.qh = *reinterpret_cast<const uint32_t *>(ring + ring_at(off, QH0 + (unsigned) (u * R + r) * 256u + (unsigned) lane * 4u, RB));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// the record's rows against an activation image in LDS: lane l accumulates blocks l, l + 64, ... in increasing order, then the butterfly
+template <int FMT, int R, int U>
+__device__ __forceinline__ void rec_dot(const RawRec<FMT, R, U> & w, const QVec & a, int nbk, int lane, float (&res)[R]) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0f;
+    // (steps in groups of four: the activation reads of a group are in flight together, not those of a whole 7-step row)
+#pragma unroll
+    for (int u0 = 0; u0 < U; u0 += 4) {
+        int4 alo[4], ahi[4]; float dx[4], sx[4]; int asum[4]; bool valid[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (u0 + k < U) {
+                const int bb = (u0 + k) * WAVE + lane;
+                valid[k] = bb < nbk;
+                const int b = valid[k] ? bb : nbk - 1;
+                alo[k] = *reinterpret_cast<const int4 *>(a.q + b * 16);
+                ahi[k] = *reinterpret_cast<const int4 *>(a.q + nbk * 16 + b * 16);
+                dx[k] = a.d[b]; sx[k] = a.s[b]; asum[k] = a.isum[b];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (u0 + k < U) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    WBlk<FMT> wb;
+                    unpack_raw<FMT>(wb, w.raw[u0 + k][r]);
+                    acc[r] = blk_fma<FMT>(wb, alo[k], ahi[k], dx[k], sx[k], asum[k], acc[r], valid[k]);
+                }
+            }
+        }
+        if (u0 + 4 < U) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the kernel. EPT = D / 512, NBD = decay rank / 32, UF = 64-block steps of an F-long row, KSL = gather slots per lane for the
+// quantised F-vector. Exactly RG_NBLK workgroups of 512 threads.
+// ---------------------------------------------------------------------------------------------------------------
+#define R6STAMP(K) do { if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + (K)] = (long long) __builtin_readcyclecounter(); } while (0)
+#define R6RSTAMP(K) do { if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + (K)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
+
+template <int FMT, int EPT, int NBD, int UF, int KSL>
+struct R6 {
+    static constexpr int S = 64, NBLK = RG_NBLK, NC = RG_NC, NG = RG_NC + 1;   // NG: waves that gather (consumers + comm)
+    static constexpr int D = EPT * 512;
+    static constexpr int nb = D / 32;
+    static constexpr int UD = nb / 64;                       // steps of a D-long row
+    static constexpr int RE = D / NBLK;                      // output / receptance / value rows per workgroup
+    static constexpr int XT = (RE + NC - 1) / NC;            // rows per x unit (<= 3)
+    static constexpr int V4 = D / 1024;                      // float4 groups per prologue thread (256 threads)
+    static constexpr int XSL = (NBLK * NC + NG * 64 - 1) / (NG * 64);   // gather slots per lane for an x-like vector
+    static constexpr int DSL = (3 * nb + NG * 64 - 1) / (NG * 64);      // ... for a quantised D-vector
+    static_assert(UD >= 1 && XT <= 3 && D % 1024 == 0 && RE >= NC, "geometry");
+
+    struct Lds {
+        float *x, *tl, *bc, *out, *misc;
+        unsigned char *q1, *q2, *act, *actw, *yq, *kq, *dl, *ring;
+        double * red;
+        unsigned * fl;
+    };
+    static __device__ __forceinline__ RingShape shape(const R6P & p) {
+        RingShape s; s.D = D; s.F = p.F; s.R5 = 5 * p.R; s.DR = p.DR;
+        s.qs = QF<FMT>::QS; s.scb = QF<FMT>::HM ? 4 : 2; s.qhb = QF<FMT>::QH ? 4 : 0;
+        return s;
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // cooperative gathers: the NG gathering waves each poll a share of the units and stage it into LDS, then meet on a counter
+    // -----------------------------------------------------------------------------------------------------------
+    // x-like vector: unit (workgroup b, consumer c) at b * NC + c carries rows b * RE + c + NC * t, t < XT
+    static __device__ __forceinline__ void gather_x(Poll & pl, xrsrc xr, int buf, unsigned tag, int g, int lane, float * lx) {
+        constexpr int N = NBLK * NC;
+        const int i0 = g * 64 + lane;
+        v4u v[XSL];
+        for (unsigned spin = 0;; spin++) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < XSL; k++) v[k] = tg_load(xr, buf + i0 + k * NG * 64);
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < XSL; k++) ok = ok && (i0 + k * NG * 64 >= N || tg_ok(v[k], tag));
+            if (__all(ok) || pl.dead) break;
+            if (poll_backoff(pl, spin)) break;
+        }
+#pragma unroll
+        for (int k = 0; k < XSL; k++) {
+            const unsigned i = (unsigned) (i0 + k * NG * 64);
+            if (i < (unsigned) N) {
+                const unsigned b = (i * 43691u) >> 18;         // i / 6 for i < 2^16
+                const unsigned c = i - 6u * b;
+                float * dst = lx + b * RE + c;
+                dst[0] = __uint_as_float(v[k].x);
+                if (XT > 1 && c + NC < (unsigned) RE) dst[NC] = __uint_as_float(v[k].y);
+                if (XT > 2 && c + 2 * NC < (unsigned) RE) dst[2 * NC] = __uint_as_float(v[k].z);
+            }
+        }
+    }
+    // quantised vector of K elements (3 units per 32-element block, see tq_store_block) into its lohi image
+    template <int SL>
+    static __device__ __forceinline__ void gather_qvec(Poll & pl, xrsrc xr, int src, int K, unsigned tag, int g, int lane, unsigned char * l) {
+        const int nbk = K / 32, n = 3 * nbk;
+        const QVec q = qvec_at(l, K);
+        unsigned * img = reinterpret_cast<unsigned *>(l);
+        const int i0 = g * 64 + lane;
+        v4u v[SL];
+        for (unsigned spin = 0;; spin++) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < SL; k++) v[k] = tg_load(xr, src + i0 + k * NG * 64);
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < SL; k++) ok = ok && (i0 + k * NG * 64 >= n || tg_ok(v[k], tag));
+            if (__all(ok) || pl.dead) break;
+            if (poll_backoff(pl, spin)) break;
+        }
+#pragma unroll
+        for (int k = 0; k < SL; k++) {
+            const unsigned i = (unsigned) (i0 + k * NG * 64);
+            if (i < (unsigned) n) {
+                const unsigned b = (i * 43691u) >> 17;         // i / 3 for i < 2^16
+                const unsigned kk = i - 3u * b;
+                const unsigned j0 = 3u * kk, j1 = j0 + 1u;     // dword index of .x / .y within the block's eight code dwords
+                img[(j0 < 4u ? 0u : 4u * nbk) + 4u * b + (j0 & 3u)] = v[k].x;
+                img[(j1 < 4u ? 0u : 4u * nbk) + 4u * b + (j1 & 3u)] = v[k].y;
+                if (kk < 2u) {
+                    const unsigned j2 = j0 + 2u;
+                    img[(j2 < 4u ? 0u : 4u * nbk) + 4u * b + (j2 & 3u)] = v[k].z;
+                } else {
+                    q.d[b] = h2f_bits((uint16_t) (v[k].z & 0xFFFFu)); q.s[b] = h2f_bits((uint16_t) (v[k].z >> 16));
+                    q.isum[b] = (int) (short) (v[k].w >> 16);
+                }
+            }
+        }
+    }
+    // every gathering wave, after staging its share: arrive, then wait for the others' shares (gen = gathers of this kind so far)
+    static __device__ __forceinline__ void gather_meet(Poll & pl, unsigned * f, unsigned gen) {
+        fl_add(f, 1u);
+        fl_wait(pl, f, (unsigned) NG * gen);
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // prologues (consumer waves 0..3 = 256 threads)
+    // -----------------------------------------------------------------------------------------------------------
+    struct PA { float4 lw[V4], lb[V4], pv[V4], mx[V4]; };
+    struct PF { float4 lw[V4], lb[V4], pv[V4], mk[V4], mr[V4]; };
+    static __device__ __forceinline__ void issue_pa(PA & pa, const M6Arena & ar, const M6Layer & L, const float * sin_l, int pt) {
+        const float * ln1_w = ar.f(L.ln1_w), * ln1_b = ar.f(L.ln1_b), * maa_x = ar.f(L.maa_x);
+#pragma unroll
+        for (int u = 0; u < V4; u++) {
+            const int i = pt * 4 + u * 1024;
+            pa.lw[u] = *reinterpret_cast<const float4 *>(ln1_w + i); pa.lb[u] = *reinterpret_cast<const float4 *>(ln1_b + i);
+            pa.pv[u] = *reinterpret_cast<const float4 *>(sin_l + D + i); pa.mx[u] = *reinterpret_cast<const float4 *>(maa_x + i);
+        }
+    }
+    static __device__ __forceinline__ void issue_pf(PF & pf, const M6Arena & ar, const M6Layer & L, const float * sin_l, int pt) {
+        const float * ln2_w = ar.f(L.ln2_w), * ln2_b = ar.f(L.ln2_b), * fmaa_k = ar.f(L.fmaa_k), * fmaa_r = ar.f(L.fmaa_r);
+#pragma unroll
+        for (int u = 0; u < V4; u++) {
+            const int i = pt * 4 + u * 1024;
+            pf.lw[u] = *reinterpret_cast<const float4 *>(ln2_w + i); pf.lb[u] = *reinterpret_cast<const float4 *>(ln2_b + i);
+            pf.pv[u] = *reinterpret_cast<const float4 *>(sin_l + i);
+            pf.mk[u] = *reinterpret_cast<const float4 *>(fmaa_k + i); pf.mr[u] = *reinterpret_cast<const float4 *>(fmaa_r + i);
+        }
+    }
+    // LayerNorm statistics of the row in l.x: thread pt < 256 owns the partial over elements pt, pt + 256, ...;
+    // every wave folds the 256 partials itself (the additions of block_sum_d). Leaves x - mean in l.x. gen = prologues so far.
+    static __device__ __forceinline__ float ln_stats(Poll & pl, const Lds & l, int pt, int lane, unsigned gen) {
+        constexpr int NP = D / 256;
+        float xv[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) xv[j] = l.x[pt + 256 * j];
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; j++) sacc += (double) xv[j];
+        l.red[pt] = sacc;
+        fl_add(l.fl + FL_RED1, 1u);
+        fl_wait(pl, l.fl + FL_RED1, 4u * gen);
+        const double t1 = (l.red[lane] + l.red[lane + 128]) + (l.red[lane + 64] + l.red[lane + 192]);
+        const float mean = (float) (wave_sum_d(t1) / (double) D);
+        double s2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; j++) { const float v = xv[j] - mean; l.x[pt + 256 * j] = v; s2 += (double) (v * v); }
+        l.red[256 + pt] = s2;
+        fl_add(l.fl + FL_RED2, 1u);
+        fl_wait(pl, l.fl + FL_RED2, 4u * gen);
+        const double t2 = (l.red[256 + lane] + l.red[256 + lane + 128]) + (l.red[256 + lane + 64] + l.red[256 + lane + 192]);
+        const float var = (float) (wave_sum_d(t2) / (double) D);
+        return 1.0f / sqrtf(var + 1e-5f);
+    }
+    // A: LN1 + token shift + maa_x mix + quantise -> l.q1
+    static __device__ __forceinline__ void prologue_A(Poll & pl, const Lds & l, const PA & pa, float * sout_l, bool write_state, int pt, int lane, unsigned gen) {
+        const float scale = ln_stats(pl, l, pt, lane, gen);
+        if (pt == 0) l.misc[0] = scale;
+        const QVec lq = qvec_at(l.q1, D);
+#pragma unroll
+        for (int u = 0; u < V4; u++) {
+            const int i = pt * 4 + u * 1024;
+            const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
+            const float xs[4] = {xc.x, xc.y, xc.z, xc.w};
+            const float lw[4] = {pa.lw[u].x, pa.lw[u].y, pa.lw[u].z, pa.lw[u].w}, lb[4] = {pa.lb[u].x, pa.lb[u].y, pa.lb[u].z, pa.lb[u].w};
+            const float pv[4] = {pa.pv[u].x, pa.pv[u].y, pa.pv[u].z, pa.pv[u].w}, mx[4] = {pa.mx[u].x, pa.mx[u].y, pa.mx[u].z, pa.mx[u].w};
+            float xn[4], xxx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float y = xs[j] * scale;
+                const float yw = y * lw[j];
+                xn[j] = yw + lb[j];
+                const float sx = pv[j] - xn[j];
+                const float sm = sx * mx[j];
+                xxx[j] = sm + xn[j];
+            }
+            if (write_state) *reinterpret_cast<float4 *>(sout_l + D + i) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+            unsigned packed; float d16, s16; int isum;
+            quant_vec4(xxx, packed, d16, s16, isum);
+            qvec_store4(lq, nb, i, packed, d16, s16, isum);
+        }
+        fl_add(l.fl + FL_PRO, 1u);
+    }
+    // F: LN2 + token shift + the two mixes + quantise -> l.q1 (key input), l.q2 (receptance input)
+    static __device__ __forceinline__ void prologue_F(Poll & pl, const Lds & l, const PF & pf, float * sout_l, bool write_state, int pt, int lane, unsigned gen) {
+        const float scale = ln_stats(pl, l, pt, lane, gen);
+        const QVec qk = qvec_at(l.q1, D), qr = qvec_at(l.q2, D);
+#pragma unroll
+        for (int u = 0; u < V4; u++) {
+            const int i = pt * 4 + u * 1024;
+            const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
+            const float xs[4] = {xc.x, xc.y, xc.z, xc.w};
+            const float lw[4] = {pf.lw[u].x, pf.lw[u].y, pf.lw[u].z, pf.lw[u].w}, lb[4] = {pf.lb[u].x, pf.lb[u].y, pf.lb[u].z, pf.lb[u].w};
+            const float pv[4] = {pf.pv[u].x, pf.pv[u].y, pf.pv[u].z, pf.pv[u].w};
+            const float mk[4] = {pf.mk[u].x, pf.mk[u].y, pf.mk[u].z, pf.mk[u].w}, mr[4] = {pf.mr[u].x, pf.mr[u].y, pf.mr[u].z, pf.mr[u].w};
+            float xn[4], xk[4], xr[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float y = xs[j] * scale;
+                const float yw = y * lw[j];
+                xn[j] = yw + lb[j];
+                const float sx = pv[j] - xn[j];
+                const float sk = sx * mk[j];
+                xk[j] = sk + xn[j];
+                const float sr = sx * mr[j];
+                xr[j] = sr + xn[j];
+            }
+            if (write_state) *reinterpret_cast<float4 *>(sout_l + i) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+            unsigned packed; float d16, s16; int isum;
+            quant_vec4(xk, packed, d16, s16, isum);
+            qvec_store4(qk, nb, i, packed, d16, s16, isum);
+            quant_vec4(xr, packed, d16, s16, isum);
+            qvec_store4(qr, nb, i, packed, d16, s16, isum);
+        }
+        fl_add(l.fl + FL_PRO, 1u);
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // loader wave
+    // -----------------------------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void dma_chunk(unsigned long long sbase, unsigned voff, unsigned m0dst) {
+        // (inline asm: M0 is not preserved around a statement, and through the builtin the compiler would wait for every DMA in flight
+        //  at the next LDS access; completion is counted by hand. s_nop 4: the scalar base may have been written just before.)
+        unsigned keep;
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0dst) : "memory");
+    }
+    static __device__ __forceinline__ void wait_vm(int w) {
+        switch (w) {   // (immediate operand)
+            case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 8:  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+            case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+            case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+        }
+    }
+    static __device__ __forceinline__ void loader_main(const R6P & p, const Lds & l, int lane) {
+        const int wave = 0;
+        const R6Cu cu = p.cus[blockIdx.x];
+        const unsigned total = __builtin_amdgcn_readfirstlane(cu.chunks);
+        const unsigned long long src0 = (unsigned long long) p.stream + cu.base;
+        const unsigned s_lo = __builtin_amdgcn_readfirstlane((unsigned) src0), s_hi = __builtin_amdgcn_readfirstlane((unsigned) (src0 >> 32));
+        const unsigned RB = __builtin_amdgcn_readfirstlane(p.ring_bytes);
+        const unsigned ring_m0 = __builtin_amdgcn_readfirstlane((unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) l.ring);
+        const unsigned voff = (unsigned) lane * 16u;
+        const int w_norm = __builtin_amdgcn_readfirstlane(p.inflight), w_thin = __builtin_amdgcn_readfirstlane(p.thin);
+        Poll pl{p.ctl, false};
+        unsigned issued = 0, roff = 0, landed = 0;
+        unsigned min_done = 0, thin = 0;
+        const int li = p.trace_layer;   // (stamps: once per launch)
+        R6STAMP(0);
+        unsigned stalls = 0;
+        for (unsigned spin = 0; issued < total;) {
+            const unsigned lim0 = min_done >= total * 1024u ? total : (min_done + RB) >> 10;
+            const unsigned lim = lim0 < total ? lim0 : total;
+            if (issued >= lim) {
+                // ring full: retire what is in flight, publish it, look again
+                if (landed != issued) { wait_vm(0); landed = issued; fl_st(l.fl + FL_LANDED, landed); }
+                stalls++;
+                if (lds_backoff(pl, spin++)) break;
+            } else {
+                spin = 0;
+                unsigned n = lim - issued;
+                n = n < 4u ? n : 4u;
+                for (unsigned k = 0; k < n; k++) {
+                    const unsigned long long sb = (((unsigned long long) s_hi << 32) | s_lo) + (unsigned long long) (issued + k) * 1024ull;
+                    dma_chunk(sb, voff, ring_m0 + roff);
+                    roff += 1024u; roff = roff >= RB ? 0u : roff;
+                }
+                issued += n;
+                const int w = thin ? w_thin : w_norm;
+                wait_vm(w);                                       // fills land in order: at most w of them are still in flight
+                const unsigned ld = issued > (unsigned) w ? issued - (unsigned) w : 0u;
+                if (ld > landed) { landed = ld; fl_st(l.fl + FL_LANDED, landed); }
+            }
+            // the consumers' positions (the ring may be refilled up to the smallest) and the gather flag
+            {
+                asm volatile("" ::: "memory");
+                const v4u a = *reinterpret_cast<const v4u *>(l.fl + FL_DONE), b = *reinterpret_cast<const v4u *>(l.fl + FL_DONE + 4);
+                unsigned m = a.x < a.y ? a.x : a.y; m = m < a.z ? m : a.z; m = m < a.w ? m : a.w;
+                m = m < b.x ? m : b.x; m = m < b.y ? m : b.y; m = m < b.z ? m : b.z; m = m < b.w ? m : b.w;
+                min_done = __builtin_amdgcn_readfirstlane(m);
+                thin = fl_ld(l.fl + FL_THIN);
+            }
+        }
+        wait_vm(0);
+        fl_st(l.fl + FL_LANDED, total);
+        R6STAMP(1);
+        if (p.trace && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 2] = (long long) stalls;
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // consumer waves
+    // -----------------------------------------------------------------------------------------------------------
+    struct Cons {
+        RingCu cu;
+        unsigned lbase;        // stream position of the current layer's block
+        unsigned rpos, roff;   // ring cursor: stream position and its ring offset
+        unsigned RB;
+        unsigned landed;       // chunks known to have landed
+        int c, lane;
+    };
+    // positions the cursor on the record at stream position pos and waits until its bytes are in the ring
+    static __device__ __forceinline__ void rec_seek(Cons & cs, Poll & pl, const Lds & l, unsigned pos, unsigned bytes) {
+        unsigned ro = cs.roff + (pos - cs.rpos);
+        while (ro >= cs.RB) ro -= cs.RB;
+        cs.roff = __builtin_amdgcn_readfirstlane(ro); cs.rpos = pos;
+        // (the loader usually runs far ahead: the last value seen mostly covers the record, no LDS round trip)
+        const unsigned need = (pos + bytes + 1023u) >> 10;
+        for (unsigned spin = 0; cs.landed < need; spin++) {
+            cs.landed = fl_ld(l.fl + FL_LANDED);
+            if (cs.landed >= need || pl.dead) break;
+            if (lds_backoff(pl, spin)) break;
+        }
+        asm volatile("" ::: "memory");
+    }
+    // the records of one phase that belong to this wave; epi(j, res) receives the row sums of record j
+    template <int PH, int R, int U, typename EpiF>
+    static __device__ __forceinline__ void run_phase(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, EpiF && epi) {
+        const unsigned n = cs.cu.n[PH], rec = cs.cu.rec[PH];
+        const unsigned after = cs.lbase + rg_next_own(cs.cu, cs.c, PH + 1);
+        for (unsigned j = rg_first_j(cs.cu, PH, cs.c); j < n; j += NC) {
+            const unsigned pos = cs.lbase + cs.cu.off[PH] + j * rec;
+            rec_seek(cs, pl, l, pos, rec);
+            RawRec<FMT, R, U> w;
+            rec_load<FMT, R, U>(w, l.ring, cs.RB, cs.roff, opq(cs.lane));
+            // the reads above are in the LDS queue: the ring may be refilled up to this wave's next record
+            fl_st(l.fl + FL_DONE + 2 + cs.c, j + NC < n ? pos + NC * rec : after);
+            float res[R];
+            rec_dot<FMT, R, U>(w, act, nbk, opq(cs.lane), res);
+            epi((int) j, res);
+        }
+    }
+
+    static __device__ __forceinline__ void consumer_main(const R6P & p, const Lds & l, int lane, int wave, unsigned base) {
+        const int blk = blockIdx.x;
+        const int c = wave - 2;                       // consumer index = gather share
+        const int pt = c * 64 + lane;                 // prologue thread (c < 4)
+        const bool pro = c < 4;
+        // The prologue parameters are loaded by EVERY consumer wave (waves 4, 5 re-read wave 0's and 1's): a load under `if (pro)` is a
+        // conditional definition, and the compiler then waits for it and copies it right where it is issued.
+        const int ppt = pro ? pt : lane;
+        const int F = p.F, nbF = F / 32;
+        Poll pl{p.ctl, false};
+        const M6Arena ar{p.arena};
+        const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
+        const RingShape sh = shape(p);
+        Cons cs;
+        cs.cu = rg_cu(sh, blk); cs.lbase = 0; cs.rpos = 0; cs.roff = 0; cs.landed = 0; cs.RB = __builtin_amdgcn_readfirstlane(p.ring_bytes); cs.c = c; cs.lane = lane;
+        const int mat = (blk * (4 * D / NBLK)) / D;   // which of r, k, v, g this workgroup's sets belong to
+        const int cbase = (blk * (4 * D / NBLK)) % D;
+        const bool has_dw1 = blk < p.DR;
+
+        float xown[XT], rrow[XT];
+#pragma unroll
+        for (int t = 0; t < XT; t++) { const int row = c + NC * t; xown[t] = row < RE ? p.x[blk * RE + row] : 0.0f; rrow[t] = 0.0f; }
+        PA pa; PF pf;
+        issue_pa(pa, ar, p.layers[0], p.sin, opq(ppt));
+
+        for (int li = 0; li < p.n_layers; li++) {
+            const M6Layer & L = p.layers[li];
+            const float * sin_l = p.sin + (long long) li * p.state_stride;
+            float * sout_l = p.sout + (long long) li * p.state_stride;
+            const unsigned tagL = base + (unsigned) li * 8u;
+            const unsigned g1 = (unsigned) li + 1u;   // generation of this layer's once-per-layer counters
+            cs.lbase = (unsigned) li * cs.cu.layer_bytes;
+            R6STAMP(0);
+            // (per-lane offsets are derived from an opaque copy of the lane index in every phase: left alone, the compiler hoists a
+            //  hundred loop-invariant address registers of the gathers out of the layer loop and spills them)
+            // ---- A: x, LN1 + mix + quantise, W1 rows ----
+            if (li == 0) {
+                for (int i = c * 64 + lane; i < D; i += NG * 64) l.x[i] = p.x[i];
+            } else {
+                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, c, opq(lane), l.x);
+            }
+            gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
+            R6STAMP(1);
+            if (pro) prologue_A(pl, l, pa, sout_l, blk == 0, opq(pt), opq(lane), 2u * li + 1u);
+            fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 1u));
+            R6STAMP(2);
+            run_phase<RG_W1, 1, UD>(cs, pl, l, qvec_at(l.q1, D), nb, [&](int j, const float (&res)[1]) {
+                if (lane == 0) tg_store(xr, p.tl + blk + NBLK * j, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
+            });
+            R6STAMP(3);
+            // ---- C: the mixed inputs (this workgroup's matrix reads ONE of the five), decay row, r/k/v/g sets ----
+            {
+                const int img = (0x4213 >> (4 * mat)) & 0xF;   // r, k, v, g -> mix image (w, k, v, r, g order)
+                gather_qvec<DSL>(pl, xr, p.act5 + img * p.act_stride, D, tagL + SLOT_ACT, c, opq(lane), l.act);
+                if (has_dw1) gather_qvec<DSL>(pl, xr, p.act5, D, tagL + SLOT_ACT, c, opq(lane), l.actw);
+                gather_meet(pl, l.fl + FL_GACT, g1);
+            }
+            R6STAMP(4);
+            run_phase<RG_DW1, 1, UD>(cs, pl, l, qvec_at(l.actw, D), nb, [&](int, const float (&res)[1]) {
+                if (lane == 0) tg_store(xr, p.dl + blk, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
+            });
+            run_phase<RG_C, 2, UD>(cs, pl, l, qvec_at(l.act, D), nb, [&](int j, const float (&res)[2]) {
+                float v = lane == 1 ? res[1] : res[0];
+                if (mat == 3) v = v / (1.0f + det_expf(-v));     // gate: silu
+                const int v1 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true);   // lane 0 collects row 1 (row_shl:1)
+                if (lane == 0) tg_store(xr, p.rkvg + ((mat * D + cbase + 2 * j) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
+            });
+            R6STAMP(5);
+            issue_pf(pf, ar, L, sin_l, opq(ppt));
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- E: output projection + residual ----
+            gather_qvec<DSL>(pl, xr, p.yq, D, tagL + SLOT_YQ, c, opq(lane), l.yq);
+            gather_meet(pl, l.fl + FL_GYQ, g1);
+            R6STAMP(6);
+            run_phase<RG_E, 1, UD>(cs, pl, l, qvec_at(l.yq, D), nb, [&](int j, const float (&res)[1]) {
+                const int t = j / NC;
+#pragma unroll
+                for (int tt = 0; tt < XT; tt++) if (tt == t) xown[tt] = xown[tt] + res[0];
+            });
+            if (lane == 0) tg_store(xr, p.xatt + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XATT);
+            R6STAMP(7);
+            // ---- F: x, LN2 + mixes + quantise, key sets (-> comm quantises them), receptance rows ----
+            gather_x(pl, xr, p.xatt, tagL + SLOT_XATT, c, opq(lane), l.x);
+            gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
+            R6STAMP(8);
+            if (pro) prologue_F(pl, l, pf, sout_l, blk == 0, opq(pt), opq(lane), 2u * li + 2u);
+            fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 2u));
+            R6STAMP(9);
+            run_phase<RG_FK, 2, UD>(cs, pl, l, qvec_at(l.q1, D), nb, [&](int j, const float (&res)[2]) {
+                const float v = lane == 1 ? res[1] : res[0];
+                const float t = v > 0.0f ? v : 0.0f;
+                if (lane < 2) l.out[2 * j + lane] = t * t;
+            });
+            fl_add(l.fl + FL_KEYS, 1u);
+            R6STAMP(10);
+            run_phase<RG_FR, 1, UD>(cs, pl, l, qvec_at(l.q2, D), nb, [&](int j, const float (&res)[1]) {
+                const int t = j / NC;
+#pragma unroll
+                for (int tt = 0; tt < XT; tt++) if (tt == t) rrow[tt] = res[0];
+            });
+            {
+                const int nl = li + 1 < p.n_layers ? li + 1 : li;
+                issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, opq(ppt));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            R6STAMP(11);
+            // ---- G: value projection, x += sigmoid(r) * (Wv k) ----
+            gather_qvec<KSL>(pl, xr, p.kq, F, tagL + SLOT_KQ, c, opq(lane), l.kq);
+            gather_meet(pl, l.fl + FL_GKQ, g1);
+            R6STAMP(12);
+            run_phase<RG_G, 1, UF>(cs, pl, l, qvec_at(l.kq, F), nbF, [&](int j, const float (&res)[1]) {
+                const int t = j / NC;
+#pragma unroll
+                for (int tt = 0; tt < XT; tt++) if (tt == t) {
+                    const float gte = sigmoid_f(rrow[tt]) * res[0];
+                    xown[tt] = xown[tt] + gte;
+                    if (li == p.n_layers - 1 && lane == 0) p.x[blk * RE + j] = xown[tt];
+                }
+            });
+            if (lane == 0) tg_store(xr, p.xffn + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
+            R6STAMP(13); R6RSTAMP(14);
+        }
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // comm wave
+    // -----------------------------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void comm_main(const R6P & p, const Lds & l, int lane, unsigned base) {
+        const int wave = 1;
+        const int blk = blockIdx.x;
+        const int g = NC;                              // gather share
+        const int F = p.F, DR = p.DR, R = p.R, H = p.H;
+        const int nbF = F / 32;
+        Poll pl{p.ctl, false};
+        const M6Arena ar{p.arena};
+        const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
+        const int mat = (blk * (4 * D / NBLK)) / D;
+        const bool has_dw1 = blk < DR;
+        const bool d_has = blk < H;
+        const int d_head = blk;
+        const int gpb = (nbF + NBLK - 1) / NBLK;
+        // B: 64-element chunks of the five mixes; chunk ch < NBLK on workgroup ch, the rest on workgroups NBLK/4.. (the first quarter
+        // runs the WKV heads)
+        constexpr int NCH = 5 * (D / 64);
+        const int b_extra = NCH - NBLK;
+        const int b_chunk2 = (b_extra > 0 && blk >= NBLK / 4 && blk < NBLK / 4 + b_extra) ? NBLK + (blk - NBLK / 4) : -1;
+
+        for (int li = 0; li < p.n_layers; li++) {
+            const M6Layer & L = p.layers[li];
+            const float * sin_l = p.sin + (long long) li * p.state_stride;
+            float * sout_l = p.sout + (long long) li * p.state_stride;
+            const unsigned tagL = base + (unsigned) li * 8u;
+            const unsigned g1 = (unsigned) li + 1u;
+            R6STAMP(0);
+            // ---- A ----
+            fl_st(l.fl + FL_THIN, 1u);
+            if (li == 0) {
+                for (int i = g * 64 + lane; i < D; i += NG * 64) l.x[i] = p.x[i];
+            } else {
+                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, g, opq(lane), l.x);
+            }
+            gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
+            fl_st(l.fl + FL_THIN, 0u);
+            R6STAMP(1); R6RSTAMP(17);
+            // W2 of this workgroup's chunk(s) (chunk-blocked copy: lane d reads float4 {m .. m+3}) and the chunk's LayerNorm / shift
+            // parameters: in flight while the prologue waves run
+            const int lnA = opq(lane);
+            float4 wB4[2][16]; float wBmaa[2], cw[2], cb_[2], cpv[2];
+            int bf[2], bd[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int ch = q == 0 ? (blk < NCH ? blk : 0) : (b_chunk2 >= 0 ? b_chunk2 : 0);
+                bf[q] = ch / (D / 64);
+                bd[q] = (ch % (D / 64)) * 64 + lnA;
+                const float4 * cbp = reinterpret_cast<const float4 *>(p.w2b + L.w2b + (long long) ch * R * 64);
+#pragma unroll
+                for (int m4 = 0; m4 < 16; m4++) { const int4 t = ldw16(cbp + (m4 < R / 4 ? m4 : R / 4 - 1) * 64 + lnA); wB4[q][m4] = make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(t.w)); }
+                wBmaa[q] = ar.f(L.maa[bf[q]])[bd[q]];
+                cw[q] = ar.f(L.ln1_w)[bd[q]]; cb_[q] = ar.f(L.ln1_b)[bd[q]]; cpv[q] = sin_l[D + bd[q]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 1u));   // l.x holds x - mean, l.misc[0] the scale
+            R6STAMP(2);
+            // ---- B: the data-dependent mixes of this workgroup's chunk(s) (rwkv_graph.inc:313-346) ----
+            {
+                const int ln = opq(lane);
+                const float scale = l.misc[0];
+                float cxn[2], csx[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const float y = l.x[bd[q]] * scale;
+                    const float yw = y * cw[q];
+                    cxn[q] = yw + cb_[q];
+                    csx[q] = cpv[q] - cxn[q];
+                }
+                fl_st(l.fl + FL_THIN, 1u);
+                poll_units<5, 64>(pl, xr, p.tl, 5 * R, tagL + SLOT_TL, ln, [&](int i, const v4u & v) { l.tl[i] = __uint_as_float(v.x); });
+                fl_st(l.fl + FL_THIN, 0u);
+                __builtin_amdgcn_wave_barrier();
+                R6STAMP(3); R6RSTAMP(18);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const bool has = q == 0 ? blk < NCH : b_chunk2 >= 0;
+                    if (has) {
+                        const float * tlf = l.tl + bf[q] * R;
+                        const float4 * tl4 = reinterpret_cast<const float4 *>(tlf);
+                        float acc = 0.0f;
+                        {
+                            float4 t4[8];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) t4[j] = tl4[j];
+#pragma unroll
+                            for (int m = 0; m < 32; m++) acc += (&wB4[q][m >> 2].x)[m & 3] * (&t4[m >> 2].x)[m & 3];
+                        }
+                        if (R > 32) {
+                            float4 t4[8];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) t4[j] = tl4[8 + j];
+#pragma unroll
+                            for (int m = 0; m < 32; m++) acc += (&wB4[q][8 + (m >> 2)].x)[m & 3] * (&t4[m >> 2].x)[m & 3];
+                        }
+                        const float mm = (acc + wBmaa[q]) * csx[q];
+                        const float o = mm + cxn[q];
+                        int qi, isum; float d16, s16;
+                        quant_block32(o, qi, d16, s16, isum);
+                        tq_store_block(xr, p.act5 + bf[q] * p.act_stride, bd[q] >> 5, ln & 31, qi, d16, s16, isum, tagL + SLOT_ACT);
+                    }
+                }
+            }
+            R6RSTAMP(19); R6STAMP(4);
+            // ---- C: stage this workgroup's share of the mixed inputs ----
+            {
+                fl_st(l.fl + FL_THIN, 1u);
+                const int img = (0x4213 >> (4 * mat)) & 0xF;
+                gather_qvec<DSL>(pl, xr, p.act5 + img * p.act_stride, D, tagL + SLOT_ACT, g, opq(lane), l.act);
+                if (has_dw1) gather_qvec<DSL>(pl, xr, p.act5, D, tagL + SLOT_ACT, g, opq(lane), l.actw);
+                gather_meet(pl, l.fl + FL_GACT, g1);
+                fl_st(l.fl + FL_THIN, 0u);
+            }
+            R6STAMP(5); R6RSTAMP(20);
+            // ---- D: WKV head of this workgroup ----
+            if (d_has) {
+                const int ln = opq(lane);
+                const int c = d_head * S + ln;
+                RawBlk<FMT> w2[NBD];
+                const WPl dw2 = ar.w(L.dw2);
+#pragma unroll
+                for (int b = 0; b < NBD; b++) load_raw<FMT>(w2[b], dw2.qs, dw2.qh, dw2.sc, (long long) c * NBD + b);
+                const float td = ar.f(L.time_decay)[c], uu = ar.f(L.faaaa)[c], lnw = ar.f(L.lnx_w)[c], lnb = ar.f(L.lnx_b)[c];
+                float s[S];
+                const float * st = sin_l + 2 * D + (long long) d_head * S * S;
+#pragma unroll
+                for (int i = 0; i < S; i++) s[i] = st[i * S + ln];
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned dq[6];
+                {
+                    const int ptr[2] = {p.dl + ln, p.dl + (NBD > 2 ? 64 + ln : ln)};
+                    const bool valid[2] = {true, NBD > 2};
+                    v4u dv[2];
+                    poll_ptrs<2>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
+                    dq[4] = dv[0].x; dq[5] = dv[1].x;
+                }
+                v4u early[4];
+                {
+                    asm volatile("" ::: "memory");
+                    early[0] = tg_load(xr, p.rkvg + (c >> 1)); early[1] = tg_load(xr, p.rkvg + ((D + c) >> 1));
+                    early[2] = tg_load(xr, p.rkvg + ((2 * D + c) >> 1)); early[3] = tg_load(xr, p.rkvg + ((3 * D + c) >> 1));
+                }
+                // 1. quantise dl (DR = 32 NBD elements) into LDS: half-wave = block
+                const QVec ldl = qvec_at(l.dl, NBD * 32);
+#pragma unroll
+                for (int j = 0; j < (NBD * 32 + 63) / 64; j++) {
+                    const int e = j * 64 + ln;
+                    const float val = e < NBD * 32 ? __uint_as_float(dq[4 + j]) : 0.0f;
+                    int qi, isum; float d16, s16;
+                    quant_block32(val, qi, d16, s16, isum);
+                    if (e < NBD * 32) qvec_store(ldl, NBD, e >> 5, e & 31, qi, d16, s16, isum);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // 2. decay row of channel c
+                float P[NBD];
+#pragma unroll
+                for (int b = 0; b < NBD; b++) {
+                    WBlk<FMT> w;
+                    unpack_raw<FMT>(w, w2[b]);
+                    const int4 alo = *reinterpret_cast<const int4 *>(ldl.q + b * 16);
+                    const int4 ahi = *reinterpret_cast<const int4 *>(ldl.q + NBD * 16 + b * 16);
+                    P[b] = blk_fma<FMT>(w, alo, ahi, ldl.d[b], ldl.s[b], ldl.isum[b], 0.0f);
+                }
+#pragma unroll
+                for (int o = NBD / 2; o > 0; o >>= 1)
+#pragma unroll
+                    for (int i = 0; i < o; i++) P[i] += P[i + o];
+                const float wdec = det_expf(-det_expf(P[0] + td));
+                // r, k, v, g of channel c: one unit per 2-row set (first read issued above, before the decay was computed)
+                {
+                    const int ptr[4] = {p.rkvg + (c >> 1), p.rkvg + ((D + c) >> 1), p.rkvg + ((2 * D + c) >> 1), p.rkvg + ((3 * D + c) >> 1)};
+                    const bool valid[4] = {true, true, true, true};
+                    v4u dv[4] = {early[0], early[1], early[2], early[3]};
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) ok = ok && tg_ok(dv[q], tagL + SLOT_RKVG);
+                    if (!__all(ok)) poll_ptrs<4>(pl, xr, ptr, valid, tagL + SLOT_RKVG, dv);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) dq[q] = (c & 1) ? dv[q].y : dv[q].x;
+                }
+                // 3. WKV6 (ggml_rwkv_wkv6): ln j owns value column j; {k, u, r, w}_i are broadcast through LDS
+                float4 * bc = reinterpret_cast<float4 *>(l.bc);
+                bc[ln] = make_float4(__uint_as_float(dq[1]), uu, __uint_as_float(dq[0]), wdec);
+                __builtin_amdgcn_wave_barrier();
+                const float vj = __uint_as_float(dq[2]);
+                float o = 0.0f;
+                float * so = sout_l + 2 * D + (long long) d_head * S * S;
+#pragma unroll
+                for (int i0 = 0; i0 < S; i0 += 8) {
+                    float4 b8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) b8[u] = bc[i0 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int i = i0 + u;
+                        const float kv = vj * b8[u].x;
+                        const float prev = s[i];
+                        const float temp = kv * b8[u].y + prev;
+                        o += temp * b8[u].z;
+                        so[i * S + ln] = prev * b8[u].w + kv;
+                    }
+                }
+                // 4. GroupNorm over the head, * ln_x, gate
+                const float mean = (float) (wave_sum_d((double) o) / (double) S);
+                const float dv = o - mean;
+                const float var = (float) (wave_sum_d((double) (dv * dv)) / (double) S);
+                const float scale = 1.0f / sqrtf(var + 64e-5f);
+                float y = dv * scale;
+                y = y * lnw;
+                y = y + lnb;
+                y *= __uint_as_float(dq[3]);
+                int qi, isum; float d16, s16;
+                quant_block32(y, qi, d16, s16, isum);
+                tq_store_block(xr, p.yq, 2 * d_head + (ln >> 5), ln & 31, qi, d16, s16, isum, tagL + SLOT_YQ);
+            }
+            R6STAMP(6); R6RSTAMP(21);
+            // ---- E ----
+            fl_st(l.fl + FL_THIN, 1u);
+            gather_qvec<DSL>(pl, xr, p.yq, D, tagL + SLOT_YQ, g, opq(lane), l.yq);
+            gather_meet(pl, l.fl + FL_GYQ, g1);
+            R6STAMP(7); R6RSTAMP(22);
+            // ---- F ----
+            gather_x(pl, xr, p.xatt, tagL + SLOT_XATT, g, opq(lane), l.x);
+            gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
+            fl_st(l.fl + FL_THIN, 0u);
+            R6STAMP(8); R6RSTAMP(23);
+            fl_wait(pl, l.fl + FL_KEYS, (unsigned) NC * g1);     // every consumer's key sets are in l.out
+            R6STAMP(9);
+            {
+                // quantise this workgroup's key groups (relu^2 outputs): half-wave = group
+                const int ln = opq(lane);
+                for (int g2 = 0; g2 < (gpb + 1) / 2; g2++) {
+                    const int gi = g2 * 2 + (ln >> 5);
+                    const int gg = blk * gpb + gi;
+                    const bool valid = gi < gpb && gg < nbF;
+                    const float v = valid ? l.out[gi * 32 + (ln & 31)] : 0.0f;
+                    int qi, isum; float d16, s16;
+                    quant_block32(v, qi, d16, s16, isum);
+                    tq_store_block(xr, p.kq, valid ? gg : 0, ln & 31, qi, d16, s16, isum, tagL + SLOT_KQ, valid);
+                }
+            }
+            R6STAMP(10); R6RSTAMP(24);
+            // ---- G ----
+            fl_st(l.fl + FL_THIN, 1u);
+            gather_qvec<KSL>(pl, xr, p.kq, F, tagL + SLOT_KQ, g, opq(lane), l.kq);
+            gather_meet(pl, l.fl + FL_GKQ, g1);
+            fl_st(l.fl + FL_THIN, 0u);
+            R6STAMP(11); R6RSTAMP(25);
+        }
+    }
+};
+
+template <int FMT, int EPT, int NBD, int UF, int KSL>
+__global__ __launch_bounds__(512) void k6_ring(R6P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef R6<FMT, EPT, NBD, UF, KSL> K;
+    const int tid0 = threadIdx.x;
+    const int lane = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const R6Lds lo = r6_lds(K::D, p.F);
+    typename K::Lds l;
+    l.x = reinterpret_cast<float *>(smem + lo.x); l.q1 = smem + lo.q1; l.q2 = smem + lo.q2;
+    const size_t qd = (qvec_bytes(K::D) + 15) / 16 * 16;
+    l.act = smem + lo.u; l.actw = smem + lo.u + qd; l.yq = smem + lo.u + 2 * qd; l.kq = smem + lo.u;
+    l.tl = reinterpret_cast<float *>(smem + lo.tl); l.bc = reinterpret_cast<float *>(smem + lo.bc); l.red = reinterpret_cast<double *>(smem + lo.red);
+    l.out = reinterpret_cast<float *>(smem + lo.out); l.dl = smem + lo.dl; l.misc = reinterpret_cast<float *>(smem + lo.misc);
+    l.fl = reinterpret_cast<unsigned *>(smem + lo.fl); l.ring = smem + lo.ring;
+    if (tid0 < FL_WORDS) l.fl[tid0] = (tid0 >= FL_DONE + 2 && tid0 < FL_DONE + 2 + RG_NC) ? 0u : (tid0 >= FL_DONE && tid0 < FL_DONE + 8 ? 0xFFFFFFFFu : 0u);
+    __syncthreads();   // the only workgroup barrier of the launch
+    const unsigned base = p.ctl[0];
+#ifndef R6_ROLES
+#define R6_ROLES 7
+#endif
+    if (wave == 0) { if (R6_ROLES & 1) K::loader_main(p, l, lane); }
+    else if (wave == 1) { if (R6_ROLES & 2) K::comm_main(p, l, lane, base); }
+    else { if (R6_ROLES & 4) K::consumer_main(p, l, lane, wave, base); }
+    if (blockIdx.x == 0 && tid0 == 64) p.ctl[0] = base + (unsigned) p.n_layers * 8u;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+
+// One workgroup of 64 threads per record: copies the record's rows out of the planes (DevTensor layout) into the stream.
+struct PackMat { M6Off w1, dw1, rkvg[4], wo, fk, fr, fv; };
+__global__ void k_ring_pack(const unsigned char * __restrict__ arena, PackMat pm, RingShape s, const R6Cu * __restrict__ cus, unsigned char * __restrict__ stream, int layer, int max_rec) {
+    const int b = blockIdx.y, q = blockIdx.x, lane = threadIdx.x;
+    const RingCu cu = rg_cu(s, b);
+    int ph = 0, j = q;
+    while (ph < RG_NPHASE && j >= (int) cu.n[ph]) { j -= (int) cu.n[ph]; ph++; }
+    if (ph >= RG_NPHASE) return;
+    const RingRec rr = rg_rec(s, b, ph, j);
+    M6Off mo;
+    int64_t nrows;
+    switch (ph) {
+        case RG_W1:  mo = pm.w1; nrows = s.R5; break;
+        case RG_DW1: mo = pm.dw1; nrows = s.DR; break;
+        case RG_C:   mo = pm.rkvg[rr.mat]; nrows = s.D; break;
+        case RG_E:   mo = pm.wo; nrows = s.D; break;
+        case RG_FK:  mo = pm.fk; nrows = s.F; break;
+        case RG_FR:  mo = pm.fr; nrows = s.D; break;
+        default:     mo = pm.fv; nrows = s.D; break;
+    }
+    const int nbk = rr.K / 32, U = rg_steps(rr.K);
+    unsigned char * dst = stream + cus[b].base + (size_t) layer * cu.layer_bytes + cu.off[ph] + (size_t) j * cu.rec[ph];
+    const unsigned char * qs = arena + mo.qs; const unsigned char * qh = arena + mo.qh; const unsigned char * sc = arena + mo.sc;
+    for (int u = 0; u < U; u++) {
+        for (int r = 0; r < rr.R; r++) {
+            const int blkk = u * 64 + lane;
+            const int64_t row = rr.row0 + r;
+            const bool valid = blkk < nbk && row < nrows;
+            const int64_t gb = row * nbk + blkk;
+            for (int h = 0; h < s.qs / 16; h++) {
+                int4 v = make_int4(0, 0, 0, 0);
+                if (valid) v = *reinterpret_cast<const int4 *>(qs + gb * s.qs + h * 16);
+                *reinterpret_cast<int4 *>(dst + rg_code_off(s, rr.R, u, r, h) + lane * 16) = v;
+            }
+            if (s.scb == 4) *reinterpret_cast<uint32_t *>(dst + rg_sc_off(s, rr.R, U, u, r) + lane * 4) = valid ? reinterpret_cast<const uint32_t *>(sc)[gb] : 0u;
+            else *reinterpret_cast<uint16_t *>(dst + rg_sc_off(s, rr.R, U, u, r) + lane * 2) = valid ? reinterpret_cast<const uint16_t *>(sc)[gb] : (uint16_t) 0;
+            if (s.qhb) *reinterpret_cast<uint32_t *>(dst + rg_qh_off(s, rr.R, U, u, r) + lane * 4) = valid ? reinterpret_cast<const uint32_t *>(qh)[gb] : 0u;
+        }
+    }
+}
+
+__global__ void k_block_w2_ring(const float * __restrict__ src, float * __restrict__ dst, int D, int R) {   // (layout: see k_block_w2, mega_v6.hip)
+    const long long n = 5ll * R * D;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const int d = (int) (i % D); const long long fm = i / D; const int m = (int) (fm % R), f = (int) (fm / R);
+        const long long o = ((((long long) f * (D / 64) + d / 64) * (R / 4) + m / 4) * 64 + d % 64) * 4 + m % 4;
+        dst[o] = src[i];
+    }
+}
+
+struct RingV6 {
+    int kind = 2;                 // (first member: mega_v6.hip's entry points dispatch on it)
+    float * w2b = nullptr;
+    M6Layer * d_layers = nullptr;
+    R6Cu * d_cus = nullptr;
+    unsigned char * stream = nullptr;
+    void * xch = nullptr;
+    unsigned * ctl = nullptr;
+    unsigned * h_ctl = nullptr;
+    R6P proto{};
+    long long * trace = nullptr;
+    int variant = -1, n_blocks = 0;
+    size_t lds = 0;
+    uint64_t bytes = 0;
+};
+
+typedef void (*RingKernel)(R6P);
+struct RingVariant { int fmt, ept, nbd, uf, ksl; RingKernel fn; };
+static const RingVariant g_ring_variants[] = {
+#define RING_VARIANTS(FMT) \
+    {FMT, 8, 4, 7, 3, k6_ring<FMT, 8, 4, 7, 3>},   /* D 4096, F 14336 (448 blocks: 7 steps, 1344 units), decay rank 128 */ \
+    {FMT, 4, 2, 4, 2, k6_ring<FMT, 4, 2, 4, 2>}    /* D 2048, F 7168 (224 blocks: 4 steps, 672 units), decay rank 64 */
+    RING_VARIANTS(T_Q4_0), RING_VARIANTS(T_Q4_1), RING_VARIANTS(T_Q5_0), RING_VARIANTS(T_Q5_1), RING_VARIANTS(T_Q8_0),
+};
+
+static int ring_variant(const Model & m, int n_cu) {
+    if (m.arch_major != 6 || m.head_size != 64 || m.layer_end <= m.layer_begin) return -1;
+    const int64_t D = m.n_embed(), H = m.head_count;
+    const int fmt = (int) m.header.data_type;
+    const LayerW & L0 = m.layers[m.layer_begin];
+    if (!L0.ffn_key || !L0.att_time_decay_w1 || !L0.att_time_maa_w1) return -1;
+    const int64_t F = L0.ffn_key->ne[1], DR = L0.att_time_decay_w1->ne[1], R5 = L0.att_time_maa_w1->ne[1], R = R5 / 5;
+    const int64_t NB = RG_NBLK;
+    const int64_t gpb = (F / 32 + NB - 1) / NB;
+    if (n_cu != NB || H > NB || F % 32 != 0 || F % (gpb * 32) != 0 || DR > NB || DR % 32 != 0 || 5 * (D / 64) > NB + NB / 2 || !(R == 32 || R == 64) || gpb * 32 > 64) return -1;
+    for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
+        const LayerW & L = m.layers[i];
+        const DevTensor * mats[] = {L.att_receptance, L.att_key, L.att_value, L.att_gate, L.att_output, L.att_time_maa_w1,
+                                    L.att_time_decay_w1, L.att_time_decay_w2, L.ffn_key, L.ffn_value, L.ffn_receptance};
+        for (const DevTensor * t : mats) if (!t || t->type != fmt) return -1;
+        if (L.ffn_key->ne[1] != F || L.att_time_decay_w1->ne[1] != DR || L.att_time_maa_w1->ne[1] != R5) return -1;
+    }
+    for (size_t v = 0; v < sizeof(g_ring_variants) / sizeof(g_ring_variants[0]); v++) {
+        const RingVariant & rv = g_ring_variants[v];
+        const int64_t nbF = F / 32;
+        if (rv.fmt == fmt && D == rv.ept * 512 && DR == rv.nbd * 32 && (nbF + 63) / 64 == rv.uf && (3 * nbF + 7 * 64 - 1) / (7 * 64) == rv.ksl) return (int) v;
+    }
+    return -1;
+}
+
+void ring_v6_destroy(void * h) {
+    RingV6 * rg = (RingV6 *) h;
+    if (!rg) return;
+    if (rg->d_layers) (void) hipFree(rg->d_layers);
+    if (rg->d_cus) (void) hipFree(rg->d_cus);
+    if (rg->w2b) (void) hipFree(rg->w2b);
+    if (rg->stream) (void) hipFree(rg->stream);
+    if (rg->xch) (void) hipFree(rg->xch);
+    if (rg->ctl) (void) hipFree(rg->ctl);
+    if (rg->h_ctl) (void) hipHostFree(rg->h_ctl);
+    if (rg->trace) (void) hipFree(rg->trace);
+    delete rg;
+}
+
+static int env_int(const char * name, int dflt) { const char * e = getenv(name); return e && e[0] ? atoi(e) : dflt; }
+
+// Returns nullptr when the model / device does not qualify (the caller tries the register-prefetch kernel, then the seven launches).
+void * ring_v6_create(const Model & m) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m.device) != hipSuccess) return nullptr;
+    const int NB = prop.multiProcessorCount;
+    const int v = ring_variant(m, NB);
+    if (v < 0) return nullptr;
+    const LayerW & L0 = m.layers[m.layer_begin];
+    const int64_t D = m.n_embed(), F = L0.ffn_key->ne[1], DR = L0.att_time_decay_w1->ne[1], R = L0.att_time_maa_w1->ne[1] / 5;
+    const int fmt = (int) m.header.data_type;
+    RingShape sh; sh.D = (int) D; sh.F = (int) F; sh.R5 = (int) (5 * R); sh.DR = (int) DR;
+    sh.qs = fmt == T_Q8_0 ? 32 : 16; sh.scb = (fmt == T_Q4_1 || fmt == T_Q5_1) ? 4 : 2; sh.qhb = (fmt == T_Q5_0 || fmt == T_Q5_1) ? 4 : 0;
+    const int n_layers = (int) (m.layer_end - m.layer_begin);
+    RingV6 * rg = new RingV6();
+    rg->variant = v; rg->n_blocks = NB;
+    const R6Lds lo = r6_lds((int) D, (int) F);
+    const size_t lds_max = 160 * 1024;
+    size_t ring = (size_t) env_int("RWKV_MI_RING_KB", 1024) * 1024;
+    if (lo.fixed + 32 * 1024 > lds_max) { delete rg; return nullptr; }
+    if (ring > lds_max - lo.fixed) ring = lds_max - lo.fixed;
+    ring = ring / 1024 * 1024;
+    if (ring < 32 * 1024) ring = 32 * 1024;
+    rg->lds = lo.fixed + ring;
+    if (hipFuncSetAttribute((const void *) g_ring_variants[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rg->lds) != hipSuccess) { delete rg; return nullptr; }
+    // per-workgroup streams
+    std::vector<R6Cu> hc(RG_NBLK);
+    uint64_t total = 0;
+    int max_rec = 0;
+    for (int b = 0; b < RG_NBLK; b++) {
+        const RingCu cu = rg_cu(sh, b);
+        int nr = 0; for (int ph = 0; ph < RG_NPHASE; ph++) nr += (int) cu.n[ph];
+        max_rec = nr > max_rec ? nr : max_rec;
+        const uint64_t bytes = (uint64_t) cu.layer_bytes * n_layers;
+        if (bytes + (1u << 20) > 0xFFFFFFFFull) { delete rg; return nullptr; }   // stream positions are 32-bit
+        hc[b].base = total; hc[b].chunks = (unsigned) ((bytes + RG_CHUNK - 1) / RG_CHUNK); hc[b].layer_bytes = cu.layer_bytes;
+        total += (uint64_t) hc[b].chunks * RG_CHUNK;
+    }
+    const size_t w2_layer = (size_t) 5 * R * D;
+    bool ok = R % 4 == 0 && hipMalloc((void **) &rg->w2b, w2_layer * n_layers * sizeof(float)) == hipSuccess
+           && hipMalloc((void **) &rg->stream, total + RG_CHUNK) == hipSuccess
+           && hipMalloc((void **) &rg->d_cus, hc.size() * sizeof(R6Cu)) == hipSuccess
+           && hipMemcpy(rg->d_cus, hc.data(), hc.size() * sizeof(R6Cu), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { ring_v6_destroy(rg); return nullptr; }
+    std::vector<M6Layer> hl;
+    const unsigned char * abase = (const unsigned char *) m.arena;
+    bool in_arena = true;
+    auto off = [&](const void * ptr) -> long long {
+        const long long o = (const unsigned char *) ptr - abase;
+        if (!ptr || o < 0 || (uint64_t) o >= m.arena_bytes) in_arena = false;
+        return o;
+    };
+    auto f = [&](const DevTensor * t) { return off(t->data); };
+    auto pl3 = [&](const DevTensor * t) { M6Off o; o.qs = off(t->qs); o.qh = t->qh ? off(t->qh) : 0; o.sc = off(t->sc); return o; };
+    uint64_t bytes = 0;
+    for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
+        const LayerW & L = m.layers[i];
+        M6Layer d{};
+        d.ln1_w = f(L.ln1_w); d.ln1_b = f(L.ln1_b); d.maa_x = f(L.att_time_maa_x);
+        d.maa[0] = f(L.att_time_maa_w); d.maa[1] = f(L.att_time_maa_k); d.maa[2] = f(L.att_time_maa_v); d.maa[3] = f(L.att_time_maa_r); d.maa[4] = f(L.att_time_maa_g);
+        d.w2b = (long long) hl.size() * 5 * R * D; d.time_decay = f(L.att_time_decay); d.faaaa = f(L.att_time_faaaa);
+        d.lnx_w = f(L.att_ln_x_w); d.lnx_b = f(L.att_ln_x_b); d.ln2_w = f(L.ln2_w); d.ln2_b = f(L.ln2_b);
+        d.fmaa_k = f(L.ffn_time_maa_k); d.fmaa_r = f(L.ffn_time_maa_r);
+        d.w1 = pl3(L.att_time_maa_w1);
+        d.rkvg[0] = pl3(L.att_receptance); d.rkvg[1] = pl3(L.att_key); d.rkvg[2] = pl3(L.att_value); d.rkvg[3] = pl3(L.att_gate);
+        d.dw1 = pl3(L.att_time_decay_w1); d.dw2 = pl3(L.att_time_decay_w2); d.wo = pl3(L.att_output);
+        d.fk = pl3(L.ffn_key); d.fr = pl3(L.ffn_receptance); d.fv = pl3(L.ffn_value);
+        if (!in_arena) break;
+        hipLaunchKernelGGL(k_block_w2_ring, dim3(512), dim3(256), 0, 0, (const float *) L.att_time_maa_w2->data, rg->w2b + hl.size() * w2_layer, (int) D, (int) R);
+        PackMat pm; pm.w1 = d.w1; pm.dw1 = d.dw1; for (int q = 0; q < 4; q++) pm.rkvg[q] = d.rkvg[q]; pm.wo = d.wo; pm.fk = d.fk; pm.fr = d.fr; pm.fv = d.fv;
+        hipLaunchKernelGGL(k_ring_pack, dim3((unsigned) max_rec, RG_NBLK), dim3(64), 0, 0, abase, pm, sh, rg->d_cus, rg->stream, (int) hl.size(), max_rec);
+        hl.push_back(d);
+        const DevTensor * all[] = {L.ln1_w, L.ln1_b, L.att_time_maa_x, L.att_time_maa_w, L.att_time_maa_k, L.att_time_maa_v, L.att_time_maa_r, L.att_time_maa_g,
+                                   L.att_time_maa_w1, L.att_time_maa_w2, L.att_time_decay, L.att_time_faaaa, L.att_time_decay_w1, L.att_time_decay_w2,
+                                   L.att_receptance, L.att_key, L.att_value, L.att_gate, L.att_output, L.att_ln_x_w, L.att_ln_x_b, L.ln2_w, L.ln2_b,
+                                   L.ffn_time_maa_k, L.ffn_time_maa_r, L.ffn_key, L.ffn_value, L.ffn_receptance};
+        for (const DevTensor * t : all) if (t) bytes += t->nbytes;
+        bytes += 2 * (uint64_t) m.state_per_layer() * sizeof(float);
+    }
+    rg->bytes = bytes;
+    if (!in_arena) { ring_v6_destroy(rg); return nullptr; }
+    const int64_t nbD = D / 32, nbF = F / 32;
+    const int64_t PAD = 2048;   // polls read whole rounds of 7 x 64 lanes: keep every buffer readable past its end
+    auto up = [](int64_t v) { return (v + 63) / 64 * 64; };
+    const int64_t act_stride = up(3 * nbD), xunits = up(RG_NBLK * RG_NC);
+    const int64_t sizes[8] = {up(1280) + PAD, 5 * act_stride + PAD, 2 * D + PAD, 256 + PAD, act_stride + PAD, xunits + PAD, up(3 * nbF) + PAD, xunits + PAD};
+    int64_t units = 0;
+    for (int64_t z : sizes) units += z;
+    ok = hipMalloc((void **) &rg->d_layers, hl.size() * sizeof(M6Layer)) == hipSuccess
+      && hipMemcpy(rg->d_layers, hl.data(), hl.size() * sizeof(M6Layer), hipMemcpyHostToDevice) == hipSuccess
+      && hipMalloc(&rg->xch, (size_t) units * 16) == hipSuccess && hipMemset(rg->xch, 0, (size_t) units * 16) == hipSuccess
+      && hipMalloc((void **) &rg->ctl, 256) == hipSuccess
+      && hipHostMalloc((void **) &rg->h_ctl, 64, hipHostMallocDefault) == hipSuccess;
+    if (ok) { rg->h_ctl[0] = 8u; rg->h_ctl[1] = 0u; }
+    const unsigned init[2] = {8u, 0u};
+    ok = ok && hipMemcpy(rg->ctl, init, sizeof(init), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok || hipDeviceSynchronize() != hipSuccess) { ring_v6_destroy(rg); return nullptr; }
+    R6P & q = rg->proto;
+    q.layers = rg->d_layers; q.n_layers = (int) hl.size();
+    q.arena = abase; q.w2b = rg->w2b;
+    q.state_stride = m.state_per_layer();
+    q.xch = rg->xch; q.xch_bytes = (unsigned) (units * 16);
+    int u = 0;
+    int * slots[8] = {&q.tl, &q.act5, &q.rkvg, &q.dl, &q.yq, &q.xatt, &q.kq, &q.xffn};
+    for (int i = 0; i < 8; i++) { *slots[i] = u; u += (int) sizes[i]; }
+    q.act_stride = (int) act_stride;
+    q.ctl = rg->ctl;
+    q.stream = rg->stream; q.cus = rg->d_cus;
+    q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;
+    q.ring_bytes = (unsigned) ring;
+    auto snap = [](int w) { const int ok_[] = {0, 4, 8, 16, 24, 32, 40, 48, 56}; int best = 0; for (int x : ok_) if (x <= w) best = x; return best; };
+    q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 48));
+    q.thin = snap(env_int("RWKV_MI_RING_THIN", 16));
+    if (q.inflight < 4) q.inflight = 4;
+    if (q.thin < 4) q.thin = 4;
+    return rg;
+}
+
+bool ring_v6_trace(void * h, int layer, long long * out, bool fetch) {
+    RingV6 * rg = (RingV6 *) h;
+    const size_t n = (size_t) rg->n_blocks * 8 * 32;
+    if (!rg->trace) { if (hipMalloc((void **) &rg->trace, n * 8) != hipSuccess) return false; (void) hipMemset(rg->trace, 0, n * 8); }
+    rg->proto.trace = rg->trace; rg->proto.trace_layer = layer;
+    if (fetch) return hipMemcpy(out, rg->trace, n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    return true;
+}
+
+uint64_t ring_v6_bytes(void * h) { return ((RingV6 *) h)->bytes; }
+
+void ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf) {
+    RingV6 * rg = (RingV6 *) h;
+    R6P q = rg->proto;
+    q.x = x; q.sin = sin; q.sout = sout;
+    const RingKernel fn = g_ring_variants[rg->variant].fn;
+    if (pf && pf->on) {
+        if (pf->used * 2 + 2 > pf->events.size()) {
+            hipEvent_t a = nullptr, c = nullptr;
+            (void) hipEventCreate(&a); (void) hipEventCreate(&c);
+            pf->events.push_back(a); pf->events.push_back(c); pf->bytes.push_back(0);
+        }
+        pf->bytes[pf->used] = rg->bytes;
+        hipExtLaunchKernelGGL(fn, dim3((unsigned) rg->n_blocks), dim3(512), (uint32_t) rg->lds, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, q);
+        pf->used++;
+    } else {
+        hipLaunchKernelGGL(fn, dim3((unsigned) rg->n_blocks), dim3(512), rg->lds, st, q);
+    }
+}
+
+bool ring_v6_ctl_fetch(void * h, hipStream_t st) {
+    RingV6 * rg = (RingV6 *) h;
+    return hipMemcpyAsync(rg->h_ctl, rg->ctl, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess;
+}
+bool ring_v6_aborted_cached(void * h) { return ((RingV6 *) h)->h_ctl[1] != 0; }
+bool ring_v6_clear_abort(void * h, hipStream_t st) {
+    RingV6 * rg = (RingV6 *) h;
+    rg->h_ctl[1] = 0u;
+    return hipMemsetAsync(rg->ctl + 1, 0, sizeof(unsigned), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+}
+bool ring_v6_set_tag(void * h, unsigned base, hipStream_t st) {
+    RingV6 * rg = (RingV6 *) h;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    return hipMemcpy(rg->ctl, &base, sizeof(unsigned), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+}  // namespace rwkvmi

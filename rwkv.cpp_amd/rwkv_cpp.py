@@ -113,6 +113,8 @@ class RWKVSharedLibrary:
         L.rwkv_mi_set_graph_enabled.restype = None
         L.rwkv_mi_decode_path.argtypes = [c_ctx]
         L.rwkv_mi_decode_path.restype = ctypes.c_int
+        L.rwkv_mi_persist_kind.argtypes = [c_ctx]
+        L.rwkv_mi_persist_kind.restype = ctypes.c_int
         L.rwkv_mi_decode_healthy.argtypes = [c_ctx]
         L.rwkv_mi_decode_healthy.restype = ctypes.c_bool
         L.rwkv_mi_sample.argtypes = [c_ctx, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, P_UINT32]
@@ -352,6 +354,10 @@ class RWKVModel:
     def decode_path(self) -> int:
         """0 = per-op kernels, 1 = fused RWKV-6 layer, 2 = persistent whole-stage kernel."""
         return int(self._library.library.rwkv_mi_decode_path(self._ctx.ptr))
+
+    def persist_kind(self) -> int:
+        """Persistent kernel behind decode path 2: 2 = LDS-DMA weight ring, 1 = register prefetch, 0 = none."""
+        return int(self._library.library.rwkv_mi_persist_kind(self._ctx.ptr))
 
     def healthy(self) -> bool:
         return bool(self._library.library.rwkv_mi_decode_healthy(self._ctx.ptr))

@@ -13,18 +13,27 @@ pytestmark = pytest.mark.gpu
 # contexts normally time both single-token paths at creation and keep the faster one; these tests are about the persistent kernel
 os.environ["RWKV_MI_NO_AUTOTUNE"] = "1"
 
+
+@pytest.fixture(params=["ring", "regs"], autouse=True)
+def persist(request):
+    """Every test runs on both persistent kernels: the LDS-DMA weight ring (ring_v6.hip, the default) and the register prefetch (mega_v6.hip)."""
+    os.environ["RWKV_MI_PERSIST"] = request.param
+    yield {"ring": 2, "regs": 1}[request.param]
+    del os.environ["RWKV_MI_PERSIST"]
+
 TOKENS = [1, 2, 3, 400, 5, 77, 300, 9, 11, 12]
 
 
 @pytest.mark.parametrize("name,fmt", [("mega-v6-2048", "Q4_0"), ("mega-v6-4096", "Q4_0"), ("mega-v6-2048", "Q4_1"), ("mega-v6-2048", "Q5_0"),
                                       ("mega-v6-4096", "Q5_1"), ("mega-v6-4096", "Q8_0")])
-def test_mega_matches_oracle(tmp_path, name, fmt):
+def test_mega_matches_oracle(tmp_path, name, fmt, persist):
     library()
     p = str(tmp_path / "m.bin")
     synth.write_model(p, synth.CONFIGS[name], fmt, seed=11)
     om = O.OracleModel(p)
     m = model(p)
     assert m.decode_path() == 2, "persistent kernel not selected for a geometry it is built for"
+    assert m.persist_kind() == persist
     ost, st = om.init_state(), None
     for i, t in enumerate(TOKENS):
         ol, ost = om.eval(t, ost)
@@ -97,7 +106,7 @@ def test_mega_stages_reproduce_full_model(tmp_path):
     full.free()
 
 
-def test_mega_health_and_trace(tmp_path):
+def test_mega_health_and_trace(tmp_path, persist):
     """rwkv_mi_decode_healthy stays true over ordinary use; rwkv_mi_trace_phases returns monotonic stamps per wave."""
     import ctypes
     lib = library()
@@ -114,8 +123,13 @@ def test_mega_health_and_trace(tmp_path):
     out = np.zeros(256 * 8 * 32, dtype=np.int64)
     assert L.rwkv_mi_trace_phases(m._ctx.ptr, 5, 1, 2, out.ctypes.data)
     t = out.reshape(256, 8, 32)
-    assert (np.diff(t[:, 1:, :17], axis=2) >= 0).all() and (t[:, 1:, 16] > t[:, 1:, 0]).all()   # worker shader-clock stamps
-    assert (np.diff(t[:, 0, :13], axis=1) >= 0).all()                                              # comm wave
+    if persist == 1:
+        assert (np.diff(t[:, 1:, :17], axis=2) >= 0).all() and (t[:, 1:, 16] > t[:, 1:, 0]).all()   # worker shader-clock stamps
+        assert (np.diff(t[:, 0, :13], axis=1) >= 0).all()                                              # comm wave
+    else:
+        assert (np.diff(t[:, 2:, :14], axis=2) >= 0).all() and (t[:, 2:, 13] > t[:, 2:, 0]).all()   # consumer waves
+        assert (np.diff(t[:, 1, :12], axis=1) >= 0).all()                                              # comm wave
+        assert (t[:, 0, 1] > t[:, 0, 0]).all()                                                         # loader: start / end
     assert L.rwkv_mi_decode_healthy(m._ctx.ptr)
     m.free()
 

@@ -60,6 +60,29 @@ def test_stage_chain_equals_single_context(tmp_path, name, fmt, devices):
     om.free()
 
 
+@pytest.mark.parametrize("name,fmt,devices", [("test-v7", "Q8_0", "0,0,0"), ("test-v6", "Q4_0", "0,0,0")])
+def test_many_passes_through_a_three_stage_chain(tmp_path, name, fmt, devices):
+    """A middle stage's x is input, running residual stream and the source of its outgoing copy: the stage before it may overwrite it
+    for the next pass only behind that copy (round 2 recorded the reuse event behind the layers instead: a rare mismatch of
+    eval_sequence_in_chunks, reproduced once in 30 runs of the test above). Many short passes, repeated."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS[name]
+    src = str(tmp_path / "f.bin")
+    synth.write_model(src, spec, "FP32", seed=31)
+    O.quantize_file(src, p, fmt)
+    om = O.OracleModel(p)
+    pm = _pipeline_model(p, devices)
+    seq = [int((1103515245 * i + 12345) % spec.n_vocab) for i in range(96)]
+    ol, ost = om.eval_sequence(seq, om.init_state())
+    for rep in range(25):
+        for chunk in (3, 7, 32):
+            lg, st = pm.eval_sequence_in_chunks(seq, None, chunk_size=chunk)
+            assert np.array_equal(lg, ol) and np.array_equal(st, ost), (name, rep, chunk)
+    pm.free()
+    om.free()
+
+
 def test_bad_device_list_is_an_argument_error(tmp_path):
     lib = library()
     p = str(tmp_path / "m.bin")

@@ -16,7 +16,7 @@ else:
     O.quantize_file(p + '.f32', p, fmt)                 # low-rank stay F32
 om = O.OracleModel(p)
 m = model(p)
-print(name, fmt, 'path', m.decode_path(), flush=True)
+print(name, fmt, 'path', m.decode_path(), 'persist', m.persist_kind(), flush=True)
 ost, st, ok = om.init_state(), None, True
 for i, t in enumerate([1, 2, 3, 400 % spec.n_vocab, 5, 77, 300 % spec.n_vocab, 9]):
     ol, ost = om.eval(t, ost)

@@ -1,0 +1,48 @@
+"""Phase stamps of the persistent RWKV-6 decode kernel on the LDS-DMA ring (ring_v6.hip), one layer of one token:
+python tools/trace_ring.py [config] [layer]. Prints cycles per phase of the consumer waves and of the comm wave, and the loader's stalls."""
+import sys, os, ctypes, numpy as np
+sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'tests'))
+os.environ.setdefault('RWKV_MI_PERSIST', 'ring')
+os.environ['RWKV_MI_NO_AUTOTUNE'] = '1'
+import torch; torch.cuda.init()
+from gpu_lib import library, model, synth
+lib = library()
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'rwkv6-7b'
+layer = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+p = '/tmp/synthetic-%s-Q4_0-seed42.bin' % cfg
+if not os.path.exists(p): synth.write_model(p, synth.CONFIGS[cfg], 'Q4_0', seed=42)
+m = model(p); m.state_load(None)
+assert m.persist_kind() == 2, 'ring kernel not active'
+L = lib.library
+L.rwkv_mi_trace_phases.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]; L.rwkv_mi_trace_phases.restype = ctypes.c_bool
+NB = 256
+out = np.zeros(NB * 8 * 32, dtype=np.int64)
+assert L.rwkv_mi_trace_phases(m._ctx.ptr, 5, layer, 3, out.ctypes.data)
+t = out.reshape(NB, 8, 32).astype(float)
+cons = t[:, 2:, :14]
+names = ['A.gather x', 'A.prologue', 'A.W1 rows', 'C.gather act', 'C.rows', 'E.gather yq', 'E.rows', 'F.gather x', 'F.prologue', 'F.key rows', 'F.rec rows', 'G.gather kq', 'G.rows']
+d = np.diff(cons, axis=2)
+print('CONSUMER waves: mean / min / max cycles (mean us at 2.4 GHz)')
+for i, n in enumerate(names): print('%-14s %8.0f %8.0f %8.0f   %.2f' % (n, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max(), d[:, :, i].mean() / 2400))
+print('consumer layer total cycles', (cons[:, :, 13] - cons[:, :, 0]).mean())
+comm = t[:, 1, :12]
+cn = ['A.gather x', 'A.W2+pro wait', 'B.poll tl', 'B.mix', 'C.gather act', 'D.head', 'E.gather yq', 'F.gather x', 'F.keys wait', 'F.quant k', 'G.gather kq']
+dc = np.diff(comm, axis=1)
+print('COMM wave: mean / min / max cycles')
+for i, n in enumerate(cn): print('%-14s %8.0f %8.0f %8.0f   %.2f' % (n, dc[:, i].mean(), dc[:, i].min(), dc[:, i].max(), dc[:, i].mean() / 2400))
+print('comm D.head on head workgroups only:', dc[:64, 5].mean(), ' others:', dc[64:, 5].mean())
+ld = t[:, 0, :3]
+print('LOADER: active cycles mean %.0f (whole token), ring-full stalls mean %.0f max %.0f' % ((ld[:, 1] - ld[:, 0]).mean(), ld[:, 2].mean(), ld[:, 2].max()))
+R = t
+rt = lambda w, k: R[:, w, k]
+print('hand-over (100 MHz real time): x staged (comm 17) spread %.2f us' % ((rt(1, 17).max() - rt(1, 17).min()) / 100))
+for nm, a, b in (('tl polled -> act5 stored', 18, 19), ('act5 stored(max) -> act gathered', 19, 20), ('act gathered -> yq stored', 20, 21), ('yq stored(max) -> yq gathered', 21, 22),
+                 ('yq gathered -> x_att gathered', 22, 23), ('x_att gathered -> kq stored', 23, 24), ('kq stored(max) -> kq gathered', 24, 25)):
+    if 'max' in nm: v = (rt(1, b) - rt(1, a).max()) / 100
+    else: v = (rt(1, b) - rt(1, a)) / 100
+    print('%-36s mean %.2f us  min %.2f  max %.2f' % (nm, v.mean(), v.min(), v.max()))
+end = R[:, 2:, 14].max(); start = rt(1, 17).min()
+print('layer wall: (x_ffn stored, max over consumers) - (x staged, min over comm): %.2f us' % ((end - start) / 100))
+by = (R[:, 2:, 14].max(axis=1) - R[:, 2:, 14].min()) / 100
+print('x_ffn stored lateness by XCD:', ' '.join('%.2f' % by[x::8].mean() for x in range(8)), ' by consumer:', ' '.join('%.2f' % ((R[:, 2 + c, 14] - R[:, 2:, 14].min()) / 100).mean() for c in range(6)))
+sys.stdout.flush(); os._exit(0)
