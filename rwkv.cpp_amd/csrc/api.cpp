@@ -64,9 +64,10 @@ static bool fetch_outputs(rwkv_context * ctx, float * state_out, float * logits_
     if (aborted) *aborted = false;
     if (state_out && !state_to_host(ctx, state_out)) return false;
     if (logits_out) HIP_CTX_OK(ctx, hipMemcpyAsync(logits_out, ctx->d_logits, (size_t) ctx->model->n_vocab() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->mega) (void) mega_v6_ctl_fetch(ctx->mega, ctx->stream);
+    // (a control-word copy that could not even be enqueued leaves a stale "not aborted" mirror: treated as an abort)
+    const bool ctl_ok = !ctx->mega || mega_v6_ctl_fetch(ctx->mega, ctx->stream);
     HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->mega && mega_v6_aborted_cached(ctx->mega)) {
+    if (ctx->mega && (!ctl_ok || mega_v6_aborted_cached(ctx->mega))) {
         recover_from_abort(ctx);
         if (aborted) { *aborted = true; return true; }
         RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, false, "%s", k_abort_msg);
@@ -412,8 +413,15 @@ RWKV_API bool rwkv_mi_profile_prefill(struct rwkv_context * ctx, const uint32_t 
     return true;
 }
 
-RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx) { return ctx->model->bytes_per_token; }
-RWKV_API uint64_t rwkv_mi_weight_bytes(const struct rwkv_context * ctx) { return ctx->model->weight_bytes; }
+// (a RWKV_MI_DEVICES front context: the sum over its stages)
+RWKV_API uint64_t rwkv_mi_bytes_per_token(const struct rwkv_context * ctx) {
+    if (ctx->stages.empty()) return ctx->model->bytes_per_token;
+    uint64_t t = 0; for (const rwkv_context * s : ctx->stages) t += s->model->bytes_per_token; return t;
+}
+RWKV_API uint64_t rwkv_mi_weight_bytes(const struct rwkv_context * ctx) {
+    if (ctx->stages.empty()) return ctx->model->weight_bytes;
+    uint64_t t = 0; for (const rwkv_context * s : ctx->stages) t += s->model->weight_bytes; return t;
+}
 
 // Arithmetic of one sequence pass over T tokens: 2 * T * (elements of every 2-D layer matrix) + 2 * V * D
 // (the head runs on the last token only). Embedding, vectors and the elementwise v7 r_k table are not matrices of the pass.
@@ -461,6 +469,7 @@ RWKV_API struct rwkv_context * rwkv_mi_init_stage(const char * file_path, uint32
 
 RWKV_API bool rwkv_mi_set_stream(struct rwkv_context * ctx, void * hip_stream) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
     for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (ctx->graph_exec[a][b]) { (void) hipGraphExecDestroy(ctx->graph_exec[a][b]); ctx->graph_exec[a][b] = nullptr; }
@@ -484,6 +493,7 @@ RWKV_API void rwkv_mi_stage_range(const struct rwkv_context * ctx, uint32_t * la
 //   last stage  : ln_out + head into the context's logits, argmax into d_next_token (device, may be NULL)
 RWKV_API bool rwkv_mi_stage_step(struct rwkv_context * ctx, const uint32_t * d_token, const float * x_in, float * x_out, uint32_t * d_next_token) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     Model & m = *ctx->model;
     HIP_CTX_OK(ctx, hipSetDevice(m.device));
     const size_t D = (size_t) m.n_embed();
@@ -514,13 +524,14 @@ RWKV_API bool rwkv_mi_stage_step(struct rwkv_context * ctx, const uint32_t * d_t
 // copies the context's logits (of the last step that produced any) to host memory, synchronising the context's stream
 RWKV_API bool rwkv_mi_logits_store(struct rwkv_context * ctx, float * logits_out) {
     ctx->last_error = RWKV_ERROR_NONE;
+    RW_NO_PIPELINE(ctx, false);
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, logits_out != nullptr, "logits_out is NULL");
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     return fetch_outputs(ctx, nullptr, logits_out);
 }
 
 // device pointer of the context's logits buffer (valid after a last-stage step / any eval that produced logits)
-RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx) { return ctx->d_logits; }
+RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx) { return ctx->stages.empty() ? ctx->d_logits : ctx->stages.back()->d_logits; }
 
 RWKV_API bool rwkv_mi_trace_phases(struct rwkv_context * ctx, uint32_t token, int layer, int n, long long * out) {
     if (!ctx->mega) return false;

@@ -148,6 +148,7 @@ rwkv_context * create_context(Model * m, uint32_t n_threads) {
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return fail(e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail(e);
     if ((e = hipEventCreateWithFlags(&ctx->mega_done, hipEventDisableTiming)) != hipSuccess) return fail(e);
+    prefill_prepare_current_device();   // dynamic-LDS limits of the sequence-mode kernels: per device
     const char * g = getenv("RWKV_MI_NO_GRAPH");
     ctx->use_graph = !(g && g[0] == '1');
     const char * nf = getenv("RWKV_MI_NO_FUSED");
@@ -280,6 +281,8 @@ struct Runner {
     int64_t T, D, H, S;
     rwkv_context::Buf & b;
 
+    bool failed = false;   // a launch of the pass could not be made (allocation failure): its outputs are not valid
+
     // inputs quantised ahead of their products, several per launch (sequence mode): source pointer -> tile image
     struct Pre { const float * x = nullptr; int wtype = -1; int64_t K = 0; TileAct ta; } pre[5];
     void prequant(int n, const float * const * xs, int64_t K, int wtype) {
@@ -334,7 +337,9 @@ struct Runner {
                 pf.bytes[pf.used] = 2ull * (uint64_t) T * (uint64_t) N * (uint64_t) K;
                 (void) hipEventRecord(pf.events[pf.used * 2], st);
             }
-            if (!launch_mmq_mfma(*W, ta, T, y, N, epi, st, &b.ws)) ctx->last_error |= RWKV_ERROR_GRAPH | RWKV_ERROR_ALLOC;
+            // (the tile-major weight image or the walk table could not be allocated: the product was NOT computed -- the pass fails,
+            //  forward() reports it; the f32 activations may not even exist here when the mix wrote tile images only)
+            if (!launch_mmq_mfma(*W, ta, T, y, N, epi, st, &b.ws)) { ctx->last_error |= RWKV_ERROR_GRAPH | RWKV_ERROR_ALLOC; failed = true; }
             if (pf.on) { (void) hipEventRecord(pf.events[pf.used * 2 + 1], st); pf.used++; }
         } else if (dtype_quantized(W->type)) {
             launch_quantize_act(x, T, K, b.qa, st);
@@ -547,6 +552,7 @@ bool forward(rwkv_context * ctx, int64_t T, bool want_logits) {
     if (chained) mega_chain_end(ctx);
     ctx->cur ^= 1;
     HIP_CTX_OK(ctx, hipGetLastError());
+    RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH | RWKV_ERROR_ALLOC, false, !r.failed, "a sequence-mode product could not be launched (out of device memory for the tile-major weight image?)");
     return true;
 }
 

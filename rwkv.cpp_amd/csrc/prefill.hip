@@ -845,13 +845,7 @@ bool launch_mix_seq_q(const MixArgs & a, int64_t T, int64_t D, hipStream_t st, c
 bool launch_wkv6_seq(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
                      const float * state_in, float * state_out, float * out, int64_t T, int64_t H, hipStream_t st) {
     const size_t lds = (size_t) (3 * 131 * 64 + 2 * 4 * 131) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) k_wkv6_seq<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        (void) hipFuncSetAttribute((const void *) k_wkv6_seq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        (void) hipFuncSetAttribute((const void *) k_wkv6_seq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        attr_set = true;
-    }
+    prefill_prepare_current_device();   // (dynamic-LDS limit: per device, set once per device)
     const dim3 grid((unsigned) (H * 8));
     switch (w_mode) {
         case 0: hipLaunchKernelGGL((k_wkv6_seq<0>), grid, dim3(256), lds, st, r, k, v, u, u_per_chan, w, state_in, state_out, out, (int) T, (int) H); break;
@@ -1013,8 +1007,7 @@ static bool launch_mmq_mfma_t(int n, const DevTensor * const * Ws, const TileAct
     A.order = wt->order; for (int a = 0; a < 9; a++) A.a_start[a] = wt->a_start[a];
     A.part = ws ? ws->part : nullptr; A.counters = ws ? ws->counters : nullptr;
     const size_t lds = (size_t) M::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) { (void) hipFuncSetAttribute((const void *) k_mmq_mfma<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr_set = true; }
+    prefill_prepare_current_device();   // (dynamic-LDS limit: per device, set once per device)
     const dim3 grid((unsigned) (RP < 8 ? RP * C : ((RP + 7) / 8) * 8 * C), (unsigned) n, (unsigned) split);
     hipLaunchKernelGGL((k_mmq_mfma<FMT>), grid, dim3(M::NT), lds, st, A);
     const dim3 cgrid((unsigned) (RP * C), (unsigned) n, 8);
@@ -1024,10 +1017,16 @@ static bool launch_mmq_mfma_t(int n, const DevTensor * const * Ws, const TileAct
     return true;
 }
 
-// hipFuncSetAttribute acts on the CURRENT device, and the launchers above raise the dynamic-LDS limit once per process (on the device
-// of the first launch). A process that runs stages on several devices (RWKV_MI_DEVICES, pipeline.cpp) calls this once per stage
-// device at start-up.
+// hipFuncSetAttribute acts on the CURRENT device: the dynamic-LDS limits of the sequence-mode kernels are raised once per DEVICE (a bitmap
+// under g_pf_mu), from create_context (engine.hip) and again, as a cheap check, from the launchers -- a process may hold contexts on
+// several devices (RWKV_MI_DEVICES, rwkv_mi_init_stage after hipSetDevice, clones on other threads).
 void prefill_prepare_current_device() {
+    static uint64_t ready[4] = {0, 0, 0, 0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return;
+    std::lock_guard<std::mutex> lk(g_pf_mu);
+    if (ready[dev >> 6] & (1ull << (dev & 63))) return;
+    ready[dev >> 6] |= 1ull << (dev & 63);
     (void) hipFuncSetAttribute((const void *) k_mmq_mfma<T_Q4_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MF<T_Q4_0>::LDS_BYTES);
     (void) hipFuncSetAttribute((const void *) k_mmq_mfma<T_Q4_1>, hipFuncAttributeMaxDynamicSharedMemorySize, MF<T_Q4_1>::LDS_BYTES);
     (void) hipFuncSetAttribute((const void *) k_mmq_mfma<T_Q5_0>, hipFuncAttributeMaxDynamicSharedMemorySize, MF<T_Q5_0>::LDS_BYTES);

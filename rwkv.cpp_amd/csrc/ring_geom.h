@@ -79,9 +79,10 @@ RG_HD RingCu rg_cu(const RingShape & s, int b) {
     c.n[RG_G] = (uint32_t) rg_rows_e(s);
     const uint32_t d1 = rg_rec_bytes(s, 1, s.D), d2 = rg_rec_bytes(s, 2, s.D), f1 = rg_rec_bytes(s, 1, s.F);
     c.rec[RG_W1] = d1; c.rec[RG_DW1] = d1; c.rec[RG_C] = d2; c.rec[RG_E] = d1; c.rec[RG_FK] = d2; c.rec[RG_FR] = d1; c.rec[RG_G] = f1;
-    // E, FR and G share one mapping (a wave keeps the residual and the receptance of its rows in registers across the three phases);
-    // the decay row goes to the wave with the fewest r/k/v/g sets, the extra key sets to the waves with the fewest receptance rows
-    c.rot[RG_W1] = 0; c.rot[RG_DW1] = RG_NC - 1; c.rot[RG_C] = 0; c.rot[RG_E] = 0; c.rot[RG_FK] = 4; c.rot[RG_FR] = 0; c.rot[RG_G] = 0;
+    // E, FR and G share one mapping (a wave keeps the residual and the receptance of its rows in registers across the three phases).
+    // The two-row sets of C and FK do not divide by six: the extra sets go to consumers 2 and 3 (waves 4 and 5, which share their SIMDs
+    // with the loader and the comm wave, not with another consumer); the decay row goes to a wave with the fewest r/k/v/g sets
+    c.rot[RG_W1] = 0; c.rot[RG_DW1] = RG_NC - 1; c.rot[RG_C] = 2; c.rot[RG_E] = 0; c.rot[RG_FK] = 2; c.rot[RG_FR] = 0; c.rot[RG_G] = 0;
     uint32_t p = 0;
     for (int ph = 0; ph < RG_NPHASE; ph++) { c.off[ph] = p; p += c.n[ph] * c.rec[ph]; }
     c.layer_bytes = p;

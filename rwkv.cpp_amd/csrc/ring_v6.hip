@@ -44,12 +44,16 @@ struct R6P {
     int F, DR, R, H;
     unsigned ring_bytes;                               // LDS ring (multiple of 1 KiB)
     int inflight, thin;                                // loader: DMA instructions in flight (normal / while the workgroup gathers)
+    int nap;                                           // extra 64-cycle sleeps between two looks at a gather's sentinel unit
+    int burst;                                         // loader: fills issued per round (between two looks at the consumers' positions)
+    int dbg;                                           // timing experiments (results are WRONG): 1 skip the row arithmetic, 2 skip the ring reads, 4 do not wait for the loader
     long long * trace; int trace_layer;
 };
 
 // monotonic words in LDS
-enum { FL_LANDED = 0, FL_THIN = 1, FL_DONE = 4 /* [8], 16-byte aligned */, FL_GX = 12, FL_GACT = 13, FL_GYQ = 14, FL_GKQ = 15,
-       FL_RED1 = 16, FL_RED2 = 17, FL_PRO = 18, FL_KEYS = 19, FL_WORDS = 32 };
+enum { FL_LANDED = 0, FL_SWB = 1, FL_SWE = 2 /* wide sweeps begun / ended (the loader keeps fewer fills in flight while they differ) */, FL_DONE = 4 /* [8], 16-byte aligned */, FL_GX = 12, FL_GACT = 13, FL_GYQ = 14, FL_GKQ = 15,
+       FL_RED1 = 16, FL_RED2 = 17, FL_PRO = 18, FL_KEYS = 19,
+       FL_HX = 20, FL_HACT = 21, FL_HYQ = 22, FL_HKQ = 23, FL_HTL = 24 /* "some wave saw its sentinel turn" per gather kind */, FL_WORDS = 32 };
 
 struct R6Lds { size_t x, q1, q2, u, tl, bc, red, out, dl, misc, fl, ring, fixed; };
 __host__ __device__ inline R6Lds r6_lds(int D, int F) {
@@ -100,60 +104,89 @@ __device__ __forceinline__ unsigned ring_at(unsigned off, unsigned rel, unsigned
 
 template <int FMT, int R, int U>
 __device__ __forceinline__ void rec_load(RawRec<FMT, R, U> & w, const unsigned char * ring, unsigned RB, unsigned off, int lane) {
-    constexpr unsigned QS = QF<FMT>::QS, SCB = QF<FMT>::HM ? 4 : 2;
-    constexpr unsigned SC0 = U * R * 64 * QS, QH0 = SC0 + U * R * 64 * SCB;
+    constexpr unsigned QS = QF<FMT>::QS, SCB = QF<FMT>::HM ? 4 : 2, QHB = QF<FMT>::QH ? 4 : 0;
+    constexpr unsigned SC0 = U * R * 64 * QS, QH0 = SC0 + U * R * 64 * SCB, BYTES = U * R * 64 * (QS + SCB + QHB);
+    if (off + BYTES <= RB) {
+        // the record does not wrap (the usual case): one base per access width, every read at an immediate offset
+        const unsigned char * b16 = ring + off + (unsigned) lane * 16u;
+        const unsigned char * bsc = ring + off + SC0 + (unsigned) lane * SCB;
+        const unsigned char * bqh = ring + off + QH0 + (unsigned) lane * 4u;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
+        for (int u = 0; u < U; u++) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            RawBlk<FMT> & o = w.raw[u][r];
-            const unsigned c0 = (unsigned) ((u * R + r) * (QS / 16)) * 1024u + (unsigned) lane * 16u;
-            o.q[0] = *reinterpret_cast<const int4 *>(ring + ring_at(off, c0, RB));
-            if constexpr (QS == 32) o.q[1] = *reinterpret_cast<const int4 *>(ring + ring_at(off, c0 + 1024u, RB));
-            if constexpr (QF<FMT>::HM) o.sc = *reinterpret_cast<const uint32_t *>(ring + ring_at(off, SC0 + (unsigned) (u * R + r) * 256u + (unsigned) lane * 4u, RB));
-            else o.sc = (unsigned) *reinterpret_cast<const uint16_t *>(ring + ring_at(off, SC0 + (unsigned) (u * R + r) * 128u + (unsigned) lane * 2u, RB));
-            if constexpr (QF<FMT>::QH) o.qh = *reinterpret_cast<const uint32_t *>(ring + ring_at(off, QH0 + (unsigned) (u * R + r) * 256u + (unsigned) lane * 4u, RB));
+            for (int r = 0; r < R; r++) {
+                RawBlk<FMT> & o = w.raw[u][r];
+                const unsigned c0 = (unsigned) ((u * R + r) * (QS / 16)) * 1024u;
+                o.q[0] = *reinterpret_cast<const int4 *>(b16 + c0);
+                if constexpr (QS == 32) o.q[1] = *reinterpret_cast<const int4 *>(b16 + c0 + 1024u);
+                if constexpr (QF<FMT>::HM) o.sc = *reinterpret_cast<const uint32_t *>(bsc + (unsigned) (u * R + r) * 256u);
+                else o.sc = (unsigned) *reinterpret_cast<const uint16_t *>(bsc + (unsigned) (u * R + r) * 128u);
+                if constexpr (QF<FMT>::QH) o.qh = *reinterpret_cast<const uint32_t *>(bqh + (unsigned) (u * R + r) * 256u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                RawBlk<FMT> & o = w.raw[u][r];
+                const unsigned c0 = (unsigned) ((u * R + r) * (QS / 16)) * 1024u + (unsigned) lane * 16u;
+                o.q[0] = *reinterpret_cast<const int4 *>(ring + ring_at(off, c0, RB));
+                if constexpr (QS == 32) o.q[1] = *reinterpret_cast<const int4 *>(ring + ring_at(off, c0 + 1024u, RB));
+                if constexpr (QF<FMT>::HM) o.sc = *reinterpret_cast<const uint32_t *>(ring + ring_at(off, SC0 + (unsigned) (u * R + r) * 256u + (unsigned) lane * 4u, RB));
+                else o.sc = (unsigned) *reinterpret_cast<const uint16_t *>(ring + ring_at(off, SC0 + (unsigned) (u * R + r) * 128u + (unsigned) lane * 2u, RB));
+                if constexpr (QF<FMT>::QH) o.qh = *reinterpret_cast<const uint32_t *>(ring + ring_at(off, QH0 + (unsigned) (u * R + r) * 256u + (unsigned) lane * 4u, RB));
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// the record's rows against an activation image in LDS: lane l accumulates blocks l, l + 64, ... in increasing order, then the butterfly
+// The activation blocks a lane needs are the same for every record of a phase (block 64 u + lane of the image): read once per phase.
+template <int U> struct ActRegs { int4 alo[U], ahi[U]; float dx[U], sx[U]; int asum[U]; };
+template <int U>
+__device__ __forceinline__ void act_load(ActRegs<U> & ar, const QVec & a, int nbk, int lane) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int bb = u * WAVE + lane;
+        const int b = bb < nbk ? bb : nbk - 1;
+        ar.alo[u] = *reinterpret_cast<const int4 *>(a.q + b * 16);
+        ar.ahi[u] = *reinterpret_cast<const int4 *>(a.q + nbk * 16 + b * 16);
+        ar.dx[u] = a.d[b]; ar.sx[u] = a.s[b]; ar.asum[u] = a.isum[b];
+    }
+}
+
+// the record's rows against the activation registers: lane l accumulates blocks l, l + 64, ... in increasing order (per-lane partials)
 template <int FMT, int R, int U>
-__device__ __forceinline__ void rec_dot(const RawRec<FMT, R, U> & w, const QVec & a, int nbk, int lane, float (&res)[R]) {
-    float acc[R];
+__device__ __forceinline__ void rec_acc(const RawRec<FMT, R, U> & w, const ActRegs<U> & ar, int nbk, int lane, float * acc) {
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
-    // (steps in groups of four: the activation reads of a group are in flight together, not those of a whole 7-step row)
 #pragma unroll
-    for (int u0 = 0; u0 < U; u0 += 4) {
-        int4 alo[4], ahi[4]; float dx[4], sx[4]; int asum[4]; bool valid[4];
+    for (int u = 0; u < U; u++) {
+        const bool valid = u * WAVE + lane < nbk;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (u0 + k < U) {
-                const int bb = (u0 + k) * WAVE + lane;
-                valid[k] = bb < nbk;
-                const int b = valid[k] ? bb : nbk - 1;
-                alo[k] = *reinterpret_cast<const int4 *>(a.q + b * 16);
-                ahi[k] = *reinterpret_cast<const int4 *>(a.q + nbk * 16 + b * 16);
-                dx[k] = a.d[b]; sx[k] = a.s[b]; asum[k] = a.isum[b];
-            }
+        for (int r = 0; r < R; r++) {
+            WBlk<FMT> wb;
+            unpack_raw<FMT>(wb, w.raw[u][r]);
+            acc[r] = blk_fma<FMT>(wb, ar.alo[u], ar.ahi[u], ar.dx[u], ar.sx[u], ar.asum[u], acc[r], valid);
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (u0 + k < U) {
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    WBlk<FMT> wb;
-                    unpack_raw<FMT>(wb, w.raw[u0 + k][r]);
-                    acc[r] = blk_fma<FMT>(wb, alo[k], ahi[k], dx[k], sx[k], asum[k], acc[r], valid[k]);
-                }
-            }
-        }
-        if (u0 + 4 < U) __builtin_amdgcn_sched_barrier(0);
     }
+}
+// N xor-butterflies (the halving tree of wave_sum_f) written level by level, so that the N dependent chains interleave
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
-    for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
+    for (int i = 0; i < N; i++) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false); v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+#pragma unroll
+    for (int i = 0; i < N; i++) { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false); v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + __int_as_float(lane_xor8_i(__float_as_int(v[i])));
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + __int_as_float(lane_xor4_i(__float_as_int(v[i])));
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + __int_as_float(lane_xor2_i(__float_as_int(v[i])));
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = v[i] + __int_as_float(lane_xor1_i(__float_as_int(v[i])));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -256,11 +289,31 @@ struct R6 {
             }
         }
     }
+    // Stage 1 of a gather. Sweeping all units while the producers are still microseconds away is what the first version did: 256
+    // workgroups x 7 waves re-reading up to 24 KB each per round trip, through the fabric (tagged units are read past the L2s) -- as
+    // many bytes per layer as the weight stream itself, on a handful of memory channels, and the stream crawled during every gather.
+    // Here every wave first watches ONE unit (a different one per wave and workgroup: 64 bytes per attempt) until its tag turns or until
+    // another wave of the workgroup has seen its own turn (LDS word); only then the wide sweeps start.
+    static __device__ __forceinline__ void gather_hint(Poll & pl, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap) {
+        for (unsigned spin = 0;; spin++) {
+            if (fl_ld(go) >= gen || pl.dead) break;
+            asm volatile("" ::: "memory");
+            const v4u v = tg_load(xr, unit);
+            if (__builtin_amdgcn_readfirstlane((int) tg_ok(v, tag))) { fl_st(go, gen); break; }
+            if (poll_backoff(pl, spin)) break;
+            for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
+        }
+    }
     // every gathering wave, after staging its share: arrive, then wait for the others' shares (gen = gathers of this kind so far)
     static __device__ __forceinline__ void gather_meet(Poll & pl, unsigned * f, unsigned gen) {
         fl_add(f, 1u);
         fl_wait(pl, f, (unsigned) NG * gen);
     }
+    // A wave's wide sweep of a hand-over (after its sentinel turned) until the workgroup's gather is complete: the loader is thinned
+    // for exactly that span -- its fills sit in the same memory pipe as the polls (row gather-pass). NOT while a wave merely watches a
+    // sentinel: the comm wave reaches most gathers a whole row phase early, and a loader thinned through the row phases streams at half rate.
+    static __device__ __forceinline__ void sweep_begin(const Lds & l) { fl_add(l.fl + FL_SWB, 1u); }
+    static __device__ __forceinline__ void sweep_end(const Lds & l) { fl_add(l.fl + FL_SWE, 1u); }
 
     // -----------------------------------------------------------------------------------------------------------
     // prologues (consumer waves 0..3 = 256 threads)
@@ -379,77 +432,98 @@ struct R6 {
     // -----------------------------------------------------------------------------------------------------------
     static __device__ __forceinline__ void dma_chunk(unsigned long long sbase, unsigned voff, unsigned m0dst) {
         // (inline asm: M0 is not preserved around a statement, and through the builtin the compiler would wait for every DMA in flight
-        //  at the next LDS access; completion is counted by hand. s_nop 4: the scalar base may have been written just before.)
+        //  at the next LDS access; completion is counted by hand. The scalar base is produced by SALU instructions: no wait state.)
         unsigned keep;
-        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0dst) : "memory");
     }
     static __device__ __forceinline__ void wait_vm(int w) {
-        switch (w) {   // (immediate operand)
+        switch (w >> 2) {   // (immediate operand; multiples of four)
             case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 8:  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-            case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-            case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-            case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+            case 1:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 2:  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 3:  asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 4:  asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 5:  asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 6:  asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 7:  asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+            case 8:  asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+            case 9:  asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
         }
     }
+    // The loader never waits for more than it must: `level` is a known upper bound of the DMA instructions still in flight (fills land in
+    // order, so everything before issued - level is in the ring). With room in the ring it issues up to `burst` fills per round, in
+    // straight-line groups of four, and only waits when more than `w` would be in flight; when the ring is full it retires the fills in
+    // flight a few at a time -- publishing them to the consumers and looking at their positions in between -- instead of draining the queue.
+    // (Measured with the loader alone in this kernel, RWKV_MI_RING_DBG=8: a round costs ~700 cycles + ~100 per fill as a rolled loop with a
+    //  look at the LDS words per round -- 3 GB/s per CU at one fill per round, 13 at eight, 19.5 at thirty-two; tools/ring_bench.hip: 27.)
     static __device__ __forceinline__ void loader_main(const R6P & p, const Lds & l, int lane) {
         const int wave = 0;
         const R6Cu cu = p.cus[blockIdx.x];
         const unsigned total = __builtin_amdgcn_readfirstlane(cu.chunks);
         const unsigned long long src0 = (unsigned long long) p.stream + cu.base;
-        const unsigned s_lo = __builtin_amdgcn_readfirstlane((unsigned) src0), s_hi = __builtin_amdgcn_readfirstlane((unsigned) (src0 >> 32));
         const unsigned RB = __builtin_amdgcn_readfirstlane(p.ring_bytes);
         const unsigned ring_m0 = __builtin_amdgcn_readfirstlane((unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) l.ring);
         const unsigned voff = (unsigned) lane * 16u;
-        const int w_norm = __builtin_amdgcn_readfirstlane(p.inflight), w_thin = __builtin_amdgcn_readfirstlane(p.thin);
+        const int w_norm = __builtin_amdgcn_readfirstlane(p.inflight) & ~3, w_thin = __builtin_amdgcn_readfirstlane(p.thin) & ~3;
         Poll pl{p.ctl, false};
         unsigned issued = 0, roff = 0, landed = 0;
         unsigned min_done = 0, thin = 0;
+        int level = 0;
+        const unsigned burst = (unsigned) __builtin_amdgcn_readfirstlane(p.burst);
+        const unsigned s_lo = __builtin_amdgcn_readfirstlane((unsigned) src0), s_hi = __builtin_amdgcn_readfirstlane((unsigned) (src0 >> 32));
         const int li = p.trace_layer;   // (stamps: once per launch)
         R6STAMP(0);
-        unsigned stalls = 0;
+        unsigned stalls = 0, rounds = 0;
+        unsigned long long sb = ((unsigned long long) s_hi << 32) | s_lo;
+        auto one = [&]() {
+            dma_chunk(sb, voff, ring_m0 + roff);
+            sb += 1024ull;
+            roff += 1024u; roff = roff >= RB ? 0u : roff;
+        };
         for (unsigned spin = 0; issued < total;) {
             const unsigned lim0 = min_done >= total * 1024u ? total : (min_done + RB) >> 10;
             const unsigned lim = lim0 < total ? lim0 : total;
-            if (issued >= lim) {
-                // ring full: retire what is in flight, publish it, look again
-                if (landed != issued) { wait_vm(0); landed = issued; fl_st(l.fl + FL_LANDED, landed); }
-                stalls++;
-                if (lds_backoff(pl, spin++)) break;
-            } else {
+            // the consumers' positions and the sweep counters for the NEXT round: the reads travel while this round's fills are issued
+            asm volatile("" ::: "memory");
+            const v4u da = *reinterpret_cast<const v4u *>(l.fl + FL_DONE), db = *reinterpret_cast<const v4u *>(l.fl + FL_DONE + 4);
+            const v4u dh = *reinterpret_cast<const v4u *>(l.fl);   // {landed, sweeps begun, sweeps ended, -}
+            const int w = thin ? w_thin : w_norm;
+            rounds++;
+            if (issued < lim) {
                 spin = 0;
                 unsigned n = lim - issued;
-                n = n < 4u ? n : 4u;
-                for (unsigned k = 0; k < n; k++) {
-                    const unsigned long long sb = (((unsigned long long) s_hi << 32) | s_lo) + (unsigned long long) (issued + k) * 1024ull;
-                    dma_chunk(sb, voff, ring_m0 + roff);
-                    roff += 1024u; roff = roff >= RB ? 0u : roff;
-                }
+                n = n < burst ? n : burst;
+                unsigned k = 0;
+                for (; k + 4u <= n; k += 4u) { one(); one(); one(); one(); }
+                for (; k < n; k++) one();
                 issued += n;
-                const int w = thin ? w_thin : w_norm;
-                wait_vm(w);                                       // fills land in order: at most w of them are still in flight
-                const unsigned ld = issued > (unsigned) w ? issued - (unsigned) w : 0u;
-                if (ld > landed) { landed = ld; fl_st(l.fl + FL_LANDED, landed); }
+                level += (int) n;
+                if (level > w) { wait_vm(w); level = w; }
+            } else {
+                stalls++;
+                if (level > 0) { const int x = (level - 1) & ~3; wait_vm(x); level = x; }
+                else if (lds_backoff(pl, spin++)) break;
             }
-            // the consumers' positions (the ring may be refilled up to the smallest) and the gather flag
+            if (issued - (unsigned) level > landed) { landed = issued - (unsigned) level; fl_st(l.fl + FL_LANDED, landed); }
             {
-                asm volatile("" ::: "memory");
-                const v4u a = *reinterpret_cast<const v4u *>(l.fl + FL_DONE), b = *reinterpret_cast<const v4u *>(l.fl + FL_DONE + 4);
-                unsigned m = a.x < a.y ? a.x : a.y; m = m < a.z ? m : a.z; m = m < a.w ? m : a.w;
-                m = m < b.x ? m : b.x; m = m < b.y ? m : b.y; m = m < b.z ? m : b.z; m = m < b.w ? m : b.w;
+                unsigned m = da.x < da.y ? da.x : da.y; m = m < da.z ? m : da.z; m = m < da.w ? m : da.w;
+                m = m < db.x ? m : db.x; m = m < db.y ? m : db.y; m = m < db.z ? m : db.z; m = m < db.w ? m : db.w;
                 min_done = __builtin_amdgcn_readfirstlane(m);
-                thin = fl_ld(l.fl + FL_THIN);
+                thin = __builtin_amdgcn_readfirstlane(dh.y != dh.z ? 1u : 0u);
             }
         }
         wait_vm(0);
         fl_st(l.fl + FL_LANDED, total);
         R6STAMP(1);
-        if (p.trace && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 2] = (long long) stalls;
+        if (p.trace && lane == 0) {
+            p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 2] = (long long) stalls;
+            p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 3] = (long long) rounds;
+        }
     }
 
     // -----------------------------------------------------------------------------------------------------------
@@ -461,7 +535,8 @@ struct R6 {
         unsigned rpos, roff;   // ring cursor: stream position and its ring offset
         unsigned RB;
         unsigned landed;       // chunks known to have landed
-        int c, lane;
+        int c, lane, dbg;
+        bool prof; long long t_load, t_dot, t_epi, t_mark;   // (trace layer: where a pair's cycles go)
     };
     // positions the cursor on the record at stream position pos and waits until its bytes are in the ring
     static __device__ __forceinline__ void rec_seek(Cons & cs, Poll & pl, const Lds & l, unsigned pos, unsigned bytes) {
@@ -469,7 +544,7 @@ struct R6 {
         while (ro >= cs.RB) ro -= cs.RB;
         cs.roff = __builtin_amdgcn_readfirstlane(ro); cs.rpos = pos;
         // (the loader usually runs far ahead: the last value seen mostly covers the record, no LDS round trip)
-        const unsigned need = (pos + bytes + 1023u) >> 10;
+        const unsigned need = (cs.dbg & 4) ? 0u : (pos + bytes + 1023u) >> 10;
         for (unsigned spin = 0; cs.landed < need; spin++) {
             cs.landed = fl_ld(l.fl + FL_LANDED);
             if (cs.landed >= need || pl.dead) break;
@@ -477,21 +552,68 @@ struct R6 {
         }
         asm volatile("" ::: "memory");
     }
-    // the records of one phase that belong to this wave; epi(j, res) receives the row sums of record j
-    template <int PH, int R, int U, typename EpiF>
+    // the records of one phase that belong to this wave; epi(j, res) receives the row sums of record j.
+    // PAIR: two records per round -- both records' ring reads in flight together, their 2 R rows accumulated in one straight-line block
+    // (2 R independent chains) and folded by one interleaved butterfly; the per-record fixed costs (cursor, landed check, release,
+    // branches, LDS round trip) are paid once per pair. A record alone took ~1700 cycles for ~140 instructions.
+    template <int PH, int R, int U, bool PAIR, typename EpiF>
     static __device__ __forceinline__ void run_phase(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, EpiF && epi) {
         const unsigned n = cs.cu.n[PH], rec = cs.cu.rec[PH];
         const unsigned after = cs.lbase + rg_next_own(cs.cu, cs.c, PH + 1);
-        for (unsigned j = rg_first_j(cs.cu, PH, cs.c); j < n; j += NC) {
-            const unsigned pos = cs.lbase + cs.cu.off[PH] + j * rec;
+        unsigned j = rg_first_j(cs.cu, PH, cs.c);
+        if (j >= n) return;
+        ActRegs<U> ar;
+        act_load<U>(ar, act, nbk, opq(cs.lane));
+        auto load = [&](RawRec<FMT, R, U> & w, unsigned jj) {
+            const unsigned pos = cs.lbase + cs.cu.off[PH] + jj * rec;
             rec_seek(cs, pl, l, pos, rec);
-            RawRec<FMT, R, U> w;
-            rec_load<FMT, R, U>(w, l.ring, cs.RB, cs.roff, opq(cs.lane));
-            // the reads above are in the LDS queue: the ring may be refilled up to this wave's next record
-            fl_st(l.fl + FL_DONE + 2 + cs.c, j + NC < n ? pos + NC * rec : after);
-            float res[R];
-            rec_dot<FMT, R, U>(w, act, nbk, opq(cs.lane), res);
-            epi((int) j, res);
+            if (!(cs.dbg & 2)) rec_load<FMT, R, U>(w, l.ring, cs.RB, cs.roff, opq(cs.lane));
+            return pos;
+        };
+        // (after a record's reads are in the LDS queue the ring may be refilled up to this wave's next record)
+        auto release = [&](unsigned jj, unsigned pos) { fl_st(l.fl + FL_DONE + 2 + cs.c, jj + NC < n ? pos + NC * rec : after); };
+        if constexpr (PAIR) {
+            for (;;) {
+                RawRec<FMT, R, U> wa, wb;
+                const bool two = j + NC < n;
+                const long long t0 = cs.prof ? (long long) __builtin_readcyclecounter() : 0ll;
+                unsigned pos = load(wa, j);
+                if (two) { pos = load(wb, j + NC); release(j + NC, pos); } else release(j, pos);
+                if (cs.prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t1 = (long long) __builtin_readcyclecounter(); cs.t_load += t1 - t0; cs.t_mark = t1; }
+                if (two) {
+                    float acc[2 * R];
+                    if (!(cs.dbg & 1)) {
+                        rec_acc<FMT, R, U>(wa, ar, nbk, opq(cs.lane), acc);
+                        rec_acc<FMT, R, U>(wb, ar, nbk, opq(cs.lane), acc + R);
+                        wave_sum_n<2 * R>(acc);
+                    } else { for (int r = 0; r < 2 * R; r++) acc[r] = 0.0f; }
+                    float ra[R], rb[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) { ra[r] = acc[r]; rb[r] = acc[R + r]; }
+                    if (cs.prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[2 * R - 1])); const long long t2 = (long long) __builtin_readcyclecounter(); cs.t_dot += t2 - cs.t_mark; cs.t_mark = t2; }
+                    epi((int) j, ra);
+                    epi((int) (j + NC), rb);
+                    if (cs.prof) { const long long t3 = (long long) __builtin_readcyclecounter(); cs.t_epi += t3 - cs.t_mark; }
+                    j += 2 * NC;
+                    if (j >= n) break;
+                } else {
+                    float acc[R];
+                    if (!(cs.dbg & 1)) { rec_acc<FMT, R, U>(wa, ar, nbk, opq(cs.lane), acc); wave_sum_n<R>(acc); }
+                    else { for (int r = 0; r < R; r++) acc[r] = 0.0f; }
+                    epi((int) j, acc);
+                    break;
+                }
+            }
+        } else {
+            for (; j < n; j += NC) {
+                RawRec<FMT, R, U> w;
+                const unsigned pos = load(w, j);
+                release(j, pos);
+                float acc[R];
+                if (!(cs.dbg & 1)) { rec_acc<FMT, R, U>(w, ar, nbk, opq(cs.lane), acc); wave_sum_n<R>(acc); }
+                else { for (int r = 0; r < R; r++) acc[r] = 0.0f; }
+                epi((int) j, acc);
+            }
         }
     }
 
@@ -509,7 +631,7 @@ struct R6 {
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         const RingShape sh = shape(p);
         Cons cs;
-        cs.cu = rg_cu(sh, blk); cs.lbase = 0; cs.rpos = 0; cs.roff = 0; cs.landed = 0; cs.RB = __builtin_amdgcn_readfirstlane(p.ring_bytes); cs.c = c; cs.lane = lane;
+        cs.cu = rg_cu(sh, blk); cs.lbase = 0; cs.rpos = 0; cs.roff = 0; cs.landed = 0; cs.dbg = __builtin_amdgcn_readfirstlane(p.dbg); cs.prof = false; cs.t_load = cs.t_dot = cs.t_epi = cs.t_mark = 0; cs.RB = __builtin_amdgcn_readfirstlane(p.ring_bytes); cs.c = c; cs.lane = lane;
         const int mat = (blk * (4 * D / NBLK)) / D;   // which of r, k, v, g this workgroup's sets belong to
         const int cbase = (blk * (4 * D / NBLK)) % D;
         const bool has_dw1 = blk < p.DR;
@@ -532,44 +654,74 @@ struct R6 {
             //  hundred loop-invariant address registers of the gathers out of the layer loop and spills them)
             // ---- A: x, LN1 + mix + quantise, W1 rows ----
             if (li == 0) {
+                sweep_begin(l);
                 for (int i = c * 64 + lane; i < D; i += NG * 64) l.x[i] = p.x[i];
             } else {
+                gather_hint(pl, xr, p.xffn + ((blk * 37 + c * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
+                sweep_begin(l);
                 gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, c, opq(lane), l.x);
             }
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
+            sweep_end(l);
             R6STAMP(1);
             if (pro) prologue_A(pl, l, pa, sout_l, blk == 0, opq(pt), opq(lane), 2u * li + 1u);
             fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 1u));
             R6STAMP(2);
-            run_phase<RG_W1, 1, UD>(cs, pl, l, qvec_at(l.q1, D), nb, [&](int j, const float (&res)[1]) {
+            run_phase<RG_W1, 1, UD, false>(cs, pl, l, qvec_at(l.q1, D), nb, [&](int j, const float (&res)[1]) {
                 if (lane == 0) tg_store(xr, p.tl + blk + NBLK * j, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
             });
             R6STAMP(3);
             // ---- C: the mixed inputs (this workgroup's matrix reads ONE of the five), decay row, r/k/v/g sets ----
             {
                 const int img = (0x4213 >> (4 * mat)) & 0xF;   // r, k, v, g -> mix image (w, k, v, r, g order)
+                gather_hint(pl, xr, p.act5 + img * p.act_stride + ((blk * 7 + c * 19) & 127), tagL + SLOT_ACT, l.fl + FL_HACT, g1, p.nap);
+                sweep_begin(l);
                 gather_qvec<DSL>(pl, xr, p.act5 + img * p.act_stride, D, tagL + SLOT_ACT, c, opq(lane), l.act);
                 if (has_dw1) gather_qvec<DSL>(pl, xr, p.act5, D, tagL + SLOT_ACT, c, opq(lane), l.actw);
                 gather_meet(pl, l.fl + FL_GACT, g1);
+                sweep_end(l);
             }
             R6STAMP(4);
-            run_phase<RG_DW1, 1, UD>(cs, pl, l, qvec_at(l.actw, D), nb, [&](int, const float (&res)[1]) {
+            run_phase<RG_DW1, 1, UD, false>(cs, pl, l, qvec_at(l.actw, D), nb, [&](int, const float (&res)[1]) {
                 if (lane == 0) tg_store(xr, p.dl + blk, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
             });
-            run_phase<RG_C, 2, UD>(cs, pl, l, qvec_at(l.act, D), nb, [&](int j, const float (&res)[2]) {
-                float v = lane == 1 ? res[1] : res[0];
+            {
+                // all row sums first, then ONE epilogue: lane 2 t + r finishes row r of this wave's t-th set (the gate's silu is a double-
+                // precision exp: once per phase, not once per record) and lanes 0, 2, 4, ... store their set's unit with one instruction
+                constexpr int MAXT = (D * 4 / NBLK / 2 + NC - 1) / NC;
+                float all[2 * MAXT];
+#pragma unroll
+                for (int t = 0; t < 2 * MAXT; t++) all[t] = 0.0f;
+                const int j0 = (int) rg_first_j(cs.cu, RG_C, c);
+                if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 20] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_C]);
+                cs.prof = p.trace != nullptr && li == p.trace_layer && (p.dbg & 16);
+                cs.t_load = cs.t_dot = cs.t_epi = 0;
+                run_phase<RG_C, 2, UD, true>(cs, pl, l, qvec_at(l.act, D), nb, [&](int j, const float (&res)[2]) {
+                    const int t = (j - j0) / NC;
+#pragma unroll
+                    for (int tt = 0; tt < MAXT; tt++) if (tt == t) { all[2 * tt] = res[0]; all[2 * tt + 1] = res[1]; }
+                });
+                if (cs.prof && lane == 0) { long long * tr = p.trace + ((long long) blockIdx.x * 8 + wave) * 32; tr[16] = cs.t_load; tr[18] = cs.t_dot; tr[19] = cs.t_epi; }
+                cs.prof = false;
+                const int ln = opq(lane);
+                float v = pick_lane<2 * MAXT>(all, ln);
                 if (mat == 3) v = v / (1.0f + det_expf(-v));     // gate: silu
-                const int v1 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true);   // lane 0 collects row 1 (row_shl:1)
-                if (lane == 0) tg_store(xr, p.rkvg + ((mat * D + cbase + 2 * j) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
-            });
+                const int v1 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true);   // lane 2 t collects row 1 (row_shl:1)
+                const int j = j0 + NC * (ln >> 1);
+                if (ln < 2 * MAXT && (ln & 1) == 0 && j < (int) cs.cu.n[RG_C])
+                    tg_store(xr, p.rkvg + ((mat * D + cbase + 2 * j) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
+            }
             R6STAMP(5);
             issue_pf(pf, ar, L, sin_l, opq(ppt));
             __builtin_amdgcn_sched_barrier(0);
             // ---- E: output projection + residual ----
+            gather_hint(pl, xr, p.yq + ((blk * 7 + c * 19) & 127), tagL + SLOT_YQ, l.fl + FL_HYQ, g1, p.nap);
+            sweep_begin(l);
             gather_qvec<DSL>(pl, xr, p.yq, D, tagL + SLOT_YQ, c, opq(lane), l.yq);
             gather_meet(pl, l.fl + FL_GYQ, g1);
+            sweep_end(l);
             R6STAMP(6);
-            run_phase<RG_E, 1, UD>(cs, pl, l, qvec_at(l.yq, D), nb, [&](int j, const float (&res)[1]) {
+            run_phase<RG_E, 1, UD, true>(cs, pl, l, qvec_at(l.yq, D), nb, [&](int j, const float (&res)[1]) {
                 const int t = j / NC;
 #pragma unroll
                 for (int tt = 0; tt < XT; tt++) if (tt == t) xown[tt] = xown[tt] + res[0];
@@ -577,20 +729,24 @@ struct R6 {
             if (lane == 0) tg_store(xr, p.xatt + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XATT);
             R6STAMP(7);
             // ---- F: x, LN2 + mixes + quantise, key sets (-> comm quantises them), receptance rows ----
+            gather_hint(pl, xr, p.xatt + ((blk * 37 + c * 211) & 1023), tagL + SLOT_XATT, l.fl + FL_HX, 2u * li + 2u, p.nap);
+            sweep_begin(l);
             gather_x(pl, xr, p.xatt, tagL + SLOT_XATT, c, opq(lane), l.x);
             gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
+            sweep_end(l);
             R6STAMP(8);
             if (pro) prologue_F(pl, l, pf, sout_l, blk == 0, opq(pt), opq(lane), 2u * li + 2u);
             fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 2u));
             R6STAMP(9);
-            run_phase<RG_FK, 2, UD>(cs, pl, l, qvec_at(l.q1, D), nb, [&](int j, const float (&res)[2]) {
+            if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 21] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_FK]);
+            run_phase<RG_FK, 2, UD, true>(cs, pl, l, qvec_at(l.q1, D), nb, [&](int j, const float (&res)[2]) {
                 const float v = lane == 1 ? res[1] : res[0];
                 const float t = v > 0.0f ? v : 0.0f;
                 if (lane < 2) l.out[2 * j + lane] = t * t;
             });
             fl_add(l.fl + FL_KEYS, 1u);
             R6STAMP(10);
-            run_phase<RG_FR, 1, UD>(cs, pl, l, qvec_at(l.q2, D), nb, [&](int j, const float (&res)[1]) {
+            run_phase<RG_FR, 1, UD, true>(cs, pl, l, qvec_at(l.q2, D), nb, [&](int j, const float (&res)[1]) {
                 const int t = j / NC;
 #pragma unroll
                 for (int tt = 0; tt < XT; tt++) if (tt == t) rrow[tt] = res[0];
@@ -602,10 +758,14 @@ struct R6 {
             __builtin_amdgcn_sched_barrier(0);
             R6STAMP(11);
             // ---- G: value projection, x += sigmoid(r) * (Wv k) ----
+            gather_hint(pl, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap);
+            sweep_begin(l);
             gather_qvec<KSL>(pl, xr, p.kq, F, tagL + SLOT_KQ, c, opq(lane), l.kq);
             gather_meet(pl, l.fl + FL_GKQ, g1);
+            sweep_end(l);
             R6STAMP(12);
-            run_phase<RG_G, 1, UF>(cs, pl, l, qvec_at(l.kq, F), nbF, [&](int j, const float (&res)[1]) {
+            if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 22] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_G]);
+            run_phase<RG_G, 1, UF, false>(cs, pl, l, qvec_at(l.kq, F), nbF, [&](int j, const float (&res)[1]) {
                 const int t = j / NC;
 #pragma unroll
                 for (int tt = 0; tt < XT; tt++) if (tt == t) {
@@ -650,14 +810,16 @@ struct R6 {
             const unsigned g1 = (unsigned) li + 1u;
             R6STAMP(0);
             // ---- A ----
-            fl_st(l.fl + FL_THIN, 1u);
             if (li == 0) {
+                sweep_begin(l);
                 for (int i = g * 64 + lane; i < D; i += NG * 64) l.x[i] = p.x[i];
             } else {
+                gather_hint(pl, xr, p.xffn + ((blk * 37 + g * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
+                sweep_begin(l);
                 gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, g, opq(lane), l.x);
             }
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
-            fl_st(l.fl + FL_THIN, 0u);
+            sweep_end(l);
             R6STAMP(1); R6RSTAMP(17);
             // W2 of this workgroup's chunk(s) (chunk-blocked copy: lane d reads float4 {m .. m+3}) and the chunk's LayerNorm / shift
             // parameters: in flight while the prologue waves run
@@ -690,9 +852,8 @@ struct R6 {
                     cxn[q] = yw + cb_[q];
                     csx[q] = cpv[q] - cxn[q];
                 }
-                fl_st(l.fl + FL_THIN, 1u);
+                gather_hint(pl, xr, p.tl + ((blk * 7) & 127), tagL + SLOT_TL, l.fl + FL_HTL, g1, p.nap);   // (one unit first, then the sweep)
                 poll_units<5, 64>(pl, xr, p.tl, 5 * R, tagL + SLOT_TL, ln, [&](int i, const v4u & v) { l.tl[i] = __uint_as_float(v.x); });
-                fl_st(l.fl + FL_THIN, 0u);
                 __builtin_amdgcn_wave_barrier();
                 R6STAMP(3); R6RSTAMP(18);
 #pragma unroll
@@ -727,12 +888,13 @@ struct R6 {
             R6RSTAMP(19); R6STAMP(4);
             // ---- C: stage this workgroup's share of the mixed inputs ----
             {
-                fl_st(l.fl + FL_THIN, 1u);
                 const int img = (0x4213 >> (4 * mat)) & 0xF;
+                gather_hint(pl, xr, p.act5 + img * p.act_stride + ((blk * 7 + g * 19) & 127), tagL + SLOT_ACT, l.fl + FL_HACT, g1, p.nap);
+                sweep_begin(l);
                 gather_qvec<DSL>(pl, xr, p.act5 + img * p.act_stride, D, tagL + SLOT_ACT, g, opq(lane), l.act);
                 if (has_dw1) gather_qvec<DSL>(pl, xr, p.act5, D, tagL + SLOT_ACT, g, opq(lane), l.actw);
                 gather_meet(pl, l.fl + FL_GACT, g1);
-                fl_st(l.fl + FL_THIN, 0u);
+                sweep_end(l);
             }
             R6STAMP(5); R6RSTAMP(20);
             // ---- D: WKV head of this workgroup ----
@@ -838,14 +1000,18 @@ struct R6 {
             }
             R6STAMP(6); R6RSTAMP(21);
             // ---- E ----
-            fl_st(l.fl + FL_THIN, 1u);
+            gather_hint(pl, xr, p.yq + ((blk * 7 + g * 19) & 127), tagL + SLOT_YQ, l.fl + FL_HYQ, g1, p.nap);
+            sweep_begin(l);
             gather_qvec<DSL>(pl, xr, p.yq, D, tagL + SLOT_YQ, g, opq(lane), l.yq);
             gather_meet(pl, l.fl + FL_GYQ, g1);
+            sweep_end(l);
             R6STAMP(7); R6RSTAMP(22);
             // ---- F ----
+            gather_hint(pl, xr, p.xatt + ((blk * 37 + g * 211) & 1023), tagL + SLOT_XATT, l.fl + FL_HX, 2u * li + 2u, p.nap);
+            sweep_begin(l);
             gather_x(pl, xr, p.xatt, tagL + SLOT_XATT, g, opq(lane), l.x);
             gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
-            fl_st(l.fl + FL_THIN, 0u);
+            sweep_end(l);
             R6STAMP(8); R6RSTAMP(23);
             fl_wait(pl, l.fl + FL_KEYS, (unsigned) NC * g1);     // every consumer's key sets are in l.out
             R6STAMP(9);
@@ -864,10 +1030,11 @@ struct R6 {
             }
             R6STAMP(10); R6RSTAMP(24);
             // ---- G ----
-            fl_st(l.fl + FL_THIN, 1u);
+            gather_hint(pl, xr, p.kq + ((blk * 5 + g * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap);
+            sweep_begin(l);
             gather_qvec<KSL>(pl, xr, p.kq, F, tagL + SLOT_KQ, g, opq(lane), l.kq);
             gather_meet(pl, l.fl + FL_GKQ, g1);
-            fl_st(l.fl + FL_THIN, 0u);
+            sweep_end(l);
             R6STAMP(11); R6RSTAMP(25);
         }
     }
@@ -894,6 +1061,11 @@ __global__ __launch_bounds__(512) void k6_ring(R6P p) {
 #ifndef R6_ROLES
 #define R6_ROLES 7
 #endif
+    if (p.dbg & 8) {   // timing experiment: the loader alone (every other wave releases the whole ring and leaves)
+        if (wave == 0) K::loader_main(p, l, lane);
+        else fl_st(l.fl + FL_DONE + wave, 0xFFFFFFFFu);
+        return;
+    }
     if (wave == 0) { if (R6_ROLES & 1) K::loader_main(p, l, lane); }
     else if (wave == 1) { if (R6_ROLES & 2) K::comm_main(p, l, lane, base); }
     else { if (R6_ROLES & 4) K::consumer_main(p, l, lane, wave, base); }
@@ -1129,11 +1301,14 @@ void * ring_v6_create(const Model & m) {
     q.stream = rg->stream; q.cus = rg->d_cus;
     q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;
     q.ring_bytes = (unsigned) ring;
-    auto snap = [](int w) { const int ok_[] = {0, 4, 8, 16, 24, 32, 40, 48, 56}; int best = 0; for (int x : ok_) if (x <= w) best = x; return best; };
-    q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 48));
+    auto snap = [](int w) { w &= ~3; return w < 4 ? 4 : (w > 52 ? 52 : w); };
+    q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 32));
     q.thin = snap(env_int("RWKV_MI_RING_THIN", 16));
-    if (q.inflight < 4) q.inflight = 4;
-    if (q.thin < 4) q.thin = 4;
+    q.nap = env_int("RWKV_MI_RING_NAP", 2);
+    q.dbg = env_int("RWKV_MI_RING_DBG", 0);
+    q.burst = env_int("RWKV_MI_RING_BURST", 16);
+    if (q.burst < 1) q.burst = 1;
+    if (q.burst > 32) q.burst = 32;
     return rg;
 }
 

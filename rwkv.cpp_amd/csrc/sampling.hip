@@ -34,11 +34,12 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned lon
 }
 
 __global__ __launch_bounds__(1024) void k_sample(const float * __restrict__ logits, int n, float temperature, float top_p, float u_in,
-                                                 unsigned long long seed, const unsigned long long * __restrict__ counter_in, unsigned long long * __restrict__ counter_out,
+                                                 unsigned long long seed, unsigned long long * counter /* read and advanced by thread 0; may be NULL */,
                                                  float * __restrict__ probs, uint32_t * __restrict__ out_token, uint32_t * __restrict__ hist, int hist_pos) {
     __shared__ float red[32];
     __shared__ float l_scan[1024];
     __shared__ int l_pick;
+    __shared__ unsigned long long l_ctr;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int C = (n + NT - 1) / NT;                 // contiguous chunk per thread
     const int i0 = tid * C, i1 = i0 + C < n ? i0 + C : n;
@@ -78,6 +79,12 @@ __global__ __launch_bounds__(1024) void k_sample(const float * __restrict__ logi
         if (top_p < 1.0f) {
             // largest bit pattern T with sum{p : bits(p) >= T} > top_p  (probabilities are non-negative floats: bit order = value order)
             unsigned T = 0u;
+            // (when not even the sum over ALL probabilities exceeds top_p -- float rounding of the softmax -- the reference's
+            //  argmax over an all-false mask is 0: the cut-off is the LARGEST probability, i.e. 1 * inv)
+            float g0 = 0.0f;
+            for (int i = i0; i < i1; i++) g0 += probs[i];
+            g0 = block_sum_f(g0, red);
+            const bool none = !(g0 > top_p);
             for (int bit = 30; bit >= 0; bit--) {
                 const unsigned cand = T | (1u << bit);
                 float g = 0.0f;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(1024) void k_sample(const float * __restrict__ logi
                 g = block_sum_f(g, red);
                 if (g > top_p) T = cand;
             }
-            cutoff_bits = T;
+            cutoff_bits = none ? __float_as_uint(1.0f * inv) : T;
         }
         const float it = 1.0f / temperature;
         part = 0.0f;
@@ -106,19 +113,22 @@ __global__ __launch_bounds__(1024) void k_sample(const float * __restrict__ logi
             __syncthreads();
         }
         const float all = l_scan[NT - 1];
-        const unsigned long long ctr = counter_in ? *counter_in : 0ull;
-        const float u = (u_in >= 0.0f ? u_in : uniform01(seed, ctr)) * all;
-        if (tid == 0) l_pick = -1;
+        if (tid == 0) { l_ctr = counter ? *counter : 0ull; l_pick = 0x7fffffff; }
         __syncthreads();
+        const unsigned long long ctr = l_ctr;
+        const float u = (u_in >= 0.0f ? u_in : uniform01(seed, ctr)) * all;
         const float before = tid ? l_scan[tid - 1] : 0.0f;
-        if (i0 < i1 && before <= u && u < l_scan[tid]) {   // exactly one thread: the prefix sums are non-decreasing
+        if (i0 < i1 && before <= u && u < l_scan[tid]) {
+            // (float prefix sums of a Hillis-Steele scan need not be monotone: more than one thread may see u in its interval -- the
+            //  lowest candidate index wins)
             float acc = before;
             int found = -1, last_pos = -1;
             for (int i = i0; i < i1; i++) { acc += probs[i]; if (probs[i] > 0.0f) last_pos = i; if (found < 0 && acc > u) found = i; }
-            l_pick = found >= 0 ? found : last_pos;       // (acc can fall short of l_scan[tid] by rounding: the chunk's last candidate)
+            const int cand = found >= 0 ? found : last_pos;   // (acc can fall short of l_scan[tid] by rounding: the chunk's last candidate)
+            if (cand >= 0) atomicMin(&l_pick, cand);
         }
         __syncthreads();
-        if (l_pick < 0 && tid == 0) {
+        if (l_pick == 0x7fffffff && tid == 0) {
             // u landed on / beyond the total through rounding: the last token with non-zero probability
             int lp = 0;
             for (int i = n - 1; i >= 0; i--) if (probs[i] > 0.0f) { lp = i; break; }
@@ -126,14 +136,14 @@ __global__ __launch_bounds__(1024) void k_sample(const float * __restrict__ logi
         }
         __syncthreads();
         pick = l_pick;
-        if (tid == 0 && counter_out) *counter_out = ctr + 1;
+        if (tid == 0 && counter) *counter = ctr + 1;
     }
     if (tid == 0) { *out_token = (uint32_t) pick; if (hist) hist[hist_pos] = (uint32_t) pick; }
 }
 
 void launch_sample(const float * logits, int n, float temperature, float top_p, float u, unsigned long long seed, unsigned long long * counter,
                    float * probs, uint32_t * out_token, uint32_t * hist, int hist_pos, hipStream_t st) {
-    hipLaunchKernelGGL(k_sample, dim3(1), dim3(1024), 0, st, logits, n, temperature, top_p, u, seed, counter, counter, probs, out_token, hist, hist_pos);
+    hipLaunchKernelGGL(k_sample, dim3(1), dim3(1024), 0, st, logits, n, temperature, top_p, u, seed, counter, probs, out_token, hist, hist_pos);
 }
 
 }  // namespace rwkvmi

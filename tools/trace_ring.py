@@ -31,8 +31,13 @@ dc = np.diff(comm, axis=1)
 print('COMM wave: mean / min / max cycles')
 for i, n in enumerate(cn): print('%-14s %8.0f %8.0f %8.0f   %.2f' % (n, dc[:, i].mean(), dc[:, i].min(), dc[:, i].max(), dc[:, i].mean() / 2400))
 print('comm D.head on head workgroups only:', dc[:64, 5].mean(), ' others:', dc[64:, 5].mean())
-ld = t[:, 0, :3]
-print('LOADER: active cycles mean %.0f (whole token), ring-full stalls mean %.0f max %.0f' % ((ld[:, 1] - ld[:, 0]).mean(), ld[:, 2].mean(), ld[:, 2].max()))
+if os.environ.get('RWKV_MI_RING_DBG', '0') != '0' and int(os.environ['RWKV_MI_RING_DBG']) & 16:
+    pr = t[:, 2:, 16:20]
+    print('C.rows split (cycles, mean over consumer waves): load+wait %.0f  arithmetic+butterfly %.0f  epilogue %.0f' % (pr[:, :, 0].mean(), pr[:, :, 2].mean(), pr[:, :, 3].mean()))
+ah = t[:, 2:, 20:23] / 1024
+print('loader ahead of the phase start when the consumers begin (KiB, mean / min / max): C %.0f %.0f %.0f   keys %.0f %.0f %.0f   G %.0f %.0f %.0f' % (ah[:, :, 0].mean(), ah[:, :, 0].min(), ah[:, :, 0].max(), ah[:224, :, 1].mean(), ah[:224, :, 1].min(), ah[:224, :, 1].max(), ah[:, :, 2].mean(), ah[:, :, 2].min(), ah[:, :, 2].max()))
+ld = t[:, 0, :4]
+print('LOADER: active cycles mean %.0f (whole token), ring-full rounds mean %.0f max %.0f, rounds mean %.0f' % ((ld[:, 1] - ld[:, 0]).mean(), ld[:, 2].mean(), ld[:, 2].max(), ld[:, 3].mean()))
 R = t
 rt = lambda w, k: R[:, w, k]
 print('hand-over (100 MHz real time): x staged (comm 17) spread %.2f us' % ((rt(1, 17).max() - rt(1, 17).min()) / 100))
