@@ -46,7 +46,7 @@ struct R6P {
     int inflight, thin;                                // loader: DMA instructions in flight (normal / while the workgroup gathers)
     int nap;                                           // extra 64-cycle sleeps between two looks at a gather's sentinel unit
     int burst;                                         // loader: fills issued per round (between two looks at the consumers' positions)
-    int dbg;                                           // timing experiments (results are WRONG): 1 skip the row arithmetic, 2 skip the ring reads, 4 do not wait for the loader
+    int dbg;                                           // timing experiment: 8 = the loader alone (every other wave leaves at once; results are WRONG)
     long long * trace; int trace_layer;
 };
 
@@ -163,7 +163,7 @@ __device__ __forceinline__ void rec_acc(const RawRec<FMT, R, U> & w, const ActRe
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const bool valid = u * WAVE + lane < nbk;
+        const bool valid = u + 1 < U || u * WAVE + lane < nbk;   // (only the last step of a row can be short)
 #pragma unroll
         for (int r = 0; r < R; r++) {
             WBlk<FMT> wb;
@@ -532,87 +532,89 @@ struct R6 {
     struct Cons {
         RingCu cu;
         unsigned lbase;        // stream position of the current layer's block
-        unsigned rpos, roff;   // ring cursor: stream position and its ring offset
         unsigned RB;
         unsigned landed;       // chunks known to have landed
-        int c, lane, dbg;
-        bool prof; long long t_load, t_dot, t_epi, t_mark;   // (trace layer: where a pair's cycles go)
+        int c, lane;
     };
-    // positions the cursor on the record at stream position pos and waits until its bytes are in the ring
-    static __device__ __forceinline__ void rec_seek(Cons & cs, Poll & pl, const Lds & l, unsigned pos, unsigned bytes) {
-        unsigned ro = cs.roff + (pos - cs.rpos);
-        while (ro >= cs.RB) ro -= cs.RB;
-        cs.roff = __builtin_amdgcn_readfirstlane(ro); cs.rpos = pos;
-        // (the loader usually runs far ahead: the last value seen mostly covers the record, no LDS round trip)
-        const unsigned need = (cs.dbg & 4) ? 0u : (pos + bytes + 1023u) >> 10;
-        for (unsigned spin = 0; cs.landed < need; spin++) {
-            cs.landed = fl_ld(l.fl + FL_LANDED);
-            if (cs.landed >= need || pl.dead) break;
-            if (lds_backoff(pl, spin)) break;
-        }
-        asm volatile("" ::: "memory");
-    }
-    // the records of one phase that belong to this wave; epi(j, res) receives the row sums of record j.
-    // PAIR: two records per round -- both records' ring reads in flight together, their 2 R rows accumulated in one straight-line block
-    // (2 R independent chains) and folded by one interleaved butterfly; the per-record fixed costs (cursor, landed check, release,
-    // branches, LDS round trip) are paid once per pair. A record alone took ~1700 cycles for ~140 instructions.
-    template <int PH, int R, int U, bool PAIR, typename EpiF>
-    static __device__ __forceinline__ void run_phase(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, EpiF && epi) {
-        const unsigned n = cs.cu.n[PH], rec = cs.cu.rec[PH];
+    template <int T, int TE> struct Unroll {
+        template <typename F> static __device__ __forceinline__ void run(F && f) { f(std::integral_constant<int, T>{}); Unroll<T + 1, TE>::run(f); }
+    };
+    template <int TE> struct Unroll<TE, TE> { template <typename F> static __device__ __forceinline__ void run(F &&) {} };
+
+    // The records of one phase that belong to this wave: j0, j0 + NC, ...; the first TF exist for every wave (compile-time), one more
+    // ("tail") for some. Statically unrolled: the cursor is scalar arithmetic (stream position and ring offset advance by a constant),
+    // the loader's progress is compared against a cached scalar, a record's ring reads are immediate offsets from one base register
+    // (unless it wraps around the ring end: slow path) and, with PIPE, go out BEFORE the previous record's arithmetic.
+    // epi(integral_constant<t>, j, res) receives the row sums of the wave's t-th record (record j of the phase).
+    // (The first version walked the records in a loop with the cursor in a struct: ~300 overhead instructions per record -- half of
+    //  them scalar, forty branches -- around ~140 useful ones; a C phase took 13.7 k cycles for 3.6 k cycles of arithmetic.)
+    template <int PH, int R, int U, int TF, bool PIPE, typename EpiF>
+    static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, EpiF && epi) {
+        constexpr unsigned RECB = (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0));
+        constexpr unsigned STRIDE = NC * RECB;
+        const unsigned n = cs.cu.n[PH];
+        const unsigned j0 = rg_first_j(cs.cu, PH, cs.c);
+        if (j0 >= n) return;
+        const bool tail = j0 + NC * TF < n;                         // wave-uniform
         const unsigned after = cs.lbase + rg_next_own(cs.cu, cs.c, PH + 1);
-        unsigned j = rg_first_j(cs.cu, PH, cs.c);
-        if (j >= n) return;
+        unsigned pos = __builtin_amdgcn_readfirstlane(cs.lbase + cs.cu.off[PH] + j0 * RECB);
+        unsigned ro = pos;
+        { const unsigned q = pos / cs.RB; ro = __builtin_amdgcn_readfirstlane(pos - q * cs.RB); }   // (once per phase)
+        const unsigned RB = cs.RB;
+        const int ln = opq(cs.lane);
         ActRegs<U> ar;
-        act_load<U>(ar, act, nbk, opq(cs.lane));
-        auto load = [&](RawRec<FMT, R, U> & w, unsigned jj) {
-            const unsigned pos = cs.lbase + cs.cu.off[PH] + jj * rec;
-            rec_seek(cs, pl, l, pos, rec);
-            if (!(cs.dbg & 2)) rec_load<FMT, R, U>(w, l.ring, cs.RB, cs.roff, opq(cs.lane));
-            return pos;
-        };
-        // (after a record's reads are in the LDS queue the ring may be refilled up to this wave's next record)
-        auto release = [&](unsigned jj, unsigned pos) { fl_st(l.fl + FL_DONE + 2 + cs.c, jj + NC < n ? pos + NC * rec : after); };
-        if constexpr (PAIR) {
-            for (;;) {
-                RawRec<FMT, R, U> wa, wb;
-                const bool two = j + NC < n;
-                const long long t0 = cs.prof ? (long long) __builtin_readcyclecounter() : 0ll;
-                unsigned pos = load(wa, j);
-                if (two) { pos = load(wb, j + NC); release(j + NC, pos); } else release(j, pos);
-                if (cs.prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t1 = (long long) __builtin_readcyclecounter(); cs.t_load += t1 - t0; cs.t_mark = t1; }
-                if (two) {
-                    float acc[2 * R];
-                    if (!(cs.dbg & 1)) {
-                        rec_acc<FMT, R, U>(wa, ar, nbk, opq(cs.lane), acc);
-                        rec_acc<FMT, R, U>(wb, ar, nbk, opq(cs.lane), acc + R);
-                        wave_sum_n<2 * R>(acc);
-                    } else { for (int r = 0; r < 2 * R; r++) acc[r] = 0.0f; }
-                    float ra[R], rb[R];
-#pragma unroll
-                    for (int r = 0; r < R; r++) { ra[r] = acc[r]; rb[r] = acc[R + r]; }
-                    if (cs.prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[2 * R - 1])); const long long t2 = (long long) __builtin_readcyclecounter(); cs.t_dot += t2 - cs.t_mark; cs.t_mark = t2; }
-                    epi((int) j, ra);
-                    epi((int) (j + NC), rb);
-                    if (cs.prof) { const long long t3 = (long long) __builtin_readcyclecounter(); cs.t_epi += t3 - cs.t_mark; }
-                    j += 2 * NC;
-                    if (j >= n) break;
-                } else {
-                    float acc[R];
-                    if (!(cs.dbg & 1)) { rec_acc<FMT, R, U>(wa, ar, nbk, opq(cs.lane), acc); wave_sum_n<R>(acc); }
-                    else { for (int r = 0; r < R; r++) acc[r] = 0.0f; }
-                    epi((int) j, acc);
-                    break;
+        act_load<U>(ar, act, nbk, ln);
+        unsigned * const dn = l.fl + FL_DONE + 2 + cs.c;
+        RawRec<FMT, R, U> w[PIPE ? 2 : 1];
+        // ring reads + release of the record at (pos, ro); last = no further record of this wave in the phase
+        auto load = [&](RawRec<FMT, R, U> & wr, bool last) {
+            const unsigned need = (pos + RECB + 1023u) >> 10;
+            if (cs.landed < need) {
+                for (unsigned spin = 0;; spin++) {
+                    cs.landed = fl_ld(l.fl + FL_LANDED);
+                    if (cs.landed >= need || pl.dead) break;
+                    if (lds_backoff(pl, spin)) break;
                 }
             }
+            asm volatile("" ::: "memory");
+            rec_load<FMT, R, U>(wr, l.ring, RB, ro, ln);
+            // the reads above are in the LDS queue: the ring may be refilled up to this wave's next record (every lane writes the same word)
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(dn, last ? after : pos + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto advance = [&]() { pos += STRIDE; ro += STRIDE; ro = ro >= RB ? ro - RB : ro; };
+        auto finish = [&](auto tc, const RawRec<FMT, R, U> & wr) {
+            constexpr int t = decltype(tc)::value;
+            float acc[R];
+            rec_acc<FMT, R, U>(wr, ar, nbk, ln, acc);
+            wave_sum_n<R>(acc);
+            epi(tc, (int) (j0 + NC * t), acc);
+        };
+        if constexpr (PIPE) {
+            if constexpr (TF > 0) {
+                load(w[0], TF == 1 && !tail);
+                Unroll<0, TF>::run([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if constexpr (t + 1 < TF) { advance(); load(w[(t + 1) & 1], t + 2 == TF && !tail); }
+                    else if (tail) { advance(); load(w[(t + 1) & 1], true); }
+                    finish(tc, w[t & 1]);
+                });
+                if (tail) finish(std::integral_constant<int, TF>{}, w[TF & 1]);
+            } else {
+                load(w[0], true);
+                finish(std::integral_constant<int, 0>{}, w[0]);
+            }
         } else {
-            for (; j < n; j += NC) {
-                RawRec<FMT, R, U> w;
-                const unsigned pos = load(w, j);
-                release(j, pos);
-                float acc[R];
-                if (!(cs.dbg & 1)) { rec_acc<FMT, R, U>(w, ar, nbk, opq(cs.lane), acc); wave_sum_n<R>(acc); }
-                else { for (int r = 0; r < R; r++) acc[r] = 0.0f; }
-                epi((int) j, acc);
+            Unroll<0, TF>::run([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t > 0) advance();
+                load(w[0], t + 1 == TF && !tail);
+                finish(tc, w[0]);
+            });
+            if (tail) {
+                if constexpr (TF > 0) advance();
+                load(w[0], true);
+                finish(std::integral_constant<int, TF>{}, w[0]);
             }
         }
     }
@@ -631,7 +633,7 @@ struct R6 {
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         const RingShape sh = shape(p);
         Cons cs;
-        cs.cu = rg_cu(sh, blk); cs.lbase = 0; cs.rpos = 0; cs.roff = 0; cs.landed = 0; cs.dbg = __builtin_amdgcn_readfirstlane(p.dbg); cs.prof = false; cs.t_load = cs.t_dot = cs.t_epi = cs.t_mark = 0; cs.RB = __builtin_amdgcn_readfirstlane(p.ring_bytes); cs.c = c; cs.lane = lane;
+        cs.cu = rg_cu(sh, blk); cs.lbase = 0; cs.landed = 0; cs.RB = __builtin_amdgcn_readfirstlane(p.ring_bytes); cs.c = c; cs.lane = lane;
         const int mat = (blk * (4 * D / NBLK)) / D;   // which of r, k, v, g this workgroup's sets belong to
         const int cbase = (blk * (4 * D / NBLK)) % D;
         const bool has_dw1 = blk < p.DR;
@@ -667,7 +669,7 @@ struct R6 {
             if (pro) prologue_A(pl, l, pa, sout_l, blk == 0, opq(pt), opq(lane), 2u * li + 1u);
             fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 1u));
             R6STAMP(2);
-            run_phase<RG_W1, 1, UD, false>(cs, pl, l, qvec_at(l.q1, D), nb, [&](int j, const float (&res)[1]) {
+            rows<RG_W1, 1, UD, 0, false>(cs, pl, l, qvec_at(l.q1, D), nb, [&](auto, int j, const float (&res)[1]) {
                 if (lane == 0) tg_store(xr, p.tl + blk + NBLK * j, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
             });
             R6STAMP(3);
@@ -682,27 +684,22 @@ struct R6 {
                 sweep_end(l);
             }
             R6STAMP(4);
-            run_phase<RG_DW1, 1, UD, false>(cs, pl, l, qvec_at(l.actw, D), nb, [&](int, const float (&res)[1]) {
+            rows<RG_DW1, 1, UD, 0, false>(cs, pl, l, qvec_at(l.actw, D), nb, [&](auto, int, const float (&res)[1]) {
                 if (lane == 0) tg_store(xr, p.dl + blk, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
             });
             {
                 // all row sums first, then ONE epilogue: lane 2 t + r finishes row r of this wave's t-th set (the gate's silu is a double-
                 // precision exp: once per phase, not once per record) and lanes 0, 2, 4, ... store their set's unit with one instruction
-                constexpr int MAXT = (D * 4 / NBLK / 2 + NC - 1) / NC;
+                constexpr int NSET = D * 4 / NBLK / 2, MAXT = (NSET + NC - 1) / NC;
                 float all[2 * MAXT];
 #pragma unroll
                 for (int t = 0; t < 2 * MAXT; t++) all[t] = 0.0f;
                 const int j0 = (int) rg_first_j(cs.cu, RG_C, c);
                 if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 20] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_C]);
-                cs.prof = p.trace != nullptr && li == p.trace_layer && (p.dbg & 16);
-                cs.t_load = cs.t_dot = cs.t_epi = 0;
-                run_phase<RG_C, 2, UD, true>(cs, pl, l, qvec_at(l.act, D), nb, [&](int j, const float (&res)[2]) {
-                    const int t = (j - j0) / NC;
-#pragma unroll
-                    for (int tt = 0; tt < MAXT; tt++) if (tt == t) { all[2 * tt] = res[0]; all[2 * tt + 1] = res[1]; }
+                rows<RG_C, 2, UD, NSET / NC, true>(cs, pl, l, qvec_at(l.act, D), nb, [&](auto tc, int, const float (&res)[2]) {
+                    constexpr int t = decltype(tc)::value;
+                    all[2 * t] = res[0]; all[2 * t + 1] = res[1];
                 });
-                if (cs.prof && lane == 0) { long long * tr = p.trace + ((long long) blockIdx.x * 8 + wave) * 32; tr[16] = cs.t_load; tr[18] = cs.t_dot; tr[19] = cs.t_epi; }
-                cs.prof = false;
                 const int ln = opq(lane);
                 float v = pick_lane<2 * MAXT>(all, ln);
                 if (mat == 3) v = v / (1.0f + det_expf(-v));     // gate: silu
@@ -721,10 +718,9 @@ struct R6 {
             gather_meet(pl, l.fl + FL_GYQ, g1);
             sweep_end(l);
             R6STAMP(6);
-            run_phase<RG_E, 1, UD, true>(cs, pl, l, qvec_at(l.yq, D), nb, [&](int j, const float (&res)[1]) {
-                const int t = j / NC;
-#pragma unroll
-                for (int tt = 0; tt < XT; tt++) if (tt == t) xown[tt] = xown[tt] + res[0];
+            rows<RG_E, 1, UD, RE / NC, true>(cs, pl, l, qvec_at(l.yq, D), nb, [&](auto tc, int, const float (&res)[1]) {
+                constexpr int t = decltype(tc)::value;
+                xown[t] = xown[t] + res[0];
             });
             if (lane == 0) tg_store(xr, p.xatt + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XATT);
             R6STAMP(7);
@@ -739,17 +735,16 @@ struct R6 {
             fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 2u));
             R6STAMP(9);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 21] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_FK]);
-            run_phase<RG_FK, 2, UD, true>(cs, pl, l, qvec_at(l.q1, D), nb, [&](int j, const float (&res)[2]) {
+            rows<RG_FK, 2, UD, (UF * 64 > NBLK ? 32 : 16) / NC, true>(cs, pl, l, qvec_at(l.q1, D), nb, [&](auto, int j, const float (&res)[2]) {
                 const float v = lane == 1 ? res[1] : res[0];
                 const float t = v > 0.0f ? v : 0.0f;
                 if (lane < 2) l.out[2 * j + lane] = t * t;
             });
             fl_add(l.fl + FL_KEYS, 1u);
             R6STAMP(10);
-            run_phase<RG_FR, 1, UD, true>(cs, pl, l, qvec_at(l.q2, D), nb, [&](int j, const float (&res)[1]) {
-                const int t = j / NC;
-#pragma unroll
-                for (int tt = 0; tt < XT; tt++) if (tt == t) rrow[tt] = res[0];
+            rows<RG_FR, 1, UD, RE / NC, true>(cs, pl, l, qvec_at(l.q2, D), nb, [&](auto tc, int, const float (&res)[1]) {
+                constexpr int t = decltype(tc)::value;
+                rrow[t] = res[0];
             });
             {
                 const int nl = li + 1 < p.n_layers ? li + 1 : li;
@@ -765,14 +760,11 @@ struct R6 {
             sweep_end(l);
             R6STAMP(12);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 22] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_G]);
-            run_phase<RG_G, 1, UF, false>(cs, pl, l, qvec_at(l.kq, F), nbF, [&](int j, const float (&res)[1]) {
-                const int t = j / NC;
-#pragma unroll
-                for (int tt = 0; tt < XT; tt++) if (tt == t) {
-                    const float gte = sigmoid_f(rrow[tt]) * res[0];
-                    xown[tt] = xown[tt] + gte;
-                    if (li == p.n_layers - 1 && lane == 0) p.x[blk * RE + j] = xown[tt];
-                }
+            rows<RG_G, 1, UF, RE / NC, false>(cs, pl, l, qvec_at(l.kq, F), nbF, [&](auto tc, int j, const float (&res)[1]) {
+                constexpr int t = decltype(tc)::value;
+                const float gte = sigmoid_f(rrow[t]) * res[0];
+                xown[t] = xown[t] + gte;
+                if (li == p.n_layers - 1 && lane == 0) p.x[blk * RE + j] = xown[t];
             });
             if (lane == 0) tg_store(xr, p.xffn + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
             R6STAMP(13); R6RSTAMP(14);
