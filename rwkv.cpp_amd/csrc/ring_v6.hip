@@ -42,7 +42,7 @@ struct R6P {
     unsigned * ctl;                                    // [0] tag generation, [1] abort
     const unsigned char * stream; const R6Cu * cus;     // the per-workgroup weight streams
     int F, DR, R, H;
-    unsigned ring_bytes;                               // LDS ring (multiple of 1 KiB)
+    unsigned ring_bytes, mirror_bytes;                 // LDS ring (multiple of 4 KiB) and how much of its head is repeated behind its end
     int inflight, thin;                                // loader: DMA instructions in flight (normal / while the workgroup gathers)
     int nap;                                           // extra 64-cycle sleeps between two looks at a gather's sentinel unit
     int burst;                                         // loader: fills issued per round (between two looks at the consumers' positions)
@@ -99,44 +99,28 @@ __device__ __forceinline__ void fl_wait(Poll & pl, unsigned * f, unsigned want) 
 // ---------------------------------------------------------------------------------------------------------------
 template <int FMT, int R, int U> struct RawRec { RawBlk<FMT> raw[U][R]; };
 
-// byte `rel` of the record at ring offset `off`, for this lane (the ring wraps inside records)
-__device__ __forceinline__ unsigned ring_at(unsigned off, unsigned rel, unsigned RB) { const unsigned a = off + rel, a2 = a - RB; return a < a2 ? a : a2; }
-
+// A record is read linearly from its ring offset: the first `mirror` bytes of the ring exist a second time right behind its end (the
+// loader fills both), so a record that starts near the end continues there -- no wrap arithmetic, every read an immediate offset from
+// one base register per access width.
 template <int FMT, int R, int U>
-__device__ __forceinline__ void rec_load(RawRec<FMT, R, U> & w, const unsigned char * ring, unsigned RB, unsigned off, int lane) {
-    constexpr unsigned QS = QF<FMT>::QS, SCB = QF<FMT>::HM ? 4 : 2, QHB = QF<FMT>::QH ? 4 : 0;
-    constexpr unsigned SC0 = U * R * 64 * QS, QH0 = SC0 + U * R * 64 * SCB, BYTES = U * R * 64 * (QS + SCB + QHB);
-    if (off + BYTES <= RB) {
-        // the record does not wrap (the usual case): one base per access width, every read at an immediate offset
-        const unsigned char * b16 = ring + off + (unsigned) lane * 16u;
-        const unsigned char * bsc = ring + off + SC0 + (unsigned) lane * SCB;
-        const unsigned char * bqh = ring + off + QH0 + (unsigned) lane * 4u;
+__device__ __forceinline__ void rec_load(RawRec<FMT, R, U> & w, const unsigned char * ring, unsigned off, int lane) {
+    constexpr unsigned QS = QF<FMT>::QS, SCB = QF<FMT>::HM ? 4 : 2;
+    constexpr unsigned SC0 = U * R * 64 * QS, QH0 = SC0 + U * R * 64 * SCB;
+    const int4 * b16 = reinterpret_cast<const int4 *>(ring + off) + lane;
+    const unsigned char * bsc = ring + off + SC0 + (unsigned) lane * SCB;
+    const uint32_t * bqh = reinterpret_cast<const uint32_t *>(ring + off + QH0) + lane;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
+    for (int u = 0; u < U; u++) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                RawBlk<FMT> & o = w.raw[u][r];
-                const unsigned c0 = (unsigned) ((u * R + r) * (QS / 16)) * 1024u;
-                o.q[0] = *reinterpret_cast<const int4 *>(b16 + c0);
-                if constexpr (QS == 32) o.q[1] = *reinterpret_cast<const int4 *>(b16 + c0 + 1024u);
-                if constexpr (QF<FMT>::HM) o.sc = *reinterpret_cast<const uint32_t *>(bsc + (unsigned) (u * R + r) * 256u);
-                else o.sc = (unsigned) *reinterpret_cast<const uint16_t *>(bsc + (unsigned) (u * R + r) * 128u);
-                if constexpr (QF<FMT>::QH) o.qh = *reinterpret_cast<const uint32_t *>(bqh + (unsigned) (u * R + r) * 256u);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                RawBlk<FMT> & o = w.raw[u][r];
-                const unsigned c0 = (unsigned) ((u * R + r) * (QS / 16)) * 1024u + (unsigned) lane * 16u;
-                o.q[0] = *reinterpret_cast<const int4 *>(ring + ring_at(off, c0, RB));
-                if constexpr (QS == 32) o.q[1] = *reinterpret_cast<const int4 *>(ring + ring_at(off, c0 + 1024u, RB));
-                if constexpr (QF<FMT>::HM) o.sc = *reinterpret_cast<const uint32_t *>(ring + ring_at(off, SC0 + (unsigned) (u * R + r) * 256u + (unsigned) lane * 4u, RB));
-                else o.sc = (unsigned) *reinterpret_cast<const uint16_t *>(ring + ring_at(off, SC0 + (unsigned) (u * R + r) * 128u + (unsigned) lane * 2u, RB));
-                if constexpr (QF<FMT>::QH) o.qh = *reinterpret_cast<const uint32_t *>(ring + ring_at(off, QH0 + (unsigned) (u * R + r) * 256u + (unsigned) lane * 4u, RB));
-            }
+        for (int r = 0; r < R; r++) {
+            RawBlk<FMT> & o = w.raw[u][r];
+            constexpr int dummy = 0; (void) dummy;
+            const int c16 = (u * R + r) * (int) (QS / 16) * 64;
+            o.q[0] = b16[c16];
+            if constexpr (QS == 32) o.q[1] = b16[c16 + 64];
+            if constexpr (QF<FMT>::HM) o.sc = *reinterpret_cast<const uint32_t *>(bsc + (unsigned) (u * R + r) * 256u);
+            else o.sc = (unsigned) *reinterpret_cast<const uint16_t *>(bsc + (unsigned) (u * R + r) * 128u);
+            if constexpr (QF<FMT>::QH) o.qh = bqh[(u * R + r) * 64];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -156,19 +140,54 @@ __device__ __forceinline__ void act_load(ActRegs<U> & ar, const QVec & a, int nb
     }
 }
 
-// the record's rows against the activation registers: lane l accumulates blocks l, l + 64, ... in increasing order (per-lane partials)
+// The record's rows against the activation registers: lane l accumulates blocks l, l + 64, ... in increasing order (per-lane partials,
+// no butterfly). Written breadth first -- every block's codes unpacked, then the eight dot4 steps round-robin over the U x R blocks with
+// two integer accumulators each (integer sums are exact in any order), then the scales -- so that the U x R dependent chains interleave
+// instead of running back to back.
 template <int FMT, int R, int U>
 __device__ __forceinline__ void rec_acc(const RawRec<FMT, R, U> & w, const ActRegs<U> & ar, int nbk, int lane, float * acc) {
+    constexpr int GB = QF<FMT>::QS == 32 ? 2 : 4;     // blocks unpacked at a time (registers; Q8_0 blocks are twice the size)
+    constexpr int GU = (GB / R) < U ? ((GB / R) > 0 ? (GB / R) : 1) : U;
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const bool valid = u + 1 < U || u * WAVE + lane < nbk;   // (only the last step of a row can be short)
+    for (int u0 = 0; u0 < U; u0 += GU) {
+        WBlk<FMT> wb[GU][R];
+        int s0[GU][R], s1[GU][R];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            WBlk<FMT> wb;
-            unpack_raw<FMT>(wb, w.raw[u][r]);
-            acc[r] = blk_fma<FMT>(wb, ar.alo[u], ar.ahi[u], ar.dx[u], ar.sx[u], ar.asum[u], acc[r], valid);
+        for (int g = 0; g < GU; g++)
+#pragma unroll
+            for (int r = 0; r < R; r++) { if (u0 + g < U) unpack_raw<FMT>(wb[g][r], w.raw[u0 + g][r]); s0[g][r] = 0; s1[g][r] = 0; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int g = 0; g < GU; g++) {
+                if (u0 + g < U) {
+                    const int u = u0 + g;
+                    const int alo = k == 0 ? ar.alo[u].x : (k == 1 ? ar.alo[u].y : (k == 2 ? ar.alo[u].z : ar.alo[u].w));
+                    const int ahi = k == 0 ? ar.ahi[u].x : (k == 1 ? ar.ahi[u].y : (k == 2 ? ar.ahi[u].z : ar.ahi[u].w));
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        s0[g][r] = __builtin_amdgcn_sdot4(wb[g][r].c[k], alo, s0[g][r], false);
+                        s1[g][r] = __builtin_amdgcn_sdot4(wb[g][r].c[4 + k], ahi, s1[g][r], false);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GU; g++) {
+            if (u0 + g < U) {
+                const int u = u0 + g;
+                const bool valid = u + 1 < U || u * WAVE + lane < nbk;   // (only the last step of a row can be short)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    int sv = s0[g][r] + s1[g][r];
+                    if constexpr (QF<FMT>::OFF != 0) sv -= QF<FMT>::OFF * ar.asum[u];
+                    const float dd = wb[g][r].d * ar.dx[u];
+                    acc[r] = fmaf(dd, valid ? (float) sv : 0.0f, acc[r]);
+                    if constexpr (QF<FMT>::HM) acc[r] = fmaf(wb[g][r].m, valid ? ar.sx[u] : 0.0f, acc[r]);
+                }
+            }
         }
     }
 }
@@ -430,12 +449,30 @@ struct R6 {
     // -----------------------------------------------------------------------------------------------------------
     // loader wave
     // -----------------------------------------------------------------------------------------------------------
-    static __device__ __forceinline__ void dma_chunk(unsigned long long sbase, unsigned voff, unsigned m0dst) {
-        // (inline asm: M0 is not preserved around a statement, and through the builtin the compiler would wait for every DMA in flight
-        //  at the next LDS access; completion is counted by hand. The scalar base is produced by SALU instructions: no wait state.)
+    // Four consecutive 1-KiB fills as ONE statement: M0 (the LDS destination) is set once, the instruction offset advances the global
+    // AND the LDS address. (Inline asm: M0 is not preserved around a statement, and through the builtin the compiler would wait for every
+    // DMA in flight at the next LDS access; completion is counted by hand.) A wave issues at most one instruction every four cycles, so
+    // the loader's instruction count per fill IS its ceiling: 16 instructions per fill (scalar address arithmetic, M0 save / restore per
+    // fill) gave 23 GB/s alone in this kernel; this is 2 per fill.
+#ifndef R6_DMA_OFFSET_BOTH
+#define R6_DMA_OFFSET_BOTH 1
+#endif
+    template <bool NT>
+    static __device__ __forceinline__ void dma_quad(unsigned long long sbase, unsigned voff, unsigned m0dst) {
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0dst) : "memory");
+#if R6_DMA_OFFSET_BOTH
+#define R6_QUAD(POL) "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" \
+                     "global_load_lds_dwordx4 %1, %2" POL "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" POL "\n\t" \
+                     "global_load_lds_dwordx4 %1, %2 offset:2048" POL "\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072" POL "\n\ts_mov_b32 m0, %0"
+#else
+#define R6_QUAD(POL) "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" \
+                     "global_load_lds_dwordx4 %1, %2" POL "\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" POL "\n\t" \
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048" POL "\n\t" \
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072" POL "\n\ts_mov_b32 m0, %0"
+#endif
+        if constexpr (NT) asm volatile(R6_QUAD(" nt") : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0dst) : "memory");
+        else asm volatile(R6_QUAD("") : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0dst) : "memory");
+#undef R6_QUAD
     }
     static __device__ __forceinline__ void wait_vm(int w) {
         switch (w >> 2) {   // (immediate operand; multiples of four)
@@ -456,17 +493,17 @@ struct R6 {
         }
     }
     // The loader never waits for more than it must: `level` is a known upper bound of the DMA instructions still in flight (fills land in
-    // order, so everything before issued - level is in the ring). With room in the ring it issues up to `burst` fills per round, in
-    // straight-line groups of four, and only waits when more than `w` would be in flight; when the ring is full it retires the fills in
-    // flight a few at a time -- publishing them to the consumers and looking at their positions in between -- instead of draining the queue.
-    // (Measured with the loader alone in this kernel, RWKV_MI_RING_DBG=8: a round costs ~700 cycles + ~100 per fill as a rolled loop with a
-    //  look at the LDS words per round -- 3 GB/s per CU at one fill per round, 13 at eight, 19.5 at thirty-two; tools/ring_bench.hip: 27.)
+    // order, so everything before issued - level is in the ring). With room in the ring it issues up to `burst` groups of four fills per
+    // round and only waits when more than `w` would be in flight; when the ring is full it retires the fills in flight a few at a time --
+    // publishing them to the consumers and looking at their positions in between -- instead of draining the queue.
+    // The first `mirror` bytes of the ring are filled twice: once in place, once behind the ring's end (the copy first, so that "the
+    // fill has landed" covers it; its source lines stay in L2 for the second read: default policy, everything else is non-temporal).
     static __device__ __forceinline__ void loader_main(const R6P & p, const Lds & l, int lane) {
         const int wave = 0;
         const R6Cu cu = p.cus[blockIdx.x];
-        const unsigned total = __builtin_amdgcn_readfirstlane(cu.chunks);
+        const unsigned total = __builtin_amdgcn_readfirstlane(cu.chunks);          // fills (multiple of four)
         const unsigned long long src0 = (unsigned long long) p.stream + cu.base;
-        const unsigned RB = __builtin_amdgcn_readfirstlane(p.ring_bytes);
+        const unsigned RB = __builtin_amdgcn_readfirstlane(p.ring_bytes), MIR = __builtin_amdgcn_readfirstlane(p.mirror_bytes);
         const unsigned ring_m0 = __builtin_amdgcn_readfirstlane((unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) l.ring);
         const unsigned voff = (unsigned) lane * 16u;
         const int w_norm = __builtin_amdgcn_readfirstlane(p.inflight) & ~3, w_thin = __builtin_amdgcn_readfirstlane(p.thin) & ~3;
@@ -480,13 +517,9 @@ struct R6 {
         R6STAMP(0);
         unsigned stalls = 0, rounds = 0;
         unsigned long long sb = ((unsigned long long) s_hi << 32) | s_lo;
-        auto one = [&]() {
-            dma_chunk(sb, voff, ring_m0 + roff);
-            sb += 1024ull;
-            roff += 1024u; roff = roff >= RB ? 0u : roff;
-        };
+        unsigned * const fland = l.fl + FL_LANDED;
         for (unsigned spin = 0; issued < total;) {
-            const unsigned lim0 = min_done >= total * 1024u ? total : (min_done + RB) >> 10;
+            const unsigned lim0 = min_done >= total * 1024u ? total : ((min_done + RB) >> 12) << 2;
             const unsigned lim = lim0 < total ? lim0 : total;
             // the consumers' positions and the sweep counters for the NEXT round: the reads travel while this round's fills are issued
             asm volatile("" ::: "memory");
@@ -496,20 +529,26 @@ struct R6 {
             rounds++;
             if (issued < lim) {
                 spin = 0;
-                unsigned n = lim - issued;
+                unsigned n = (lim - issued) >> 2;
                 n = n < burst ? n : burst;
-                unsigned k = 0;
-                for (; k + 4u <= n; k += 4u) { one(); one(); one(); one(); }
-                for (; k < n; k++) one();
-                issued += n;
-                level += (int) n;
+                for (unsigned k = 0; k < n; k++) {
+                    if (roff < MIR) { dma_quad<false>(sb, voff, ring_m0 + RB + roff); dma_quad<true>(sb, voff, ring_m0 + roff); level += 8; }
+                    else { dma_quad<true>(sb, voff, ring_m0 + roff); level += 4; }
+                    sb += 4096ull;
+                    roff += 4096u; roff = roff >= RB ? 0u : roff;
+                }
+                issued += 4u * n;
                 if (level > w) { wait_vm(w); level = w; }
             } else {
                 stalls++;
                 if (level > 0) { const int x = (level - 1) & ~3; wait_vm(x); level = x; }
                 else if (lds_backoff(pl, spin++)) break;
             }
-            if (issued - (unsigned) level > landed) { landed = issued - (unsigned) level; fl_st(l.fl + FL_LANDED, landed); }
+            {
+                // (level counts instructions, a mirrored fill is two of them: issued - level never over-states what has landed)
+                const unsigned ld = issued > (unsigned) level ? issued - (unsigned) level : 0u;
+                if (ld > landed) { landed = ld; asm volatile("" ::: "memory"); __hip_atomic_store(fland, landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            }
             {
                 unsigned m = da.x < da.y ? da.x : da.y; m = m < da.z ? m : da.z; m = m < da.w ? m : da.w;
                 m = m < db.x ? m : db.x; m = m < db.y ? m : db.y; m = m < db.z ? m : db.z; m = m < db.w ? m : db.w;
@@ -548,8 +587,9 @@ struct R6 {
     // epi(integral_constant<t>, j, res) receives the row sums of the wave's t-th record (record j of the phase).
     // (The first version walked the records in a loop with the cursor in a struct: ~300 overhead instructions per record -- half of
     //  them scalar, forty branches -- around ~140 useful ones; a C phase took 13.7 k cycles for 3.6 k cycles of arithmetic.)
-    template <int PH, int R, int U, int TF, bool PIPE, typename EpiF>
+    template <int PH, int R, int U, int TF, bool PIPE_, typename EpiF>
     static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, EpiF && epi) {
+        constexpr bool PIPE = PIPE_ && QF<FMT>::QS == 16;   // (Q8_0 records are twice the registers: one buffer)
         constexpr unsigned RECB = (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0));
         constexpr unsigned STRIDE = NC * RECB;
         const unsigned n = cs.cu.n[PH];
@@ -577,18 +617,25 @@ struct R6 {
                 }
             }
             asm volatile("" ::: "memory");
-            rec_load<FMT, R, U>(wr, l.ring, RB, ro, ln);
+            rec_load<FMT, R, U>(wr, l.ring, ro, ln);
             // the reads above are in the LDS queue: the ring may be refilled up to this wave's next record (every lane writes the same word)
             asm volatile("" ::: "memory");
             __hip_atomic_store(dn, last ? after : pos + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        auto advance = [&]() { pos += STRIDE; ro += STRIDE; ro = ro >= RB ? ro - RB : ro; };
+        // (a wave's records are NC records apart: more than one lap of the ring for the long Q8_0 value rows)
+        auto advance = [&]() { pos += STRIDE; ro += STRIDE; ro = ro >= RB ? ro - RB : ro; if constexpr (STRIDE > 32768u) { ro = ro >= RB ? ro - RB : ro; ro = ro >= RB ? ro - RB : ro; } };
+        // per-lane partial sums of every record of the phase; ONE interleaved butterfly over all of them at the end (a butterfly is six
+        // dependent cross-lane steps: per record they ran back to back, two chains at a time)
+        float part[(TF + 1) * R];
+#pragma unroll
+        for (int i = 0; i < (TF + 1) * R; i++) part[i] = 0.0f;
         auto finish = [&](auto tc, const RawRec<FMT, R, U> & wr) {
             constexpr int t = decltype(tc)::value;
-            float acc[R];
-            rec_acc<FMT, R, U>(wr, ar, nbk, ln, acc);
-            wave_sum_n<R>(acc);
-            epi(tc, (int) (j0 + NC * t), acc);
+            rec_acc<FMT, R, U>(wr, ar, nbk, ln, part + t * R);
+            // (anchor: the arithmetic of record t stays in front of the ring reads of record t + 2 -- volatile statements keep their
+            //  order; without it the compiler issues every record's reads first and all the arithmetic behind the last landed check)
+#pragma unroll
+            for (int r = 0; r < R; r++) asm volatile("" :: "v"(part[t * R + r]));
         };
         if constexpr (PIPE) {
             if constexpr (TF > 0) {
@@ -616,6 +663,20 @@ struct R6 {
                 load(w[0], true);
                 finish(std::integral_constant<int, TF>{}, w[0]);
             }
+        }
+        wave_sum_n<(TF + 1) * R>(part);
+        Unroll<0, TF>::run([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            float res[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) res[r] = part[t * R + r];
+            epi(tc, (int) (j0 + NC * t), res);
+        });
+        if (tail) {
+            float res[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) res[r] = part[TF * R + r];
+            epi(std::integral_constant<int, TF>{}, (int) (j0 + NC * TF), res);
         }
     }
 
@@ -746,11 +807,6 @@ struct R6 {
                 constexpr int t = decltype(tc)::value;
                 rrow[t] = res[0];
             });
-            {
-                const int nl = li + 1 < p.n_layers ? li + 1 : li;
-                issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, opq(ppt));
-            }
-            __builtin_amdgcn_sched_barrier(0);
             R6STAMP(11);
             // ---- G: value projection, x += sigmoid(r) * (Wv k) ----
             gather_hint(pl, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap);
@@ -768,6 +824,11 @@ struct R6 {
             });
             if (lane == 0) tg_store(xr, p.xffn + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
             R6STAMP(13); R6RSTAMP(14);
+            {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
+                const int nl = li + 1 < p.n_layers ? li + 1 : li;
+                issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, opq(ppt));
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -1201,12 +1262,15 @@ void * ring_v6_create(const Model & m) {
     rg->variant = v; rg->n_blocks = NB;
     const R6Lds lo = r6_lds((int) D, (int) F);
     const size_t lds_max = 160 * 1024;
+    // the ring is filled in 4-KiB groups of four DMA instructions; its head is repeated behind its end for the longest record (rec_load)
+    const size_t max_rec_bytes = rg_rec_bytes(sh, 1, (int) F) > rg_rec_bytes(sh, 2, (int) D) ? rg_rec_bytes(sh, 1, (int) F) : rg_rec_bytes(sh, 2, (int) D);
+    const size_t mirror = (max_rec_bytes + 4095) / 4096 * 4096;
     size_t ring = (size_t) env_int("RWKV_MI_RING_KB", 1024) * 1024;
-    if (lo.fixed + 32 * 1024 > lds_max) { delete rg; return nullptr; }
-    if (ring > lds_max - lo.fixed) ring = lds_max - lo.fixed;
-    ring = ring / 1024 * 1024;
+    if (lo.fixed + mirror + 32 * 1024 > lds_max) { delete rg; return nullptr; }
+    if (ring > lds_max - lo.fixed - mirror) ring = lds_max - lo.fixed - mirror;
+    ring = ring / 4096 * 4096;
     if (ring < 32 * 1024) ring = 32 * 1024;
-    rg->lds = lo.fixed + ring;
+    rg->lds = lo.fixed + ring + mirror;
     if (hipFuncSetAttribute((const void *) g_ring_variants[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rg->lds) != hipSuccess) { delete rg; return nullptr; }
     // per-workgroup streams
     std::vector<R6Cu> hc(RG_NBLK);
@@ -1218,12 +1282,12 @@ void * ring_v6_create(const Model & m) {
         max_rec = nr > max_rec ? nr : max_rec;
         const uint64_t bytes = (uint64_t) cu.layer_bytes * n_layers;
         if (bytes + (1u << 20) > 0xFFFFFFFFull) { delete rg; return nullptr; }   // stream positions are 32-bit
-        hc[b].base = total; hc[b].chunks = (unsigned) ((bytes + RG_CHUNK - 1) / RG_CHUNK); hc[b].layer_bytes = cu.layer_bytes;
+        hc[b].base = total; hc[b].chunks = (unsigned) ((bytes + 4 * RG_CHUNK - 1) / (4 * RG_CHUNK)) * 4u; hc[b].layer_bytes = cu.layer_bytes;
         total += (uint64_t) hc[b].chunks * RG_CHUNK;
     }
     const size_t w2_layer = (size_t) 5 * R * D;
     bool ok = R % 4 == 0 && hipMalloc((void **) &rg->w2b, w2_layer * n_layers * sizeof(float)) == hipSuccess
-           && hipMalloc((void **) &rg->stream, total + RG_CHUNK) == hipSuccess
+           && hipMalloc((void **) &rg->stream, total + 4 * RG_CHUNK) == hipSuccess
            && hipMalloc((void **) &rg->d_cus, hc.size() * sizeof(R6Cu)) == hipSuccess
            && hipMemcpy(rg->d_cus, hc.data(), hc.size() * sizeof(R6Cu), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { ring_v6_destroy(rg); return nullptr; }
@@ -1292,15 +1356,15 @@ void * ring_v6_create(const Model & m) {
     q.ctl = rg->ctl;
     q.stream = rg->stream; q.cus = rg->d_cus;
     q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;
-    q.ring_bytes = (unsigned) ring;
+    q.ring_bytes = (unsigned) ring; q.mirror_bytes = (unsigned) mirror;
     auto snap = [](int w) { w &= ~3; return w < 4 ? 4 : (w > 52 ? 52 : w); };
-    q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 32));
+    q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 48));
     q.thin = snap(env_int("RWKV_MI_RING_THIN", 16));
     q.nap = env_int("RWKV_MI_RING_NAP", 2);
     q.dbg = env_int("RWKV_MI_RING_DBG", 0);
-    q.burst = env_int("RWKV_MI_RING_BURST", 16);
+    q.burst = env_int("RWKV_MI_RING_BURST", 24) / 4;   // in groups of four fills
     if (q.burst < 1) q.burst = 1;
-    if (q.burst > 32) q.burst = 32;
+    if (q.burst > 6) q.burst = 6;
     return rg;
 }
 

@@ -22,7 +22,7 @@
 constexpr int SLOT = 16384, NSLOT = 8, NT = 512;
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <int NCONS, int DEPTH, bool NTP>
+template <int NCONS, int DEPTH, bool NTP, bool SADDR = false>
 __global__ void __launch_bounds__(NT) k_ring(const unsigned char * __restrict__ buf, size_t bytes_per_cu, long long * __restrict__ sums) {
     static_assert(DEPTH >= 1 && DEPTH <= 4, "vmcnt has 6 bits: 16 DMA instructions per fill, at most 3 fills behind the one waited for");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -48,7 +48,14 @@ __global__ void __launch_bounds__(NT) k_ring(const unsigned char * __restrict__ 
                     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned) (s * SLOT + i * 1024));
                     const unsigned char * p = src + i * 1024;
                     unsigned keep;
-                    if (NTP) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+                    if (SADDR) {
+                        // scalar base + per-lane 32-bit offset (the form ring_v6.hip's loader uses)
+                        const unsigned long long sb = (unsigned long long) (mine + (size_t) f * SLOT + i * 1024);
+                        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) sb), hi = __builtin_amdgcn_readfirstlane((unsigned) (sb >> 32));
+                        const unsigned long long sbu = ((unsigned long long) hi << 32) | lo;
+                        const unsigned voff = (unsigned) lane * 16u;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbu), "s"(dst) : "memory");
+                    } else if (NTP) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
                     else     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
                 }
             }
@@ -95,10 +102,10 @@ __global__ void __launch_bounds__(NT) k_ring(const unsigned char * __restrict__ 
     if (lane == 0) atomicAdd((unsigned long long *) &sums[blockIdx.x], (unsigned long long) tot);
 }
 
-template <int NCONS, int DEPTH, bool NTP>
+template <int NCONS, int DEPTH, bool NTP, bool SADDR = false>
 static void run(const unsigned char * d_buf, size_t bytes_per_cu, long long * d_sums, const std::vector<long long> & want, int reps) {
     const size_t lds = (size_t) NSLOT * SLOT;
-    CK(hipFuncSetAttribute((const void *) k_ring<NCONS, DEPTH, NTP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    CK(hipFuncSetAttribute((const void *) k_ring<NCONS, DEPTH, NTP, SADDR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
@@ -106,7 +113,7 @@ static void run(const unsigned char * d_buf, size_t bytes_per_cu, long long * d_
     for (int r = 0; r < reps; r++) {
         CK(hipMemset(d_sums, 0, 256 * sizeof(long long)));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_ring<NCONS, DEPTH, NTP>), dim3(256), dim3(NT), lds, 0, d_buf, bytes_per_cu, d_sums);
+        hipLaunchKernelGGL((k_ring<NCONS, DEPTH, NTP, SADDR>), dim3(256), dim3(NT), lds, 0, d_buf, bytes_per_cu, d_sums);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms = 0;
@@ -117,7 +124,7 @@ static void run(const unsigned char * d_buf, size_t bytes_per_cu, long long * d_
         for (int b = 0; b < 256; b++) ok = ok && got[b] == want[b];
     }
     const double fills = (double) (bytes_per_cu / SLOT);
-    printf("cons %d depth %d %s: %8.3f ms  %6.3f us per 16-KiB fill  %6.1f GB/s per CU  %6.2f TB/s chip  sums %s\n", NCONS, DEPTH, NTP ? "nt     " : "default",
+    printf("cons %d depth %d %s: %8.3f ms  %6.3f us per 16-KiB fill  %6.1f GB/s per CU  %6.2f TB/s chip  sums %s\n", NCONS, DEPTH, SADDR ? "nt saddr" : (NTP ? "nt     " : "default"),
            best, best * 1e3 / fills, bytes_per_cu / (best * 1e-3) / 1e9, 256.0 * bytes_per_cu / (best * 1e-3) / 1e12, ok ? "OK" : "WRONG");
 }
 
@@ -142,5 +149,8 @@ int main(int argc, char ** argv) {
     run<4, 4, false>(d_buf, bytes_per_cu, d_sums, want, reps);
     run<7, 4, true>(d_buf, bytes_per_cu, d_sums, want, reps);
     run<7, 1, true>(d_buf, bytes_per_cu, d_sums, want, reps);
+    run<4, 2, true, true>(d_buf, bytes_per_cu, d_sums, want, reps);
+    run<4, 4, true, true>(d_buf, bytes_per_cu, d_sums, want, reps);
+    run<0, 2, true>(d_buf, bytes_per_cu, d_sums, want, reps);
     return 0;
 }
