@@ -151,13 +151,42 @@ def cpu_baseline(path, first_token, budget_s):
         el = time.time() - t_start
         if n >= 2 and (el + el / n > budget_s or n >= 64):
             break
+    final = (np.array(logits, copy=True), np.array(state, copy=True))
     om.free()
     return {"value": n / el, "unit": "tokens/s", "cores": cores, "kind": "port", "simd": simd,
             "sample": f"{n} greedy decode tokens of the same model file on the host CPU ({el:.1f}s, load {load_s:.1f}s); "
-                      f"ggml's CPU algorithm restated with {simd} block dots, OpenMP over rows"}, toks
+                      f"ggml's CPU algorithm restated with {simd} block dots, OpenMP over rows"}, toks, final
 
 
-KERNEL_NAMES = {2: "k6_mega (persistent decode kernel: all layers of the stage in one launch)",
+def load_leg(pkg, lib, path, spec):
+    """File -> HBM with the file's pages dropped from the page cache first (fsync + POSIX_FADV_DONTNEED; a tmpfs cannot drop them and the
+    figure then equals the warm one): parallel pread into pinned staging buffers, asynchronous copies, re-pack kernels (model.hip)."""
+    if os.environ.get("RWKV_BENCH_NO_COLD") == "1":
+        return {}
+    try:
+        fd = os.open(path, os.O_RDONLY)
+        os.fsync(fd)
+        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        os.close(fd)
+        prev = os.environ.get("RWKV_MI_NO_AUTOTUNE")
+        os.environ["RWKV_MI_NO_AUTOTUNE"] = "1"      # (this context only measures the load: no path calibration)
+        try:
+            m = pkg.RWKVModel(lib, path, thread_count=1, gpu_layer_count=spec.n_layer + 1)
+            sec, nbytes = m.load_stats()
+            m.free()
+        finally:
+            if prev is None:
+                del os.environ["RWKV_MI_NO_AUTOTUNE"]
+            else:
+                os.environ["RWKV_MI_NO_AUTOTUNE"] = prev
+        return {"cold_seconds": sec, "cold_GBps": nbytes / max(sec, 1e-9) / 1e9,
+                "what": "payload of the model file -> HBM (reads + copies + re-pack); cold = after fsync + POSIX_FADV_DONTNEED on the file"}
+    except Exception as e:   # noqa: BLE001
+        return {"cold_error": repr(e)}
+
+
+KERNEL_NAMES = {2: "k6_ring (persistent decode kernel: all layers of the stage in one launch, weights streamed through an LDS ring by LDS-DMA)",
+                3: "k6_mega (persistent decode kernel: all layers of the stage in one launch, weights prefetched into registers)",
                 1: "fused single-token layer kernels (quantised row phases)",
                 0: "k_mvq_t1 (quantised single-token projection)"}
 
@@ -165,9 +194,12 @@ KERNEL_NAMES = {2: "k6_mega (persistent decode kernel: all layers of the stage i
 def bench_decode(args, pkg, lib, path, spec, torch):
     """One step = one decoded token (embedding row, every layer, ln_out, head, on-device argmax), state resident in HBM."""
     import numpy as np
+    load = load_leg(pkg, lib, path, spec)
     t0 = time.time()
     model = pkg.RWKVModel(lib, path, thread_count=1, gpu_layer_count=spec.n_layer + 1)
     load_s = time.time() - t0
+    sec, nbytes = model.load_stats()
+    load.update({"warm_seconds": sec, "bytes": nbytes, "warm_GBps": nbytes / max(sec, 1e-9) / 1e9, "context_seconds": load_s})
     bpt = model.bytes_per_token()
     first = 1103515245 % spec.n_vocab
     model.state_load(None)
@@ -185,42 +217,47 @@ def bench_decode(args, pkg, lib, path, spec, torch):
         "ms_per_step": wall_s * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": DTYPE_DESC.get(args.dtype, args.dtype), "data": "synthetic",
         "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode, state resident in HBM", "layers": spec.n_layer,
-                   "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": "1 GPU", "decode_path": path_id},
+                   "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": "1 GPU", "decode_path": path_id, "persist_kind": model.persist_kind()},
         "hbm": {"algorithmic_bytes_per_token": bpt, "achieved_GBps": bpt * tok_s / 1e9, "frac_of_8TBps": bpt * tok_s / 1e9 / HBM_PEAK_GBS,
                 "hip_event_ms_per_token": ev_ms / args.steps},
-        "load_seconds": load_s,
+        "load_seconds": load_s, "load": load,
     }
     if not args.no_profile:
         p = model.profile_decode(first, min(args.steps, 32))
         if p["launches"] > 0:
             ach = p["bytes"] / max(p["kernel_ms"], 1e-9) / 1e6
             traffic, traffic_src = pmc_traffic(path_id, args)
-            result["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAMES[path_id] + f" [{args.dtype}]", "achieved": ach,
+            kname = KERNEL_NAMES[3 if (path_id == 2 and model.persist_kind() == 1) else path_id]
+            result["roofline"] = {"bound": "hbm", "kernel": kname + f" [{args.dtype}]", "achieved": ach,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                   "launches": p["launches"], "avg_launch_us": p["kernel_ms"] * 1e3 / p["launches"],
                                   "avg_bytes_per_launch": p["bytes"] / p["launches"]}
-    # GPU tokens for the parity leg: a fresh state, and -- on the persistent path -- the rolling hand-over tag preset so that
-    # the compared tokens cross its 16-bit wrap (it advances 8 per layer: every 256 tokens at 32 layers).
-    gpu_toks, wrap = None, False
-    if args.parity_tokens > 0 and args.cpu_seconds > 0:
-        if path_id == 2:
-            wrap = model.test_set_tag(0x10000 - 8 * spec.n_layer * (args.parity_tokens // 4))
-        model.state_load(None)
-        gpu_toks, _ = model.decode_greedy(first, args.parity_tokens)
-        healthy = model.healthy()
     if args.abi_tokens > 0:
         result["abi"] = abi_rate(model, first, args.abi_tokens)
-    model.free()
     if args.cpu_seconds > 0:
-        result["cpu_baseline"], cpu_toks = cpu_baseline(path, first, args.cpu_seconds)
-        if gpu_toks is not None:
-            n = min(len(cpu_toks), len(gpu_toks))
-            equal = bool(n > 0 and list(gpu_toks[:n]) == list(cpu_toks[:n]) and healthy)
-            result["parity"] = {"tokens_checked": n, "equal": equal, "crosses_tag_wrap": bool(wrap and n > args.parity_tokens // 4),
-                                "what": "greedy tokens of rwkv_mi_decode_greedy on this file vs the CPU oracle's from the same first token and a fresh state"}
+        # The CPU oracle (checker and reported baseline) decodes n greedy tokens of the same file within its budget; the GPU then decodes
+        # exactly n tokens from a fresh state -- on the persistent path with the rolling hand-over tag preset so that they cross its
+        # 16-bit wrap (it advances 8 per layer: every 256 tokens at 32 layers) -- and tokens, the last token's LOGITS and the whole
+        # recurrent STATE must be equal bit for bit (argmax alone would hide low-order differences).
+        result["cpu_baseline"], cpu_toks, (cpu_logits, cpu_state) = cpu_baseline(path, first, args.cpu_seconds)
+        n = min(len(cpu_toks), args.parity_tokens)
+        if n > 0 and n == len(cpu_toks):
+            wrap = path_id == 2 and model.test_set_tag(0x10000 - 8 * spec.n_layer * max(1, n // 2))
+            model.state_load(None)
+            gpu_toks, _ = model.decode_greedy(first, n)
+            gpu_logits, gpu_state = model.logits_store(), model.state_store()
+            healthy = model.healthy()
+            eq_t = list(gpu_toks[:n]) == list(cpu_toks[:n])
+            eq_l, eq_s = bool(np.array_equal(gpu_logits, cpu_logits)), bool(np.array_equal(gpu_state, cpu_state))
+            equal = bool(eq_t and eq_l and eq_s and healthy)
+            result["parity"] = {"tokens_checked": n, "equal": equal, "tokens_equal": eq_t, "logits_equal": eq_l, "state_equal": eq_s,
+                                "crosses_tag_wrap": bool(wrap),
+                                "what": "n greedy tokens of rwkv_mi_decode_greedy on this file from a fresh state vs the CPU oracle's: token ids, the last "
+                                        "token's logits and the whole state, np.array_equal"}
             if not equal:
                 print(json.dumps(result))
-                raise SystemExit(f"[bench] PARITY FAILURE: GPU greedy tokens differ from the CPU oracle's within the first {n} tokens")
+                raise SystemExit(f"[bench] PARITY FAILURE: GPU != CPU oracle after {n} greedy tokens (tokens {eq_t}, logits {eq_l}, state {eq_s}, healthy {healthy})")
+    model.free()
     return result
 
 
@@ -268,7 +305,7 @@ def bench_prefill(args, pkg, lib, path, spec, torch):
         oracle_lib.lib().orc_set_threads(usable_cores())
         oracle_lib.lib().orc_set_fast(1)
         om = oracle_lib.OracleModel(path)
-        n = min(T, 48)
+        n = min(T, max(48, args.parity_tokens))   # --parity-tokens 1024: the whole benchmarked pass (the oracle needs ~20 s for it)
         t0 = time.time()
         ol, ost = om.eval_sequence(prompt[:n], om.init_state())
         cpu_s = time.time() - t0

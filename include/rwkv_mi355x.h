@@ -69,6 +69,10 @@ RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx);
  * model qualifies), 1 = weights prefetched into the registers of the waves that use them (RWKV_MI_PERSIST=regs), 0 = path 2 not active. */
 RWKV_API int rwkv_mi_persist_kind(const struct rwkv_context * ctx);
 
+/* How long the payload of the model file took to reach HBM at rwkv_init_from_file (parallel reads into pinned staging buffers,
+ * asynchronous copies, re-pack kernels; the reference reads one tensor at a time, rwkv_file_format.inc:302-313), and its bytes. */
+RWKV_API void rwkv_mi_load_stats(const struct rwkv_context * ctx, double * seconds, uint64_t * bytes);
+
 /* Waits for the context's stream and reports whether every persistent-kernel step so far completed (false: a poll timed out
  * because not all workgroups could be resident -- the device is shared, or other kernels held CUs for seconds; results since
  * then are invalid and the context should be re-created with RWKV_MI_NO_MEGA=1). Always true on paths 0 and 1. */

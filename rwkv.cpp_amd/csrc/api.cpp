@@ -455,6 +455,15 @@ RWKV_API bool rwkv_mi_decode_healthy(struct rwkv_context * ctx) {
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx) { return ctx->mega ? 2 : ((ctx->fused_v6 || ctx->fused_v7 || ctx->fused_v4) ? 1 : 0); }
 RWKV_API int rwkv_mi_persist_kind(const struct rwkv_context * ctx) { return mega_v6_kind(ctx->mega); }
 
+// seconds the payload of the model file took to reach HBM (reads + host-to-device copies + re-pack kernels), and its bytes
+RWKV_API void rwkv_mi_load_stats(const struct rwkv_context * ctx, double * seconds, uint64_t * bytes) {
+    double s = 0.0; uint64_t b = 0;
+    if (ctx->stages.empty()) { s = ctx->model->load_seconds; b = ctx->model->weight_bytes; }
+    else for (const rwkv_context * st : ctx->stages) { s += st->model->load_seconds; b += st->model->weight_bytes; }
+    if (seconds) *seconds = s;
+    if (bytes) *bytes = b;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Layer pipeline (one process per GPU; the hand-off itself is done by the caller with RCCL send/recv)
 // ---------------------------------------------------------------------------------------------------------------

@@ -51,6 +51,7 @@ struct Model {
     int device = 0;
     uint64_t bytes_per_token = 0; // algorithmic bytes of one decoded token on this stage
     uint64_t weight_bytes = 0;
+    double load_seconds = 0.0;    // file payload -> HBM (pass 2 of load_model: reads, copies, re-pack kernels)
 
     std::atomic<int> refcount{0};
 

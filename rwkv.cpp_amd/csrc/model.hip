@@ -4,11 +4,16 @@
 // What is new: every parameter goes to one HBM arena; quantised tensors are re-packed into aligned planes on the GPU.
 #include "model.h"
 
+#include <atomic>
+#include <cerrno>
+#include <chrono>
 #include <cinttypes>
+#include <condition_variable>
 #include <cstring>
 #include <fcntl.h>
-#include <sys/mman.h>
+#include <mutex>
 #include <sys/stat.h>
+#include <thread>
 #include <unistd.h>
 
 namespace rwkvmi {
@@ -19,16 +24,6 @@ namespace rwkvmi {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace {
-
-struct MappedFile {
-    int fd = -1;
-    uint8_t * base = nullptr;
-    size_t size = 0;
-    ~MappedFile() {
-        if (base) munmap(base, size);
-        if (fd >= 0) close(fd);
-    }
-};
 
 struct PlaneSizes { size_t data = 0, qs = 0, qh = 0, sc = 0; };
 
@@ -305,38 +300,17 @@ Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end) 
     m->arena_bytes = total;
     struct ArenaGuard { Model * m; bool armed = true; ~ArenaGuard() { if (armed && m->arena) { (void) hipFree(m->arena); m->arena = nullptr; } } } aguard{m.get()};
 
-    // Two raw staging buffers for quantised payloads: the upload of tensor i+1 overlaps the re-pack of tensor i, and a
-    // buffer is only rewritten after the re-pack kernel that read it has finished (explicit event, not stream order:
-    // pageable-memory copies are staged by the runtime and must not be assumed to queue behind earlier kernels).
-    void * d_raw[2] = {nullptr, nullptr};
-    hipEvent_t raw_free[2] = {nullptr, nullptr};
-    struct RawGuard {
-        void ** p; hipEvent_t * e;
-        ~RawGuard() { for (int i = 0; i < 2; i++) { if (p[i]) (void) hipFree(p[i]); if (e[i]) (void) hipEventDestroy(e[i]); } }
-    } rguard{d_raw, raw_free};
-    if (max_raw) {
-        for (int i = 0; i < 2; i++) {
-            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_ALLOC, hipMalloc(&d_raw[i], max_raw));
-            HIP_OK_OR(nullptr, RWKV_ERROR_CTX, hipEventCreateWithFlags(&raw_free[i], hipEventDisableTiming));
-        }
-    }
-    int raw_idx = 0;
-    bool raw_used[2] = {false, false};
-
-    // pass 2: payloads. The file is mapped and copied straight from the page cache.
-    MappedFile mf;
-    mf.fd = open(path, O_RDONLY);
-    RW_CHECK(RWKV_ERROR_FILE | RWKV_ERROR_FILE_OPEN, nullptr, mf.fd >= 0, "Failed to open file %s", path);
-    mf.size = (size_t) file_size;
-    void * map = mmap(nullptr, mf.size, PROT_READ, MAP_PRIVATE, mf.fd, 0);
-    RW_CHECK(RWKV_ERROR_FILE | RWKV_ERROR_FILE_READ, nullptr, map != MAP_FAILED, "Failed to map file %s", path);
-    mf.base = (uint8_t *) map;
-    (void) madvise(map, mf.size, MADV_SEQUENTIAL);
-
-    hipStream_t st0 = nullptr;
-    HIP_OK_OR(nullptr, RWKV_ERROR_CTX, hipStreamCreate(&st0));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) (void) hipStreamDestroy(s); } } sguard{st0};
-
+    // pass 2: payloads (the reference does one malloc / fread / ggml_backend_tensor_set per tensor,
+    // rwkv_file_format.inc:302-313). The wanted tensors are cut into pieces of at most k_piece bytes; a small pool of reader threads
+    // pread()s the pieces, in file order, into a ring of PINNED host buffers; this thread enqueues, per piece and in order, the
+    // host-to-device copy (a real DMA from pinned memory, asynchronous -- a copy out of a pageable mapping is staged synchronously inside
+    // the runtime) and, for quantised payloads and the RWKV-6 mix matrix, the re-pack / transpose kernel out of a device staging
+    // buffer. Reads, copies and kernels of different pieces overlap; a slot is refilled when the event behind its last use has completed.
+    const auto t_load0 = std::chrono::steady_clock::now();
+    constexpr size_t k_piece = (size_t) 32 << 20;
+    constexpr int k_slots = 4, k_readers = 4;
+    struct Piece { const TensorInfo * t; DevTensor * dt; uint64_t off, bytes; int64_t blk0, nblk; int kind; };   // kind 0 plain, 1 quantised, 2 w2
+    std::vector<Piece> pieces;
     uint8_t * cursor = (uint8_t *) m->arena;
     for (const TensorInfo & t : infos) {
         if (!wanted(t)) continue;
@@ -344,37 +318,118 @@ Model * load_model(const char * path, uint32_t layer_begin, uint32_t layer_end) 
         dt->name = t.name; dt->type = t.type; dt->ndim = t.ndim; dt->nbytes = t.nbytes;
         for (int i = 0; i < 3; i++) dt->ne[i] = t.ne[i];
         const PlaneSizes p = plane_sizes(t);
-        const uint8_t * src = mf.base + t.file_offset;
         const bool w2 = t.type == T_F32 && t.ndim == 3 && t.name.find("att.time_maa_w2") != std::string::npos && t.ne[2] == 5;
-        if (w2) {
-            // v6 mix matrix: stored transposed ([5][R][D]) so that the mix kernels read it coalesced
+        if (!dtype_quantized(t.type)) {
             dt->data = cursor; cursor += p.data;
-            if (raw_used[raw_idx]) HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipEventSynchronize(raw_free[raw_idx]));
-            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipMemcpyAsync(d_raw[raw_idx], src, t.nbytes, hipMemcpyHostToDevice, st0));
-            launch_transpose_w2((const float *) d_raw[raw_idx], (float *) dt->data, t.ne[1], t.ne[0], st0);
-            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipEventRecord(raw_free[raw_idx], st0));
-            raw_used[raw_idx] = true;
-            raw_idx ^= 1;
-        } else if (!dtype_quantized(t.type)) {
-            dt->data = cursor; cursor += p.data;
-            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipMemcpyAsync(dt->data, src, t.nbytes, hipMemcpyHostToDevice, st0));
+            if (w2) {
+                // v6 mix matrix: stored transposed ([5][R][D]) so that the mix kernels read it coalesced -- one piece
+                RW_CHECK(RWKV_ERROR_MODEL_PARAMS | RWKV_ERROR_UNSUPPORTED, nullptr, t.nbytes <= k_piece, "Parameter %s is too large for the load pipeline", t.name.c_str());
+                pieces.push_back(Piece{&t, dt.get(), 0, t.nbytes, 0, 0, 2});
+            } else {
+                for (uint64_t o = 0; o < t.nbytes; o += k_piece) pieces.push_back(Piece{&t, dt.get(), o, t.nbytes - o < k_piece ? t.nbytes - o : k_piece, 0, 0, 0});
+            }
         } else {
             dt->qs = cursor; cursor += p.qs;
             if (p.qh) { dt->qh = (uint32_t *) cursor; cursor += p.qh; }
             dt->sc = cursor; cursor += p.sc;
-            if (raw_used[raw_idx]) HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipEventSynchronize(raw_free[raw_idx]));
-            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipMemcpyAsync(d_raw[raw_idx], src, t.nbytes, hipMemcpyHostToDevice, st0));
-            launch_repack(t.type, (const uint8_t *) d_raw[raw_idx], t.nelements() / 32, dt->qs, dt->qh, dt->sc, st0);
-            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipEventRecord(raw_free[raw_idx], st0));
-            raw_used[raw_idx] = true;
-            raw_idx ^= 1;
+            const uint64_t bsz = dtype_block_bytes(t.type);
+            const int64_t nblk = t.nelements() / 32, per = (int64_t) (k_piece / bsz);
+            for (int64_t b0 = 0; b0 < nblk; b0 += per) {
+                const int64_t nb = nblk - b0 < per ? nblk - b0 : per;
+                pieces.push_back(Piece{&t, dt.get(), (uint64_t) b0 * bsz, (uint64_t) nb * bsz, b0, nb, 1});
+            }
         }
         m->weight_bytes += t.nbytes;
         m->by_name[dt->name] = dt.get();
         m->tensors.push_back(std::move(dt));
     }
-    HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipStreamSynchronize(st0));
+
+    struct Pipe {
+        int fd = -1;
+        void * h[k_slots] = {}; void * d[k_slots] = {}; hipEvent_t ev[k_slots] = {};
+        hipStream_t st = nullptr;
+        std::vector<std::thread> th;
+        std::mutex mu; std::condition_variable cv;
+        std::vector<int> state;          // per piece: 0 not read, 1 read (slot filled), 2 enqueued (event recorded), -1 read error
+        std::atomic<size_t> next{0};
+        bool stop = false;
+        ~Pipe() {
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            for (std::thread & t : th) if (t.joinable()) t.join();
+            if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
+            for (int i = 0; i < k_slots; i++) { if (h[i]) (void) hipHostFree(h[i]); if (d[i]) (void) hipFree(d[i]); if (ev[i]) (void) hipEventDestroy(ev[i]); }
+            if (fd >= 0) close(fd);
+        }
+    } pp;
+    pp.fd = open(path, O_RDONLY);
+    RW_CHECK(RWKV_ERROR_FILE | RWKV_ERROR_FILE_OPEN, nullptr, pp.fd >= 0, "Failed to open file %s", path);
+    (void) posix_fadvise(pp.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    HIP_OK_OR(nullptr, RWKV_ERROR_CTX, hipStreamCreateWithFlags(&pp.st, hipStreamNonBlocking));
+    bool any_staged = false;
+    for (const Piece & pc : pieces) any_staged = any_staged || pc.kind != 0;
+    for (int i = 0; i < k_slots && !pieces.empty(); i++) {
+        HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_ALLOC, hipHostMalloc(&pp.h[i], k_piece, hipHostMallocDefault));
+        if (any_staged) HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_ALLOC, hipMalloc(&pp.d[i], k_piece));
+        HIP_OK_OR(nullptr, RWKV_ERROR_CTX, hipEventCreateWithFlags(&pp.ev[i], hipEventDisableTiming));
+    }
+    pp.state.assign(pieces.size(), 0);
+    auto reader = [&pp, &pieces, device]() {
+        (void) hipSetDevice(device);
+        for (;;) {
+            const size_t i = pp.next.fetch_add(1);
+            if (i >= pieces.size()) return;
+            const int slot = (int) (i % k_slots);
+            if (i >= (size_t) k_slots) {
+                // the slot's previous piece must have been enqueued (event recorded) and its copy / kernel finished
+                std::unique_lock<std::mutex> lk(pp.mu);
+                pp.cv.wait(lk, [&] { return pp.stop || pp.state[i - k_slots] == 2; });
+                if (pp.stop) return;
+                lk.unlock();
+                if (hipEventSynchronize(pp.ev[slot]) != hipSuccess) { std::lock_guard<std::mutex> g(pp.mu); pp.state[i] = -1; pp.cv.notify_all(); return; }
+            }
+            const Piece & pc = pieces[i];
+            uint64_t done = 0;
+            bool ok = true;
+            while (done < pc.bytes) {
+                const ssize_t r = pread(pp.fd, (uint8_t *) pp.h[slot] + done, pc.bytes - done, (off_t) (pc.t->file_offset + pc.off + done));
+                if (r <= 0) { if (r < 0 && errno == EINTR) continue; ok = false; break; }
+                done += (uint64_t) r;
+            }
+            { std::lock_guard<std::mutex> g(pp.mu); pp.state[i] = ok ? 1 : -1; }
+            pp.cv.notify_all();
+            if (!ok) return;
+        }
+    };
+    for (int i = 0; i < k_readers && (size_t) i < pieces.size(); i++) pp.th.emplace_back(reader);
+    for (size_t i = 0; i < pieces.size(); i++) {
+        const Piece & pc = pieces[i];
+        const int slot = (int) (i % k_slots);
+        {
+            std::unique_lock<std::mutex> lk(pp.mu);
+            pp.cv.wait(lk, [&] { return pp.state[i] != 0; });
+            RW_CHECK(RWKV_ERROR_FILE | RWKV_ERROR_FILE_READ, nullptr, pp.state[i] == 1, "Failed to read parameter %s from %s", pc.t->name.c_str(), path);
+        }
+        DevTensor * dt = pc.dt;
+        if (pc.kind == 0) {
+            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipMemcpyAsync((uint8_t *) dt->data + pc.off, pp.h[slot], pc.bytes, hipMemcpyHostToDevice, pp.st));
+        } else {
+            HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipMemcpyAsync(pp.d[slot], pp.h[slot], pc.bytes, hipMemcpyHostToDevice, pp.st));
+            if (pc.kind == 2) {
+                launch_transpose_w2((const float *) pp.d[slot], (float *) dt->data, pc.t->ne[1], pc.t->ne[0], pp.st);
+            } else {
+                const int64_t qsb = pc.t->type == T_Q8_0 ? 32 : 16, scb = (pc.t->type == T_Q4_1 || pc.t->type == T_Q5_1) ? 4 : 2;
+                launch_repack(pc.t->type, (const uint8_t *) pp.d[slot], pc.nblk, dt->qs + pc.blk0 * qsb, dt->qh ? dt->qh + pc.blk0 : nullptr,
+                              (uint8_t *) dt->sc + pc.blk0 * scb, pp.st);
+            }
+        }
+        HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipEventRecord(pp.ev[slot], pp.st));
+        { std::lock_guard<std::mutex> g(pp.mu); pp.state[i] = 2; }
+        pp.cv.notify_all();
+    }
+    HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipStreamSynchronize(pp.st));
     HIP_OK_OR(nullptr, RWKV_ERROR_MODEL | RWKV_ERROR_DATA, hipGetLastError());
+    m->load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load0).count();
 
     if (!bind_params(*m)) return nullptr;
 

@@ -115,6 +115,8 @@ class RWKVSharedLibrary:
         L.rwkv_mi_decode_path.restype = ctypes.c_int
         L.rwkv_mi_persist_kind.argtypes = [c_ctx]
         L.rwkv_mi_persist_kind.restype = ctypes.c_int
+        L.rwkv_mi_load_stats.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+        L.rwkv_mi_load_stats.restype = None
         L.rwkv_mi_decode_healthy.argtypes = [c_ctx]
         L.rwkv_mi_decode_healthy.restype = ctypes.c_bool
         L.rwkv_mi_sample.argtypes = [c_ctx, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, P_UINT32]
@@ -300,6 +302,13 @@ class RWKVModel:
             raise ValueError("rwkv_mi_state_store failed")
         return s
 
+    def logits_store(self) -> np.ndarray:
+        """Logits of the last step that produced any (device -> host; synchronises the context's stream)."""
+        lg = np.empty(self._logits_buffer_element_count, dtype=np.float32)
+        if not self._library.library.rwkv_mi_logits_store(self._ctx.ptr, ctypes.cast(_ptr(lg), P_FLOAT)):
+            raise ValueError("rwkv_mi_logits_store failed")
+        return lg
+
     def eval_resident(self, tokens: List[int], want_logits: bool = True) -> Optional[np.ndarray]:
         arr = (ctypes.c_uint32 * len(tokens))(*tokens)
         logits = np.empty(self._logits_buffer_element_count, dtype=np.float32) if want_logits else None
@@ -358,6 +367,12 @@ class RWKVModel:
     def persist_kind(self) -> int:
         """Persistent kernel behind decode path 2: 2 = LDS-DMA weight ring, 1 = register prefetch, 0 = none."""
         return int(self._library.library.rwkv_mi_persist_kind(self._ctx.ptr))
+
+    def load_stats(self) -> Tuple[float, int]:
+        """(seconds, bytes) of the model file's payload on its way to HBM at creation."""
+        sec, b = ctypes.c_double(0.0), ctypes.c_uint64(0)
+        self._library.library.rwkv_mi_load_stats(self._ctx.ptr, ctypes.byref(sec), ctypes.byref(b))
+        return float(sec.value), int(b.value)
 
     def healthy(self) -> bool:
         return bool(self._library.library.rwkv_mi_decode_healthy(self._ctx.ptr))

@@ -77,3 +77,27 @@ def test_sequence_pass_on_the_real_head_geometry(tmp_path):
     assert np.array_equal(gl, ol) and np.array_equal(gst, ost)
     m.free()
     om.free()
+
+
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q5_1"])
+def test_full_length_pass_matches_the_oracle(tmp_path, fmt):
+    """The pass that bench.py --mode prefill times is 1024 tokens: 16 token tiles per 128-row panel, the XCD-aware block map and the split
+    walks + k_mmq_combine at full occupancy -- none of which a 200-token pass exercises. Same geometry (D = 2048, F = 7168, 3 layers),
+    T = 1024, logits and state bit for bit against the oracle, and again through rwkv_eval_sequence_in_chunks (reference
+    tests/test_eval_sequence_in_chunks.c:54 asks for memcmp equality of the two)."""
+    library()
+    O.lib().orc_set_fast(1)
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS["mega-v6-2048"]
+    synth.write_model(p, spec, fmt, seed=43)
+    toks = [int((1103515245 * i + 12345) % spec.n_vocab) for i in range(1024)]
+    om = O.OracleModel(p)
+    ol, ost = om.eval_sequence(toks, om.init_state())
+    m = model(p)
+    gl, gst = m.eval_sequence(toks, None)
+    assert np.array_equal(gl, ol), float(np.abs(gl - ol).max())
+    assert np.array_equal(gst, ost), float(np.abs(gst - ost).max())
+    cl, cst = m.eval_sequence_in_chunks(toks, None, chunk_size=300)
+    assert np.array_equal(cl, ol) and np.array_equal(cst, ost)
+    m.free()
+    om.free()

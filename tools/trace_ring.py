@@ -25,6 +25,11 @@ d = np.diff(cons, axis=2)
 print('CONSUMER waves: mean / min / max cycles (mean us at 2.4 GHz)')
 for i, n in enumerate(names): print('%-14s %8.0f %8.0f %8.0f   %.2f' % (n, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max(), d[:, :, i].mean() / 2400))
 print('consumer layer total cycles', (cons[:, :, 13] - cons[:, :, 0]).mean())
+cr = d[:, :, 4]
+# per matrix group
+print('C.rows by workgroup quarter (r, k, v, g matrices) mean cycles:', ' '.join('%.0f' % cr[q * 64:(q + 1) * 64].mean() for q in range(4)), ' by consumer:', ' '.join('%.0f' % cr[:, c].mean() for c in range(6)))
+for nm, i in (('F.key rows', 9), ('G.rows', 12), ('E.rows', 6)):
+    print(nm, 'by consumer:', ' '.join('%.0f' % d[:, c, i].mean() for c in range(6)))
 comm = t[:, 1, :12]
 cn = ['A.gather x', 'A.W2+pro wait', 'B.poll tl', 'B.mix', 'C.gather act', 'D.head', 'E.gather yq', 'F.gather x', 'F.keys wait', 'F.quant k', 'G.gather kq']
 dc = np.diff(comm, axis=1)
