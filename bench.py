@@ -27,10 +27,28 @@ MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 MFMA = 2x the bf16 rate (MI355X_MICROA
 MFMA_F16_PEAK_TOPS = 2500.0
 
 
-def pmc_traffic(path_id, args):
+KERNEL_SOURCES = {2: ["rwkv.cpp_amd/csrc/ring_v6.hip", "rwkv.cpp_amd/csrc/ring_geom.h", "rwkv.cpp_amd/csrc/persist.h", "rwkv.cpp_amd/csrc/fused_blocks.h", "rwkv.cpp_amd/csrc/kdev.h"],
+                  1: ["rwkv.cpp_amd/csrc/mega_v6.hip", "rwkv.cpp_amd/csrc/persist.h", "rwkv.cpp_amd/csrc/fused_blocks.h", "rwkv.cpp_amd/csrc/kdev.h"]}
+
+
+def kernel_source_stamp(kind):
+    """sha256 over the sources of the persistent kernel (kind 2: LDS-DMA ring, 1: register prefetch): a PMC quote is only valid for the build it
+    was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES.get(kind, []):
+        try:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        except OSError:
+            h.update(b"missing:" + f.encode())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(path_id, args, kind=0):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written
     by tools/pmc_summary.py): the counters need their own profiler runs, so bench.py can only quote them, and only for the
-    workload and kernel they were taken on."""
+    workload, kernel AND kernel build they were taken on (the entry carries a hash of the kernel's sources; a quote from another
+    build is refused, not repeated)."""
     f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(f):
         return None, None
@@ -38,9 +56,11 @@ def pmc_traffic(path_id, args):
         d = json.load(open(f))
     except Exception:
         return None, None
-    e = d.get(f"{args.config}:{args.dtype}:path{path_id}")
+    e = d.get(f"{args.config}:{args.dtype}:path{path_id}" + (f":kind{kind}" if path_id == 2 else ""))
     if not e:
         return None, None
+    if path_id == 2 and e.get("kernel_source_stamp") != kernel_source_stamp(kind):
+        return None, "stale: profiles/pmc_traffic.json was taken on another build of this kernel (source stamp differs); re-run tools/gpu_final.sh"
     return e.get("hbm_bytes_per_launch"), e.get("source")
 
 
@@ -226,7 +246,7 @@ def bench_decode(args, pkg, lib, path, spec, torch):
         p = model.profile_decode(first, min(args.steps, 32))
         if p["launches"] > 0:
             ach = p["bytes"] / max(p["kernel_ms"], 1e-9) / 1e6
-            traffic, traffic_src = pmc_traffic(path_id, args)
+            traffic, traffic_src = pmc_traffic(path_id, args, model.persist_kind())
             kname = KERNEL_NAMES[3 if (path_id == 2 and model.persist_kind() == 1) else path_id]
             result["roofline"] = {"bound": "hbm", "kernel": kname + f" [{args.dtype}]", "achieved": ach,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

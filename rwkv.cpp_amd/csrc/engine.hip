@@ -68,9 +68,12 @@ static void mega_chain_forget(rwkv_context * ctx) {
     }
 }
 
-// The persistent kernel is bound by cross-XCD hand-over latency, the seven-launch path by launch boundaries; which one wins
-// depends on the device (measured: 2.0 ms vs 2.6 ms per token on most MI355X boxes, 3.4 ms vs 2.9 ms on some). A few
-// eager tokens on zeroed state settle it per context at creation; the state is (re)initialised by every caller afterwards.
+// Which single-token path is fastest depends on the device: the persistent kernels are bound by cross-XCD hand-over latency, the
+// seven-launch path by launch boundaries (measured: 1.5-1.6 ms vs 2.6 ms per token on most MI355X boxes, but on some boxes four of
+// the eight XCDs lag and a chain of all-to-all hand-overs runs at their pace: 3.4 ms vs 2.9 ms). A few eager tokens on zeroed state
+// settle it per context at creation: the persistent kernel on the LDS-DMA weight ring (ring_v6.hip), the one on register prefetch
+// (mega_v6.hip; only built for the comparison when RWKV_MI_PERSIST does not name one) and the seven launches are timed, the fastest
+// stays, the others are freed. The state is (re)initialised by every caller afterwards.
 static void calibrate_decode_path(rwkv_context * ctx) {
     if (!ctx->mega || !ctx->fused_v6) return;
     const char * e = getenv("RWKV_MI_NO_AUTOTUNE");
@@ -83,29 +86,39 @@ static void calibrate_decode_path(rwkv_context * ctx) {
     for (int i = 0; i < 2; i++) ok = ok && hipMemsetAsync(ctx->state[i], 0, sbytes, ctx->stream) == hipSuccess;
     uint32_t * saved_tokens = ctx->d_tokens;
     ctx->d_tokens = tok;
-    void * mega = ctx->mega;
-    auto run = [&](bool use_mega, int n) { ctx->mega = use_mega ? mega : nullptr; for (int i = 0; i < n && ok; i++) ok = forward(ctx, 1, false); ctx->mega = mega; };
-    auto timed = [&](bool use_mega) -> float {
-        run(use_mega, 2);
+    // candidates: [0] the handle create_context made, [1] the other persistent kernel (when the environment names none), fused = nullptr
+    void * cand[2] = {ctx->mega, nullptr};
+    const char * pk = getenv("RWKV_MI_PERSIST");
+    if (!(pk && pk[0]) && mega_v6_kind(cand[0]) == 2) cand[1] = mega_v6_create_kind(m, 1);
+    auto run = [&](void * h, int n) { ctx->mega = h; for (int i = 0; i < n && ok; i++) ok = forward(ctx, 1, false); };
+    auto timed = [&](void * h) -> float {
+        run(h, 2);
         ok = ok && hipEventRecord(ctx->ev0, ctx->stream) == hipSuccess;
-        run(use_mega, 6);
+        run(h, 6);
         ok = ok && hipEventRecord(ctx->ev1, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
         float ms = 0.0f;
         ok = ok && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess;
         return ms;
     };
-    const float t_mega = timed(true), t_fused = timed(false);
+    float t[2] = {1e30f, 1e30f};
+    bool bad[2] = {false, true};
+    for (int i = 0; i < 2; i++) {
+        if (!cand[i]) continue;
+        t[i] = timed(cand[i]);
+        bad[i] = !ok || mega_v6_aborted(cand[i], ctx->stream);
+        if (bad[i]) { if (mega_v6_aborted_cached(cand[i])) (void) mega_v6_clear_abort(cand[i], ctx->stream); ok = true; t[i] = 1e30f; }
+    }
+    const float t_fused = timed(nullptr);
     (void) hipStreamSynchronize(ctx->stream);
     ctx->d_tokens = saved_tokens;
     ctx->cur = 0;
     ctx->last_error = 0;
     (void) hipFree(tok);
-    if (!ok || mega_v6_aborted(mega, ctx->stream) || t_fused < 0.97f * t_mega) {
-        if (mega_v6_aborted_cached(mega)) (void) mega_v6_clear_abort(mega, ctx->stream);
-        mega_chain_forget(ctx);
-        mega_chain_count(ctx, -1);
-        mega_v6_destroy(mega); ctx->mega = nullptr;
-    }
+    const int best = t[1] < t[0] ? 1 : 0;
+    const bool keep = ok && !bad[best] && !(t_fused < 0.97f * t[best]);
+    for (int i = 0; i < 2; i++) if (cand[i] && !(keep && i == best)) mega_v6_destroy(cand[i]);
+    ctx->mega = keep ? cand[best] : nullptr;
+    if (!keep) { mega_chain_forget(ctx); mega_chain_count(ctx, -1); }
 }
 
 // After a poll time-out of the persistent kernel (the device was shared): the stream is drained, the abort word cleared, the
@@ -509,8 +522,11 @@ struct Runner {
         float * sout = ctx->state[ctx->cur ^ 1];
         const int64_t per_layer = m.state_per_layer();
         if (m.has_embed) launch_embed_ln0(*m.emb, ctx->d_tokens, T, D, f(m.ln0_w), f(m.ln0_b), b.x, st);
+        bool head_done = false;
         if (T == 1 && ctx->mega) {
-            mega_v6_forward(ctx->mega, b.x, sin + (int64_t) m.layer_begin * per_layer, sout + (int64_t) m.layer_begin * per_layer, st, &ctx->prof);
+            head_done = want_logits && m.has_head && mega_v6_folds_head(ctx->mega);
+            mega_v6_forward(ctx->mega, b.x, sin + (int64_t) m.layer_begin * per_layer, sout + (int64_t) m.layer_begin * per_layer, st, &ctx->prof,
+                            head_done ? ctx->d_logits : nullptr);
         } else
         for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
             const LayerW & L = m.layers[i];
@@ -528,7 +544,7 @@ struct Runner {
             }
             ffn(L, li, lo);
         }
-        if (want_logits && m.has_head) {
+        if (want_logits && m.has_head && !head_done) {
             // ln_out on the last token only, then the head projection (rwkv_graph.inc:704-708, 851-854)
             launch_layernorm(b.x + (T - 1) * D, 1, D, f(m.ln_out_w), f(m.ln_out_b), b.xlast, st);
             const int64_t Tsave = T; T = 1;

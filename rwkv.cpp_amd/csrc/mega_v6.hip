@@ -832,6 +832,11 @@ void * mega_v6_create(const Model & m) {
     const char * pk = getenv("RWKV_MI_PERSIST");
     const bool want_ring = !(pk && strcmp(pk, "regs") == 0), want_regs = !(pk && strcmp(pk, "ring") == 0);
     if (want_ring) { void * r = ring_v6_create(m); if (r || !want_regs) return r; }
+    return mega_v6_create_kind(m, 1);
+}
+
+void * mega_v6_create_kind(const Model & m, int kind) {
+    if (kind == 2) return ring_v6_create(m);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, m.device) != hipSuccess) return nullptr;
     const int NB = prop.multiProcessorCount;
@@ -929,8 +934,10 @@ int mega_v6_kind(void * h) { return h ? *(const int *) h : 0; }
 uint64_t mega_v6_bytes(void * h) { if (is_ring(h)) return ring_v6_bytes(h); return ((MegaV6 *) h)->bytes; }
 
 // sin / sout: state of the stage's FIRST layer. One launch covers every layer of the stage.
-void mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf) {
-    if (is_ring(h)) { ring_v6_forward(h, x, sin, sout, st, pf); return; }
+bool mega_v6_folds_head(void * h) { return is_ring(h) && ring_v6_folds_head(h); }
+
+void mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits) {
+    if (is_ring(h)) { ring_v6_forward(h, x, sin, sout, st, pf, logits); return; }
     MegaV6 * mg = (MegaV6 *) h;
     M6P q = mg->proto;
     q.x = x; q.sin = sin; q.sout = sout;

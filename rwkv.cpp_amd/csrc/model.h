@@ -200,9 +200,12 @@ bool   fused_v4_supported(const Model & m);
 size_t fused_v4_scratch_bytes(const Model & m);
 void   fused_v4_layer(const Model & m, const LayerW & L, float * x, const float * sin, float * sout, void * scratch, hipStream_t st, rwkv_context::Prof * pf);
 // persistent single-launch RWKV-6 decode over all layers of the stage (mega_v6.hip)
-void *   mega_v6_create(const Model & m);   // nullptr: not applicable
+void *   mega_v6_create(const Model & m);   // nullptr: not applicable. RWKV_MI_PERSIST = ring | regs names the kernel (default: ring, else regs)
+void *   mega_v6_create_kind(const Model & m, int kind);   // 1: register prefetch, 2: LDS-DMA weight ring
 void     mega_v6_destroy(void * h);
-void     mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf);
+// logits != nullptr and mega_v6_folds_head(h): ln_out + the head projection run inside the launch (the caller skips its own)
+void     mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits = nullptr);
+bool     mega_v6_folds_head(void * h);
 bool     mega_v6_ctl_fetch(void * h, hipStream_t st);       // async copy of the control words into the pinned mirror
 bool     mega_v6_aborted_cached(void * h);                  // the mirror's abort word (valid after the stream was synchronised)
 bool     mega_v6_aborted(void * h, hipStream_t st);         // fetch + synchronise + check
@@ -214,7 +217,8 @@ int      mega_v6_kind(void * h);            // 1: register prefetch (mega_v6.hip
 // the same persistent launch on the LDS-DMA weight ring (ring_v6.hip); reached through the mega_v6_* entry points
 void *   ring_v6_create(const Model & m);
 void     ring_v6_destroy(void * h);
-void     ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf);
+void     ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits);
+bool     ring_v6_folds_head(void * h);
 bool     ring_v6_ctl_fetch(void * h, hipStream_t st);
 bool     ring_v6_aborted_cached(void * h);
 bool     ring_v6_clear_abort(void * h, hipStream_t st);

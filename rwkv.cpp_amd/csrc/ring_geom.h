@@ -107,16 +107,37 @@ RG_HD RingRec rg_rec(const RingShape & s, int b, int phase, int j) {
 // first record of consumer c in a phase (its records are j0, j0 + RG_NC, ... < n)
 RG_HD uint32_t rg_first_j(const RingCu & c, int phase, int cons) { return (uint32_t) ((cons + RG_NC - (int) c.rot[phase] % RG_NC) % RG_NC); }
 
-// Offset (in the layer block; >= layer_bytes: in the next layer's block) of the first record consumer `cons` owns in phase `from` or
-// later. This is how far the ring may be refilled once the consumer has read its last record before `from`.
-RG_HD uint32_t rg_next_own(const RingCu & c, int cons, int from) {
-    for (int k = 0; k < 2 * RG_NPHASE; k++) {
-        const int ph = from + k;
-        const int p = ph % RG_NPHASE;
+// Offset in the layer block of the first record consumer `cons` owns in phase `from` or later; RG_NONE when it owns none any more in
+// this layer (the caller then continues with the next block of its stream: the next layer, or the head).
+constexpr uint32_t RG_NONE = 0xFFFFFFFFu;
+RG_HD uint32_t rg_next_own_in_layer(const RingCu & c, int cons, int from) {
+    for (int p = from; p < RG_NPHASE; p++) {
         const uint32_t j0 = rg_first_j(c, p, cons);
-        if (j0 < c.n[p]) return (ph >= RG_NPHASE ? c.layer_bytes : 0u) + c.off[p] + j0 * c.rec[p];
+        if (j0 < c.n[p]) return c.off[p] + j0 * c.rec[p];
     }
-    return 0xFFFFFFFFu;   // (a consumer without any record: cannot happen, E always has one per wave)
+    return RG_NONE;
+}
+
+// ---- the head projection behind the last layer (F16 head.weight, ggml's F16 dot order: 32 partial sums k mod 32, four lanes per row) ----
+// Workgroup b owns rows [b * hg * 16, (b + 1) * hg * 16) in hg row groups of 16 rows; a record = 16 rows x RG_HSTEPS steps of 32
+// columns: [step][lane = 4 * row + q] 16 bytes = columns 32 step + 8 q .. + 7 of that row (lane-linear for the consumer, 1 KiB per step).
+// Consumer c takes row groups c, c + 6, ... ("passes"); inside a pass the records of the participating consumers alternate, chunk by
+// chunk, so that all of them work at once out of a ring that holds only a fraction of a row group.
+constexpr int RG_HSTEPS = 8;
+constexpr uint32_t RG_HREC = RG_HSTEPS * 1024;
+struct RingHead { int hg, chunks, passes; uint32_t bytes; };      // row groups per workgroup, records per row group, passes, bytes per workgroup
+RG_HD RingHead rg_head(int n_vocab, int K) {
+    RingHead h;
+    h.hg = n_vocab / (RG_NBLK * 16);
+    h.chunks = K / 32 / RG_HSTEPS;
+    h.passes = (h.hg + RG_NC - 1) / RG_NC;
+    h.bytes = (uint32_t) h.hg * (uint32_t) h.chunks * RG_HREC;
+    return h;
+}
+RG_HD int rg_head_npc(const RingHead & h, int pass) { const int r = h.hg - RG_NC * pass; return r < RG_NC ? r : RG_NC; }   // consumers in a pass
+// offset (from the head's start in the workgroup's stream) of the record (pass, chunk, consumer)
+RG_HD uint32_t rg_head_off(const RingHead & h, int pass, int chunk, int cons) {
+    return ((uint32_t) (RG_NC * pass * h.chunks) + (uint32_t) (chunk * rg_head_npc(h, pass) + cons)) * RG_HREC;
 }
 
 // a consumer wave's rows of an x-like vector (E / FR / G mapping): unit (b, c) carries rows b * rows_e + c + RG_NC * t, t < 3

@@ -28,7 +28,7 @@
 
 namespace rwkvmi {
 
-struct R6Cu { unsigned long long base; unsigned chunks; unsigned layer_bytes; };   // per workgroup: stream offset, 1-KiB chunks, bytes per layer
+struct R6Cu { unsigned long long base; unsigned chunks, chunks_head; unsigned layer_bytes, pad; };   // per workgroup: stream offset, 1-KiB fills without / with the head, bytes per layer
 
 struct R6P {
     const M6Layer * layers; int n_layers;
@@ -47,6 +47,8 @@ struct R6P {
     int nap;                                           // extra 64-cycle sleeps between two looks at a gather's sentinel unit
     int burst;                                         // loader: fills issued per round (between two looks at the consumers' positions)
     int dbg;                                           // timing experiment: 8 = the loader alone (every other wave leaves at once; results are WRONG)
+    // the head projection folded in behind the last layer (F16 head.weight of a last stage; logits == nullptr: not this launch)
+    float * logits; long long lnout_w, lnout_b; int n_vocab;
     long long * trace; int trace_layer;
 };
 
@@ -501,7 +503,7 @@ struct R6 {
     static __device__ __forceinline__ void loader_main(const R6P & p, const Lds & l, int lane) {
         const int wave = 0;
         const R6Cu cu = p.cus[blockIdx.x];
-        const unsigned total = __builtin_amdgcn_readfirstlane(cu.chunks);          // fills (multiple of four)
+        const unsigned total = __builtin_amdgcn_readfirstlane(p.logits ? cu.chunks_head : cu.chunks);          // fills (multiple of four)
         const unsigned long long src0 = (unsigned long long) p.stream + cu.base;
         const unsigned RB = __builtin_amdgcn_readfirstlane(p.ring_bytes), MIR = __builtin_amdgcn_readfirstlane(p.mirror_bytes);
         const unsigned ring_m0 = __builtin_amdgcn_readfirstlane((unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) l.ring);
@@ -571,6 +573,7 @@ struct R6 {
     struct Cons {
         RingCu cu;
         unsigned lbase;        // stream position of the current layer's block
+        unsigned next_block;   // stream position of this wave's first record behind the current layer (next layer, head, or none)
         unsigned RB;
         unsigned landed;       // chunks known to have landed
         int c, lane;
@@ -596,7 +599,8 @@ struct R6 {
         const unsigned j0 = rg_first_j(cs.cu, PH, cs.c);
         if (j0 >= n) return;
         const bool tail = j0 + NC * TF < n;                         // wave-uniform
-        const unsigned after = cs.lbase + rg_next_own(cs.cu, cs.c, PH + 1);
+        const unsigned nxt = rg_next_own_in_layer(cs.cu, cs.c, PH + 1);
+        const unsigned after = nxt != RG_NONE ? cs.lbase + nxt : cs.next_block;
         unsigned pos = __builtin_amdgcn_readfirstlane(cs.lbase + cs.cu.off[PH] + j0 * RECB);
         unsigned ro = pos;
         { const unsigned q = pos / cs.RB; ro = __builtin_amdgcn_readfirstlane(pos - q * cs.RB); }   // (once per phase)
@@ -699,6 +703,11 @@ struct R6 {
         const int cbase = (blk * (4 * D / NBLK)) % D;
         const bool has_dw1 = blk < p.DR;
 
+        // where this wave's stream continues behind a layer: its first record of the next layer, or of the head, or nowhere
+        const unsigned first_own = rg_next_own_in_layer(cs.cu, c, 0);
+        const RingHead hd = rg_head(p.n_vocab, D);
+        const unsigned hbase = (unsigned) p.n_layers * cs.cu.layer_bytes;
+        const unsigned head_first = (p.logits && c < hd.hg) ? hbase + rg_head_off(hd, 0, 0, c) : 0xFFFFFFFFu;
         float xown[XT], rrow[XT];
 #pragma unroll
         for (int t = 0; t < XT; t++) { const int row = c + NC * t; xown[t] = row < RE ? p.x[blk * RE + row] : 0.0f; rrow[t] = 0.0f; }
@@ -712,6 +721,7 @@ struct R6 {
             const unsigned tagL = base + (unsigned) li * 8u;
             const unsigned g1 = (unsigned) li + 1u;   // generation of this layer's once-per-layer counters
             cs.lbase = (unsigned) li * cs.cu.layer_bytes;
+            cs.next_block = li + 1 < p.n_layers ? cs.lbase + cs.cu.layer_bytes + first_own : head_first;
             R6STAMP(0);
             // (per-lane offsets are derived from an opaque copy of the lane index in every phase: left alone, the compiler hoists a
             //  hundred loop-invariant address registers of the gathers out of the layer loop and spills them)
@@ -824,12 +834,116 @@ struct R6 {
             });
             if (lane == 0) tg_store(xr, p.xffn + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
             R6STAMP(13); R6RSTAMP(14);
-            {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
-                const int nl = li + 1 < p.n_layers ? li + 1 : li;
-                issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, opq(ppt));
+            if (li + 1 < p.n_layers) {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
+                issue_pa(pa, ar, p.layers[li + 1], p.sin + (long long) (li + 1) * p.state_stride, opq(ppt));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (p.logits) head_phase(p, l, cs, pl, xr, ar, hd, hbase, lane, wave, base);
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // the head behind the last layer: ln_out on the gathered residual stream, logits = head.weight (F16) . fp16(ln_out(x))
+    // (rwkv_graph.inc:704-708; ggml's F16 dot: activations rounded to fp16, 32 partial sums k mod 32 accumulated with fma in increasing k,
+    // folded 16 / 8 / 4, (p0 + p1) + (p2 + p3) -- the order of k_mvf in kernels.hip: four lanes per row, lane q holds partials 8 q .. 8 q + 7)
+    // -----------------------------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void head_phase(const R6P & p, const Lds & l, Cons & cs, Poll & pl, xrsrc xr, const M6Arena & ar, const RingHead & hd,
+                                                      unsigned hbase, int lane, int wave, unsigned base) {
+        const int blk = blockIdx.x, c = cs.c, li = p.n_layers;       // (li: the layer index the stamps and generations continue with)
+        const unsigned tagL = base + (unsigned) li * 8u;
+        const int pt = c * 64 + lane;
+        R6STAMP(0); R6RSTAMP(16);
+        // x after the last layer
+        gather_hint(pl, xr, p.xffn + ((blk * 37 + c * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
+        sweep_begin(l);
+        gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, c, opq(lane), l.x);
+        gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
+        sweep_end(l);
+        R6STAMP(1);
+        if (c < 4) {
+            const float scale = ln_stats(pl, l, pt, lane, 2u * li + 1u);
+            const float * lw = ar.f(p.lnout_w), * lb = ar.f(p.lnout_b);
+#pragma unroll
+            for (int u = 0; u < V4; u++) {
+                const int i = pt * 4 + u * 1024;
+                const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
+                const float4 w4 = *reinterpret_cast<const float4 *>(lw + i), b4 = *reinterpret_cast<const float4 *>(lb + i);
+                const float xs[4] = {xc.x, xc.y, xc.z, xc.w}, ws[4] = {w4.x, w4.y, w4.z, w4.w}, bs[4] = {b4.x, b4.y, b4.z, b4.w};
+                float y[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const float a = xs[j] * scale; const float aw = a * ws[j]; y[j] = round_f16(aw + bs[j]); }
+                *reinterpret_cast<float4 *>(l.x + i) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+            fl_add(l.fl + FL_PRO, 1u);
+        }
+        fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 1u));
+        R6STAMP(2);
+        if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 20] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) hbase;
+        long long waited = 0;
+        // row groups of this wave
+        unsigned * const dn = l.fl + FL_DONE + 2 + c;
+        const int ln = opq(lane), q = ln & 3;
+        constexpr int CHK = nb / RG_HSTEPS;      // records per row group
+        if (c >= hd.hg) { asm volatile("" ::: "memory"); __hip_atomic_store(dn, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        for (int ps = 0; ps < hd.passes; ps++) {
+            const int g = RG_NC * ps + c;
+            if (g >= hd.hg) break;
+            const unsigned stride = (unsigned) rg_head_npc(hd, ps) * RG_HREC;
+            unsigned pos = __builtin_amdgcn_readfirstlane(hbase + rg_head_off(hd, ps, 0, c));
+            unsigned ro = __builtin_amdgcn_readfirstlane(pos - (pos / cs.RB) * cs.RB);
+            const bool more = RG_NC * (ps + 1) + c < hd.hg;
+            const unsigned after = more ? hbase + rg_head_off(hd, ps + 1, 0, c) : 0xFFFFFFFFu;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] = 0.0f;
+            for (int k = 0; k < CHK; k++) {
+                const unsigned need = (pos + RG_HREC + 1023u) >> 10;
+                if (cs.landed < need) {
+                    const long long t0 = p.trace ? (long long) __builtin_readcyclecounter() : 0;
+                    for (unsigned spin = 0;; spin++) {
+                        cs.landed = fl_ld(l.fl + FL_LANDED);
+                        if (cs.landed >= need || pl.dead) break;
+                        if (lds_backoff(pl, spin)) break;
+                    }
+                    if (p.trace) waited += (long long) __builtin_readcyclecounter() - t0;
+                }
+                asm volatile("" ::: "memory");
+                const int4 * wp = reinterpret_cast<const int4 *>(l.ring + ro) + ln;
+                int4 raw[RG_HSTEPS];
+#pragma unroll
+                for (int st = 0; st < RG_HSTEPS; st++) raw[st] = wp[st * 64];
+                asm volatile("" ::: "memory");
+                __hip_atomic_store(dn, k + 1 < CHK ? pos + stride : after, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const float * xk = l.x + k * (RG_HSTEPS * 32) + 8 * q;
+#pragma unroll
+                for (int st = 0; st < RG_HSTEPS; st++) {
+                    const float4 xa = *reinterpret_cast<const float4 *>(xk + st * 32), xb = *reinterpret_cast<const float4 *>(xk + st * 32 + 4);
+                    const unsigned u[4] = {(unsigned) raw[st].x, (unsigned) raw[st].y, (unsigned) raw[st].z, (unsigned) raw[st].w};
+                    float w[8];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { w[2 * i] = h2f_bits((uint16_t) (u[i] & 0xFFFFu)); w[2 * i + 1] = h2f_bits((uint16_t) (u[i] >> 16)); }
+                    acc[0] = fmaf(w[0], xa.x, acc[0]); acc[1] = fmaf(w[1], xa.y, acc[1]); acc[2] = fmaf(w[2], xa.z, acc[2]); acc[3] = fmaf(w[3], xa.w, acc[3]);
+                    acc[4] = fmaf(w[4], xb.x, acc[4]); acc[5] = fmaf(w[5], xb.y, acc[5]); acc[6] = fmaf(w[6], xb.z, acc[6]); acc[7] = fmaf(w[7], xb.w, acc[7]);
+                }
+                pos += stride; ro += stride;
+                while (ro >= cs.RB) ro -= cs.RB;
+            }
+            float ps8[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float v = acc[e];
+                v += __int_as_float(lane_xor2_i(__float_as_int(v)));   // ps[i] += ps[i + 16]
+                v += __int_as_float(lane_xor1_i(__float_as_int(v)));   // ps[i] += ps[i + 8]
+                ps8[e] = v;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) ps8[e] += ps8[e + 4];
+            const float r = (ps8[0] + ps8[1]) + (ps8[2] + ps8[3]);
+            if (q == 0) p.logits[(long long) blk * hd.hg * 16 + g * 16 + (ln >> 2)] = r;
+            if (ps < 4) R6STAMP(3 + ps);
+        }
+        R6STAMP(7); R6RSTAMP(17);
+        if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 21] = waited;
     }
 
     // -----------------------------------------------------------------------------------------------------------
@@ -1090,6 +1204,15 @@ struct R6 {
             sweep_end(l);
             R6STAMP(11); R6RSTAMP(25);
         }
+        if (p.logits) {   // the head: this wave's share of the last x hand-over (the consumers do the rest)
+            const int li = p.n_layers;
+            const unsigned tagL = base + (unsigned) li * 8u;
+            gather_hint(pl, xr, p.xffn + ((blk * 37 + g * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
+            sweep_begin(l);
+            gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, g, opq(lane), l.x);
+            gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
+            sweep_end(l);
+        }
     }
 };
 
@@ -1170,6 +1293,26 @@ __global__ void k_ring_pack(const unsigned char * __restrict__ arena, PackMat pm
     }
 }
 
+// the head's rows in the record layout of ring_geom.h (RingHead): one workgroup of 64 threads per record
+__global__ void k_ring_pack_head(const unsigned short * __restrict__ head, int n_vocab, int K, const R6Cu * __restrict__ cus, unsigned char * __restrict__ stream, int n_layers) {
+    const int b = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    const RingHead hd = rg_head(n_vocab, K);
+    // r -> (pass, chunk, consumer): records of a pass are chunk-major over its consumers
+    int ps = 0, rr = r;
+    while (ps < hd.passes && rr >= rg_head_npc(hd, ps) * hd.chunks) { rr -= rg_head_npc(hd, ps) * hd.chunks; ps++; }
+    if (ps >= hd.passes) return;
+    const int npc = rg_head_npc(hd, ps), k = rr / npc, c = rr % npc;
+    const int g = RG_NC * ps + c;
+    const long long row = (long long) b * hd.hg * 16 + g * 16 + (lane >> 2);
+    const int q = lane & 3;
+    unsigned char * dst = stream + cus[b].base + (size_t) n_layers * cus[b].layer_bytes + rg_head_off(hd, ps, k, c);
+    for (int st = 0; st < RG_HSTEPS; st++) {
+        const int col = 32 * (k * RG_HSTEPS + st) + 8 * q;
+        const int4 v = *reinterpret_cast<const int4 *>(head + row * K + col);
+        *reinterpret_cast<int4 *>(dst + st * 1024 + lane * 16) = v;
+    }
+}
+
 __global__ void k_block_w2_ring(const float * __restrict__ src, float * __restrict__ dst, int D, int R) {   // (layout: see k_block_w2, mega_v6.hip)
     const long long n = 5ll * R * D;
     for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
@@ -1193,6 +1336,8 @@ struct RingV6 {
     int variant = -1, n_blocks = 0;
     size_t lds = 0;
     uint64_t bytes = 0;
+    bool head = false;            // the head projection is folded into the launch (F16 head.weight, vocabulary a multiple of 4096)
+    uint64_t bytes_head = 0;      // its algorithmic bytes: head.weight, ln_out, the logits written
 };
 
 typedef void (*RingKernel)(R6P);
@@ -1264,7 +1409,7 @@ void * ring_v6_create(const Model & m) {
     const size_t lds_max = 160 * 1024;
     // the ring is filled in 4-KiB groups of four DMA instructions; its head is repeated behind its end for the longest record (rec_load)
     const size_t max_rec_bytes = rg_rec_bytes(sh, 1, (int) F) > rg_rec_bytes(sh, 2, (int) D) ? rg_rec_bytes(sh, 1, (int) F) : rg_rec_bytes(sh, 2, (int) D);
-    const size_t mirror = (max_rec_bytes + 4095) / 4096 * 4096;
+    const size_t mirror = ((max_rec_bytes > RG_HREC ? max_rec_bytes : RG_HREC) + 4095) / 4096 * 4096;
     size_t ring = (size_t) env_int("RWKV_MI_RING_KB", 1024) * 1024;
     if (lo.fixed + mirror + 32 * 1024 > lds_max) { delete rg; return nullptr; }
     if (ring > lds_max - lo.fixed - mirror) ring = lds_max - lo.fixed - mirror;
@@ -1272,6 +1417,10 @@ void * ring_v6_create(const Model & m) {
     if (ring < 32 * 1024) ring = 32 * 1024;
     rg->lds = lo.fixed + ring + mirror;
     if (hipFuncSetAttribute((const void *) g_ring_variants[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rg->lds) != hipSuccess) { delete rg; return nullptr; }
+    // the head behind the last layer: F16 head.weight of a stage that owns it, rows divisible into 16-row groups per workgroup
+    const bool fold_head = m.has_head && m.head && m.head->type == T_F16 && m.head->cols() == D && m.n_vocab() % (RG_NBLK * 16) == 0 && m.ln_out_w && m.ln_out_b
+                           && !(getenv("RWKV_MI_RING_NO_HEAD") && getenv("RWKV_MI_RING_NO_HEAD")[0] == '1');
+    rg->head = fold_head;
     // per-workgroup streams
     std::vector<R6Cu> hc(RG_NBLK);
     uint64_t total = 0;
@@ -1282,8 +1431,11 @@ void * ring_v6_create(const Model & m) {
         max_rec = nr > max_rec ? nr : max_rec;
         const uint64_t bytes = (uint64_t) cu.layer_bytes * n_layers;
         if (bytes + (1u << 20) > 0xFFFFFFFFull) { delete rg; return nullptr; }   // stream positions are 32-bit
-        hc[b].base = total; hc[b].chunks = (unsigned) ((bytes + 4 * RG_CHUNK - 1) / (4 * RG_CHUNK)) * 4u; hc[b].layer_bytes = cu.layer_bytes;
-        total += (uint64_t) hc[b].chunks * RG_CHUNK;
+        const uint64_t hbytes = fold_head ? rg_head((int) m.n_vocab(), (int) D).bytes : 0;
+        if (bytes + hbytes + (1u << 20) > 0xFFFFFFFFull) { delete rg; return nullptr; }
+        hc[b].base = total; hc[b].chunks = (unsigned) ((bytes + 4 * RG_CHUNK - 1) / (4 * RG_CHUNK)) * 4u;
+        hc[b].chunks_head = (unsigned) ((bytes + hbytes + 4 * RG_CHUNK - 1) / (4 * RG_CHUNK)) * 4u; hc[b].layer_bytes = cu.layer_bytes; hc[b].pad = 0;
+        total += (uint64_t) hc[b].chunks_head * RG_CHUNK;
     }
     const size_t w2_layer = (size_t) 5 * R * D;
     bool ok = R % 4 == 0 && hipMalloc((void **) &rg->w2b, w2_layer * n_layers * sizeof(float)) == hipSuccess
@@ -1327,6 +1479,14 @@ void * ring_v6_create(const Model & m) {
         bytes += 2 * (uint64_t) m.state_per_layer() * sizeof(float);
     }
     rg->bytes = bytes;
+    long long lnw_off = 0, lnb_off = 0;
+    if (fold_head && in_arena) {
+        lnw_off = off(m.ln_out_w->data); lnb_off = off(m.ln_out_b->data);
+        const RingHead hd = rg_head((int) m.n_vocab(), (int) D);
+        hipLaunchKernelGGL(k_ring_pack_head, dim3((unsigned) (hd.hg * hd.chunks), RG_NBLK), dim3(64), 0, 0, (const unsigned short *) m.head->data, (int) m.n_vocab(), (int) D,
+                           rg->d_cus, rg->stream, n_layers);
+        rg->bytes_head = m.head->nbytes + m.ln_out_w->nbytes + m.ln_out_b->nbytes + (uint64_t) m.n_vocab() * 4;
+    }
     if (!in_arena) { ring_v6_destroy(rg); return nullptr; }
     const int64_t nbD = D / 32, nbF = F / 32;
     const int64_t PAD = 2048;   // polls read whole rounds of 7 x 64 lanes: keep every buffer readable past its end
@@ -1357,6 +1517,7 @@ void * ring_v6_create(const Model & m) {
     q.stream = rg->stream; q.cus = rg->d_cus;
     q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;
     q.ring_bytes = (unsigned) ring; q.mirror_bytes = (unsigned) mirror;
+    q.logits = nullptr; q.lnout_w = lnw_off; q.lnout_b = lnb_off; q.n_vocab = (int) m.n_vocab();
     auto snap = [](int w) { w &= ~3; return w < 4 ? 4 : (w > 52 ? 52 : w); };
     q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 48));
     q.thin = snap(env_int("RWKV_MI_RING_THIN", 16));
@@ -1379,10 +1540,14 @@ bool ring_v6_trace(void * h, int layer, long long * out, bool fetch) {
 
 uint64_t ring_v6_bytes(void * h) { return ((RingV6 *) h)->bytes; }
 
-void ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf) {
+bool ring_v6_folds_head(void * h) { return ((RingV6 *) h)->head; }
+
+// logits != nullptr (only when ring_v6_folds_head): ln_out + head run inside the launch and the logits land there
+void ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits) {
     RingV6 * rg = (RingV6 *) h;
     R6P q = rg->proto;
     q.x = x; q.sin = sin; q.sout = sout;
+    q.logits = rg->head ? logits : nullptr;
     const RingKernel fn = g_ring_variants[rg->variant].fn;
     if (pf && pf->on) {
         if (pf->used * 2 + 2 > pf->events.size()) {
@@ -1390,7 +1555,7 @@ void ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipSt
             (void) hipEventCreate(&a); (void) hipEventCreate(&c);
             pf->events.push_back(a); pf->events.push_back(c); pf->bytes.push_back(0);
         }
-        pf->bytes[pf->used] = rg->bytes;
+        pf->bytes[pf->used] = rg->bytes + (q.logits ? rg->bytes_head : 0);
         hipExtLaunchKernelGGL(fn, dim3((unsigned) rg->n_blocks), dim3(512), (uint32_t) rg->lds, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, q);
         pf->used++;
     } else {

@@ -48,6 +48,10 @@ CONFIGS = {
     # geometries the persistent RWKV-6 decode kernel is built for (mega_v6.hip), with few layers and a small vocabulary
     "mega-v6-2048": ModelSpec("6", 3, 2048, 512, 7168, 64, 32, 64, name="mega-v6-2048"),
     "mega-v6-4096": ModelSpec("6", 2, 4096, 512, 14336, 64, 64, 128, name="mega-v6-4096"),
+    # ... with vocabularies the ring kernel folds the head projection for (multiples of 4096: 1, 2 and 8 row groups of 16 rows per workgroup)
+    "mega-v6-4096-v4k": ModelSpec("6", 2, 4096, 4096, 14336, 64, 64, 128, name="mega-v6-4096-v4k"),
+    "mega-v6-2048-v8k": ModelSpec("6", 3, 2048, 8192, 7168, 64, 32, 64, name="mega-v6-2048-v8k"),
+    "mega-v6-2048-v32k": ModelSpec("6", 2, 2048, 32768, 7168, 64, 32, 64, name="mega-v6-2048-v32k"),
     "test-v7": ModelSpec("7", 3, 256, 512, 1024, 64, v7_rank_w=64, v7_rank_a=64, v7_rank_v=32, v7_rank_g=96, name="test-v7"),
 }
 

@@ -21,11 +21,13 @@ def persist(request):
     yield {"ring": 2, "regs": 1}[request.param]
     del os.environ["RWKV_MI_PERSIST"]
 
-TOKENS = [1, 2, 3, 400, 5, 77, 300, 9, 11, 12]
+TOKENS = [1, 2, 3, 400, 5, 77, 300, 9, 11, 12]   # (every test vocabulary has at least 512 entries)
 
 
 @pytest.mark.parametrize("name,fmt", [("mega-v6-2048", "Q4_0"), ("mega-v6-4096", "Q4_0"), ("mega-v6-2048", "Q4_1"), ("mega-v6-2048", "Q5_0"),
-                                      ("mega-v6-4096", "Q5_1"), ("mega-v6-4096", "Q8_0")])
+                                      ("mega-v6-4096", "Q5_1"), ("mega-v6-4096", "Q8_0"),
+                                      # vocabularies of 1, 2 and 8 sixteen-row groups per workgroup: the ring kernel runs ln_out + head inside the launch
+                                      ("mega-v6-4096-v4k", "Q4_0"), ("mega-v6-2048-v8k", "Q5_1"), ("mega-v6-2048-v32k", "Q4_0"), ("mega-v6-2048-v8k", "Q8_0")])
 def test_mega_matches_oracle(tmp_path, name, fmt, persist):
     library()
     p = str(tmp_path / "m.bin")

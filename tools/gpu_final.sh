@@ -1,23 +1,27 @@
 #!/bin/bash
-# Round-2 evidence run: full GPU test suite, bench lines of every BASELINE configuration, rocprofv3 kernel stats, PMC traffic passes and
-# the persistent kernel's phase trace. Outputs under gpurun_out/$1; the summaries that matter are copied to profiles/ afterwards.
+# Evidence run of a round: full GPU test suite, bench lines of every BASELINE configuration, rocprofv3 kernel stats, PMC traffic passes and
+# the persistent kernel's phase trace. Outputs under gpurun_out/$1; the summaries that matter are copied to profiles/ afterwards
+# (tools/collect_profiles.sh $1).
 set -u
 cd "$(dirname "$0")/.."
-O=gpurun_out/${1:-r02g}; mkdir -p $O
+O=gpurun_out/${1:-r03z}; mkdir -p $O
 export TMPDIR=/tmp RWKV_BENCH_DIR=/tmp
 R=$PWD
-( timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 ) > $O/pytest.txt; tail -2 $O/pytest.txt
+git rev-parse HEAD > $O/head.txt 2>/dev/null || cp .gpurun_head $O/head.txt 2>/dev/null || true
+( timeout 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -6 ) > $O/pytest.txt; tail -2 $O/pytest.txt
 B="timeout 400 python bench.py"
 $B --steps 256 --warmup 16 > $O/bench_7b_q4_0.json 2> $O/bench_7b_q4_0.err
+RWKV_MI_PERSIST=regs RWKV_BENCH_NO_COLD=1 $B --steps 256 --warmup 16 --cpu-seconds 0 --abi-tokens 0 > $O/bench_7b_q4_0_regs.json 2> /dev/null
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_7b -o decode -- python $R/bench.py --steps 64 --warmup 8 --cpu-seconds 0 --abi-tokens 0 --no-profile > /dev/null 2> $R/$O/rocprof_7b.err
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -o p -- python $R/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --abi-tokens 0 --no-profile > /dev/null 2> $R/$O/pmc_fetch.err
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -o p -- python $R/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --abi-tokens 0 --no-profile > /dev/null 2> $R/$O/pmc_write.err
+RWKV_MI_NO_AUTOTUNE=1 RWKV_MI_PERSIST=ring RWKV_BENCH_NO_COLD=1 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -o p -- python $R/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --abi-tokens 0 --no-profile > /dev/null 2> $R/$O/pmc_fetch.err
+RWKV_MI_NO_AUTOTUNE=1 RWKV_MI_PERSIST=ring RWKV_BENCH_NO_COLD=1 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -o p -- python $R/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --abi-tokens 0 --no-profile > /dev/null 2> $R/$O/pmc_write.err
 cd $R
-timeout 200 python tools/trace.py > $O/mega_phase_cycles.txt 2> $O/trace.err
+timeout 200 python tools/trace_ring.py rwkv6-7b 5 > $O/ring_phase_cycles_7b.txt 2> $O/trace.err
+RWKV_MI_PERSIST=regs timeout 200 python tools/trace.py > $O/mega_phase_cycles.txt 2>> $O/trace.err
 rm -f /tmp/synthetic-rwkv6-7b-Q4_0*
 $B --config rwkv6-1b6 --dtype Q4_0 --steps 256 --cpu-seconds 5 > $O/bench_1b6_q4_0.json 2> $O/bench_1b6.err
-$B --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 5 > $O/prefill_1b6_q4_0.json 2> $O/prefill_1b6.err
+$B --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 25 --parity-tokens 1024 > $O/prefill_1b6_q4_0.json 2> $O/prefill_1b6.err
 $B --config rwkv7-2b9 --dtype Q5_1 --steps 128 --cpu-seconds 5 > $O/bench_7v_2b9_q5_1.json 2> $O/bench_2b9.err
 $B --config rwkv4-169m --dtype Q5_1 --steps 256 --cpu-seconds 5 > $O/bench_4_169m_q5_1.json 2> $O/bench_169m.err
 cd /tmp
@@ -33,7 +37,7 @@ import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r=d.get("roofline",{})
-    print(d["metric"], round(d["value"],1), "ms/step", round(d["ms_per_step"],3), "path", d["config"].get("decode_path"), "roof", round(r.get("frac",0),4), "avg_us", round(r.get("avg_launch_us",0),1), "parity", d.get("parity",{}).get("equal"), "abi", round(d.get("abi",{}).get("tokens_per_s",0),1), "cpu", round(d.get("cpu_baseline",{}).get("value",0),2), d.get("cpu_baseline",{}).get("simd"))
+    print(d["metric"], round(d["value"],1), "ms/step", round(d["ms_per_step"],3), "path", d["config"].get("decode_path"), d["config"].get("persist_kind"), "roof", round(r.get("frac",0),4), "avg_us", round(r.get("avg_launch_us",0),1), "parity", d.get("parity",{}).get("equal"), "abi", round(d.get("abi",{}).get("tokens_per_s",0),1), "cpu", round(d.get("cpu_baseline",{}).get("value",0),2), "load", d.get("load",{}).get("cold_seconds"), d.get("load",{}).get("warm_seconds"))
 except Exception as e:
     print("unreadable", e)
 PY

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/${1:-r03x}; mkdir -p $O; shift
 export TMPDIR=/tmp RWKV_BENCH_DIR=/tmp RWKV_MI_NO_AUTOTUNE=1
 ok=1
-for a in "mega-v6-2048 Q4_0 direct" "mega-v6-4096 Q4_0 direct" "mega-v6-4096 Q5_1 direct" "mega-v6-4096 Q8_0 direct"; do
+for a in "mega-v6-2048 Q4_0 direct" "mega-v6-4096 Q4_0 direct" "mega-v6-4096-v4k Q4_0 direct" "mega-v6-2048-v8k Q5_1 direct" "mega-v6-2048-v32k Q4_0 direct" "mega-v6-4096 Q8_0 direct"; do
   f=$O/dbg_$(echo $a | tr ' ' '_').txt
   RWKV_MI_PERSIST=ring timeout 150 python tools/dbg_fused.py $a > $f 2>&1; echo "rc $? $(grep -E 'RESULT|path' $f | tr '\n' ' ')"
   grep -q "OK" $f || { ok=0; tail -20 $f; }

@@ -20,6 +20,7 @@ def collect(d, kernel, counter):
 def main():
     fetch_dir, write_dir, kernel, key = sys.argv[1:5]
     out = sys.argv[5] if len(sys.argv) > 5 else "profiles/pmc_traffic.json"
+    stamp = sys.argv[6] if len(sys.argv) > 6 else None      # bench.kernel_source_stamp(kind) of the build the passes ran on
     fv, wv = collect(fetch_dir, kernel, "FETCH_SIZE"), collect(write_dir, kernel, "WRITE_SIZE")
     if not fv:
         sys.exit("no FETCH_SIZE rows for kernel " + kernel)
@@ -28,6 +29,8 @@ def main():
     e = {"kernel": kernel, "launches_sampled": len(fv), "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB_raw": write_kib,
          "hbm_bytes_per_launch": fetch_kib * 1024 * 2 + write_kib * 1024,
          "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950 correction), per launch average"}
+    if stamp:
+        e["kernel_source_stamp"] = stamp
     d = json.load(open(out)) if os.path.exists(out) else {}
     d[key] = e
     json.dump(d, open(out, "w"), indent=1)
