@@ -89,6 +89,9 @@ def parse_args():
     ap.add_argument("--seq-len", type=int, default=1024)
     ap.add_argument("--parity-tokens", type=int, default=64, help="greedy tokens compared GPU vs CPU oracle on the benchmarked file (0 disables)")
     ap.add_argument("--abi-tokens", type=int, default=24, help="tokens timed through the unmodified rwkv_eval ABI (host state in/out every call; 0 disables)")
+    ap.add_argument("--chain", action="store_true",
+                    help="with --gpus N in ONE process (no torch.distributed.run): the layer chain of RWKV_MI_DEVICES over N devices, decode loop in C++")
+    ap.add_argument("--chain-devices", default=None, help="device list of --chain (default 0-(N-1); e.g. 0,0 runs two stages on one GPU)")
     return ap.parse_args()
 
 
@@ -344,6 +347,66 @@ def bench_prefill(args, pkg, lib, path, spec, torch):
     return result
 
 
+def bench_chain(args, pkg, lib, path, spec, torch):
+    """--chain: rwkv_init_from_file under RWKV_MI_DEVICES builds one stage per listed device inside this process; the greedy loop is the
+    library's (runner.cpp): per-stage hipGraph replays, residual stream device to device, the chosen token back to the first stage -- no
+    Python between tokens. Same metric as the N = 1 line (single-stream tokens/s, total work fixed = strong scaling); the aggregate of N
+    decode streams in flight (what a layer pipeline is for) is reported beside it."""
+    import numpy as np
+    n = args.gpus
+    devices = args.chain_devices or (f"0-{n - 1}" if n > 1 else "0")
+    os.environ["RWKV_MI_DEVICES"] = devices
+    try:
+        front = pkg.RWKVModel(lib, path)
+    finally:
+        del os.environ["RWKV_MI_DEVICES"]
+    first = 1103515245 % spec.n_vocab
+    front.state_load(None)
+    front.decode_greedy(first, args.warmup)
+    front.state_load(None)
+    toks, ms = front.decode_greedy(first, args.steps)
+    single_tok_s = args.steps / (ms / 1e3)
+    # N decode streams through the same chain
+    streams = [front] + [front.clone() for _ in range(max(1, n) - 1)]
+    firsts = [(1103515245 * (j + 1)) % spec.n_vocab for j in range(len(streams))]
+    for m in streams:
+        m.state_load(None)
+    pkg.RWKVModel.decode_greedy_streams(streams, firsts, args.warmup)
+    for m in streams:
+        m.state_load(None)
+    mtoks, mms = pkg.RWKVModel.decode_greedy_streams(streams, firsts, args.steps)
+    result = {
+        "metric": "tokens/sec single-stream decode", "value": single_tok_s, "unit": "tokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": DTYPE_DESC.get(args.dtype, args.dtype), "data": "synthetic",
+        "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode through a layer chain of {n} stage(s) in one process "
+                               f"(RWKV_MI_DEVICES={devices}; C++ decode loop, per-stage hipGraphs, peer copies of the residual stream)",
+                   "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": f"pp{n} (one process)"},
+        "multi_stream": {"streams": len(streams), "tokens_per_s_aggregate": len(streams) * args.steps / (mms / 1e3), "ms_per_step": mms / args.steps,
+                         "note": "independent decode streams (clones) interleaved through the same chain: aggregate throughput"},
+    }
+    if args.parity_tokens > 0:
+        # the chain against a one-device context of the same file (itself checked against the CPU oracle by the N = 1 line and tests/)
+        k = min(args.parity_tokens, args.steps)
+        ref = pkg.RWKVModel(lib, path)
+        ref.state_load(None)
+        rt, _ = ref.decode_greedy(first, k)
+        rs = ref.state_store()
+        front.state_load(None)
+        ct, _ = front.decode_greedy(first, k)
+        cs = front.state_store()
+        equal = bool(np.array_equal(rt, ct) and np.array_equal(rs, cs) and np.array_equal(toks[:k], rt) and np.array_equal(mtoks[0][:k], rt))
+        result["parity"] = {"tokens_checked": int(k), "equal": equal, "what": "tokens and recurrent state, stage chain vs one-device context, bit for bit"}
+        ref.free()
+        if not equal:
+            print(json.dumps(result))
+            raise SystemExit("[bench] PARITY FAILURE: the stage chain differs from the one-device context")
+    for m in streams[1:]:
+        m.free()
+    front.free()
+    return result
+
+
 def main():
     args = parse_args()
     # watchdog: a device call that never returns must end the process (with the Python stacks on stderr), not hang the box
@@ -352,7 +415,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    if world != args.gpus and not args.chain:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1", file=sys.stderr)
     import torch
 
@@ -378,7 +441,9 @@ def main():
 
     path, spec = ensure_model_file(args, synth, rank, barrier)
 
-    if world > 1:
+    if args.chain and world == 1:
+        result = bench_chain(args, pkg, lib, path, spec, torch)
+    elif world > 1:
         from rwkv_cpp_amd import pipeline  # layer pipeline over RCCL send/recv
         result = pipeline.bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world)
     elif args.mode == "prefill":

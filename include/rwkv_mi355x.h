@@ -16,7 +16,8 @@
 extern "C" {
 #endif
 
-/* Copies a host state (or a fresh state when NULL) into the context's device-resident state. */
+/* Copies a host state (or a fresh state when NULL) into the context's device-resident state (on a RWKV_MI_DEVICES chain: every stage
+ * takes the slice of its layers; rwkv_mi_state_store and rwkv_mi_decode_greedy work on chains as well). */
 RWKV_API bool rwkv_mi_state_load(struct rwkv_context * ctx, const float * state_in);
 /* Copies the device-resident state to host memory (FP32[rwkv_get_state_len]). */
 RWKV_API bool rwkv_mi_state_store(struct rwkv_context * ctx, float * state_out);
@@ -98,6 +99,24 @@ RWKV_API void rwkv_mi_stage_range(const struct rwkv_context * ctx, uint32_t * la
  * (d_token). Other stages: residual stream from x_in (device). Not last: writes x_out (device). Last: ln_out + head,
  * argmax into d_next_token (device, may be NULL). State stays resident (use rwkv_mi_state_load(ctx, NULL) to reset). */
 RWKV_API bool rwkv_mi_stage_step(struct rwkv_context * ctx, const uint32_t * d_token, const float * x_in, float * x_out, uint32_t * d_next_token);
+/* The greedy decode loop of a whole pipeline, enqueued from C++ (runner.cpp) -- no host language between tokens.
+ * rwkv_mi_decode_greedy_streams: n_streams contexts of ONE process (a RWKV_MI_DEVICES chain and its clones, or a one-device context
+ * and its clones), interleaved stream by stream so that every stage of the chain has work; per-stage launches replay per-device
+ * hipGraphs, the residual stream travels device to device. tokens_out: [n_streams][n_tokens] (may be NULL); elapsed_ms: host wall time
+ * of the loop including the final drain (may be NULL). State: resident (rwkv_mi_state_load works on chains too). */
+RWKV_API bool rwkv_mi_decode_greedy_streams(struct rwkv_context * const * ctxs, size_t n_streams, const uint32_t * first_tokens, size_t n_tokens,
+                                            uint32_t * tokens_out, float * elapsed_ms);
+/* One process per GPU: this rank's stage (rwkv_mi_init_stage + clones, one per decode stream, all bound to one stream) runs its share
+ * of the same loop with ncclSend / ncclRecv of librccl.so on the stage's stream. librccl.so is dlopen'ed by the first rwkv_mi_comm_*
+ * call (librwkv.so itself does not depend on it). comm_fwd: residual stream rank -> rank + 1; comm_fb: the chosen token from the last
+ * rank to rank 0 -- two communicators of the same ranks (a single one would dead-lock, see runner.cpp). The 128-byte id of
+ * rwkv_mi_comm_unique_id (rank 0) is distributed by the caller (e.g. torch.distributed.broadcast). tokens_out is filled on the last rank. */
+RWKV_API bool rwkv_mi_comm_available(void);
+RWKV_API bool rwkv_mi_comm_unique_id(void * id_out, size_t capacity);
+RWKV_API void * rwkv_mi_comm_init(const void * id128, int rank, int world);
+RWKV_API void rwkv_mi_comm_free(void * comm);
+RWKV_API bool rwkv_mi_stage_run(struct rwkv_context * const * handles, size_t n_streams, const uint32_t * first_tokens, size_t n_tokens,
+                                int rank, int world, void * comm_fwd, void * comm_fb, uint32_t * tokens_out, float * elapsed_ms);
 /* Copies the context's logits (n_vocab floats, from the last step that produced any) to host memory. */
 RWKV_API bool rwkv_mi_logits_store(struct rwkv_context * ctx, float * logits_out);
 /* Device pointer of the context's logits (n_vocab floats), valid after a step that produced logits. */

@@ -243,7 +243,7 @@ RWKV_API const char * rwkv_get_system_info_string(void) {
 
 RWKV_API bool rwkv_mi_state_load(struct rwkv_context * ctx, const float * state_in) {
     ctx->last_error = RWKV_ERROR_NONE;
-    RW_NO_PIPELINE(ctx, false);
+    if (!ctx->stages.empty()) return pipeline_state_load(ctx, state_in);
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     if (!state_from_host(ctx, state_in)) return false;
     HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
@@ -252,8 +252,8 @@ RWKV_API bool rwkv_mi_state_load(struct rwkv_context * ctx, const float * state_
 
 RWKV_API bool rwkv_mi_state_store(struct rwkv_context * ctx, float * state_out) {
     ctx->last_error = RWKV_ERROR_NONE;
-    RW_NO_PIPELINE(ctx, false);
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, state_out != nullptr, "state_out is NULL");
+    if (!ctx->stages.empty()) return pipeline_state_store(ctx, state_out);
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     return fetch_outputs(ctx, state_out, nullptr);
 }
@@ -270,10 +270,10 @@ RWKV_API bool rwkv_mi_eval_resident(struct rwkv_context * ctx, const uint32_t * 
 
 RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_token, size_t n_tokens, uint32_t * tokens_out, float * elapsed_ms) {
     ctx->last_error = RWKV_ERROR_NONE;
-    RW_NO_PIPELINE(ctx, false);
     const size_t n_vocab = (size_t) ctx->model->n_vocab();
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, first_token < n_vocab, "Token is out of range");
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, n_tokens > 0, "n_tokens is 0");
+    if (!ctx->stages.empty()) { struct rwkv_context * one[1] = {ctx}; return pipeline_decode_greedy(one, 1, &first_token, n_tokens, tokens_out, elapsed_ms); }
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
     if (!upload_tokens(ctx, &first_token, 1)) return false;
     struct DevBuf { uint32_t * p = nullptr; ~DevBuf() { if (p) (void) hipFree(p); } } hist;   // freed on every exit

@@ -231,6 +231,10 @@ rwkv_context * pipeline_create(const char * path, uint32_t n_threads, const char
 void pipeline_destroy(rwkv_context * front);
 bool pipeline_eval(rwkv_context * front, const uint32_t * tokens, size_t n, size_t chunk, const float * state_in, float * state_out, float * logits_out);
 rwkv_context * pipeline_clone(rwkv_context * front, uint32_t n_threads);
+// runner.cpp: resident state of a chain; greedy decode of n_streams contexts (chains of the same stages, or one-device contexts) interleaved
+bool pipeline_state_load(rwkv_context * front, const float * state_in);
+bool pipeline_state_store(rwkv_context * front, float * state_out);
+bool pipeline_decode_greedy(rwkv_context * const * fronts, size_t n_streams, const uint32_t * first_tokens, size_t n_tokens, uint32_t * tokens_out, float * elapsed_ms);
 // after a poll time-out of the persistent kernel: drain, clear, drop the persistent path (see engine.hip)
 void recover_from_abort(rwkv_context * ctx);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)

@@ -1,0 +1,392 @@
+// runner.cpp -- the greedy decode loop of a layer pipeline, enqueued from C++ (no interpreter between tokens):
+//
+//   * inside one process over the stage chain of RWKV_MI_DEVICES (pipeline.cpp): rwkv_mi_decode_greedy_streams()
+//   * one process per GPU over RCCL send / recv on the stage's stream:              rwkv_mi_stage_run()
+//
+// Both run the SAME per-(token, decode stream, stage) iteration below and differ only in the Hop that carries a message from one
+// stage to the next (the residual stream forward, the chosen token back from the last stage to the first):
+//
+//   LocalHop   a mailbox in the receiver's HBM, hipMemcpyPeerAsync on the sender's stream (xGMI between GPUs), two events
+//   RcclHop    ncclSend / ncclRecv of librccl.so, which is dlopen'ed on first use -- librwkv.so keeps its one-GPU dependency list
+//
+// S decode streams (clones: shared weights, own recurrent state) are interleaved, so that with S >= number of stages every stage
+// has work while the others run theirs (rwkv.cpp_amd/pipeline.py states the protocol; this is its loop without Python per token).
+// The reference has no counterpart: its only device split is the CPU / one-GPU layer split of rwkv_model_loading.inc:129-142.
+#include "model.h"
+#include "rwkv_mi355x.h"
+
+#include <chrono>
+#include <cstring>
+#include <dlfcn.h>
+#include <memory>
+#include <mutex>
+
+using namespace rwkvmi;
+
+namespace {
+
+#define RUN_OK(CTX, CALL) \
+    do { hipError_t e_ = (CALL); RW_CTX_CHECK((CTX), RWKV_ERROR_GRAPH, false, e_ == hipSuccess, "HIP error: %s", hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// hops
+// ---------------------------------------------------------------------------------------------------------------
+struct Hop {
+    virtual ~Hop() {}
+    // message of decode stream j; both calls only enqueue. The sender's call for a message is made before the receiver's.
+    virtual bool send(int j, const void * src, size_t bytes, hipStream_t st) = 0;   // current device = the sender's
+    virtual bool recv(int j, void * dst, size_t bytes, hipStream_t st) = 0;         // current device = the receiver's
+};
+
+struct LocalHop : Hop {
+    int src_dev, dst_dev;
+    struct Slot { void * box = nullptr; hipEvent_t ready = nullptr, taken = nullptr; bool used = false; };
+    std::vector<Slot> slots;
+    size_t cap;
+    LocalHop(int sdev, int ddev, int n_streams, size_t bytes, bool & ok) : src_dev(sdev), dst_dev(ddev), slots((size_t) n_streams), cap(bytes) {
+        ok = hipSetDevice(ddev) == hipSuccess;
+        for (Slot & s : slots) {
+            ok = ok && hipMalloc(&s.box, bytes) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.taken, hipEventDisableTiming) == hipSuccess;
+        }
+    }
+    ~LocalHop() override {
+        (void) hipSetDevice(dst_dev);
+        for (Slot & s : slots) {
+            if (s.box) (void) hipFree(s.box);
+            if (s.ready) (void) hipEventDestroy(s.ready);
+            if (s.taken) (void) hipEventDestroy(s.taken);
+        }
+    }
+    bool send(int j, const void * src, size_t bytes, hipStream_t st) override {
+        Slot & s = slots[(size_t) j];
+        if (bytes > cap) return false;
+        if (s.used && hipStreamWaitEvent(st, s.taken, 0) != hipSuccess) return false;   // the previous message has left the mailbox
+        if (hipMemcpyPeerAsync(s.box, dst_dev, src, src_dev, bytes, st) != hipSuccess) return false;
+        s.used = true;
+        return hipEventRecord(s.ready, st) == hipSuccess;
+    }
+    bool recv(int j, void * dst, size_t bytes, hipStream_t st) override {
+        Slot & s = slots[(size_t) j];
+        if (!s.used || bytes > cap) return false;
+        if (hipStreamWaitEvent(st, s.ready, 0) != hipSuccess) return false;
+        if (hipMemcpyAsync(dst, s.box, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+        return hipEventRecord(s.taken, st) == hipSuccess;
+    }
+};
+
+// ---- librccl.so, bound at run time (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclSend, ncclRecv, ncclCommDestroy) ----
+struct UniqueId { char internal[128]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
+struct Rccl {
+    void * lib = nullptr;
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char * (*GetErrorString)(int) = nullptr;
+    std::string why;
+    bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && Send && Recv; }
+};
+Rccl & rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // an already loaded copy first (torch.distributed brings its own): two RCCL instances in one process would not share topology state
+        const char * names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char * n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (r.lib) break; }
+        for (const char * n : names) { if (r.lib) break; r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
+        if (!r.lib) { const char * e = dlerror(); r.why = e ? e : "librccl.so not found"; return; }
+        r.GetUniqueId = (int (*)(UniqueId *)) dlsym(r.lib, "ncclGetUniqueId");
+        r.CommInitRank = (int (*)(void **, int, UniqueId, int)) dlsym(r.lib, "ncclCommInitRank");
+        r.CommDestroy = (int (*)(void *)) dlsym(r.lib, "ncclCommDestroy");
+        r.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t)) dlsym(r.lib, "ncclSend");
+        r.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t)) dlsym(r.lib, "ncclRecv");
+        r.GetErrorString = (const char * (*)(int)) dlsym(r.lib, "ncclGetErrorString");
+        if (!r.ok()) r.why = "librccl.so lacks a point-to-point entry point";
+    });
+    return r;
+}
+constexpr int k_nccl_uint8 = 1;   // ncclUint8 (rccl.h)
+
+// A point-to-point edge of an RCCL communicator. `side` = true puts the transfer on an own stream, tied to the stage's stream with
+// events: the token feedback (last -> first) must not queue behind the forward hops of its rank. Point-to-point calls of one stream
+// run in order and a send completes only against its receive, so with everything on one stream a two-rank pipeline with two decode
+// streams dead-locks: rank 0 is in send x(t, 1) while rank 1 is in send token(t, 0), each waiting for the other's next receive.
+// Forward hops form a chain without cycles and stay on the stage's stream; the feedback gets its own communicator and stream.
+struct RcclHop : Hop {
+    void * comm; int peer; bool side;
+    hipStream_t own = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    RcclHop(void * c, int p, bool s, bool & ok) : comm(c), peer(p), side(s) {
+        ok = true;
+        if (side) ok = hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev_a, hipEventDisableTiming) == hipSuccess &&
+                       hipEventCreateWithFlags(&ev_b, hipEventDisableTiming) == hipSuccess;
+    }
+    ~RcclHop() override {
+        if (own) { (void) hipStreamSynchronize(own); (void) hipStreamDestroy(own); }
+        if (ev_a) (void) hipEventDestroy(ev_a);
+        if (ev_b) (void) hipEventDestroy(ev_b);
+    }
+    bool send(int, const void * src, size_t bytes, hipStream_t st) override {
+        Rccl & r = rccl();
+        if (!side) return r.Send(src, bytes, k_nccl_uint8, peer, comm, st) == 0;
+        // behind the producer of src; the stage's stream does not wait for the transfer (src is next written a whole round trip later)
+        if (hipEventRecord(ev_a, st) != hipSuccess || hipStreamWaitEvent(own, ev_a, 0) != hipSuccess) return false;
+        return r.Send(src, bytes, k_nccl_uint8, peer, comm, own) == 0;
+    }
+    bool recv(int, void * dst, size_t bytes, hipStream_t st) override {
+        Rccl & r = rccl();
+        if (!side) return r.Recv(dst, bytes, k_nccl_uint8, peer, comm, st) == 0;
+        // not before the stage's stream has reached this point (dst is still read by what is queued ahead; and a receive that sits on
+        // a compute unit long before its sender has anything keeps that unit from the persistent decode kernel)
+        if (hipEventRecord(ev_a, st) != hipSuccess || hipStreamWaitEvent(own, ev_a, 0) != hipSuccess) return false;
+        if (r.Recv(dst, bytes, k_nccl_uint8, peer, comm, own) != 0) return false;
+        return hipEventRecord(ev_b, own) == hipSuccess && hipStreamWaitEvent(st, ev_b, 0) == hipSuccess;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// one stage's share of the loop
+// ---------------------------------------------------------------------------------------------------------------
+struct StagePart {
+    std::vector<rwkv_context *> h;     // one context per decode stream (same stage, same device)
+    Hop * in = nullptr;                // residual stream from the previous stage (nullptr on the first)
+    Hop * out = nullptr;               // ... to the next stage (nullptr on the last)
+    Hop * tok_in = nullptr;            // chosen token from the last stage (first stage of a chain of more than one stage)
+    Hop * tok_out = nullptr;           // ... to the first stage (last stage of such a chain)
+    uint32_t * d_hist = nullptr;       // (last stage) [n_streams][n_tokens] chosen tokens, device
+    size_t n_tokens = 0;
+};
+
+// stage `p`, decode stream j, token index t: receive, run the layers, send. Everything is enqueued on the context's stream.
+bool stage_iteration(StagePart & p, rwkv_context * err, size_t t, int j) {
+    rwkv_context * c = p.h[(size_t) j];
+    Model & m = *c->model;
+    const size_t D = (size_t) m.n_embed();
+    auto fail = [&]() { err->last_error |= c->last_error ? c->last_error : (int) RWKV_ERROR_GRAPH; return false; };
+    if (hipSetDevice(m.device) != hipSuccess || !ensure_scratch(c, 1)) return fail();
+    if (m.has_embed) {
+        if (t > 0 && p.tok_in && !p.tok_in->recv(j, c->d_tokens, sizeof(uint32_t), c->stream)) return fail();
+    } else {
+        if (!p.in || !p.in->recv(j, c->b.x, D * sizeof(float), c->stream)) return fail();
+        if (m.arch_major == 7 && !p.in->recv(j, c->b.v_first, D * sizeof(float), c->stream)) return fail();
+    }
+    if (!forward_decode(c, m.has_head)) return fail();
+    if (m.has_head) {
+        // the chosen token: where this context's embedding reads it (a one-stage "chain"), else in the slot the feedback hop sends from
+        uint32_t * dst = m.has_embed ? c->d_tokens : c->d_next_token;
+        launch_argmax(c->d_logits, m.n_vocab(), dst, c->stream);
+        if (hipMemcpyAsync(p.d_hist + (size_t) j * p.n_tokens + t, dst, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail();
+        if (p.tok_out && t + 1 < p.n_tokens && !p.tok_out->send(j, dst, sizeof(uint32_t), c->stream)) return fail();
+    } else {
+        if (!p.out || !p.out->send(j, c->b.x, D * sizeof(float), c->stream)) return fail();
+        if (m.arch_major == 7 && !p.out->send(j, c->b.v_first, D * sizeof(float), c->stream)) return fail();
+    }
+    return true;
+}
+
+bool seed_tokens(StagePart & p, rwkv_context * err, const uint32_t * first_tokens) {
+    for (size_t j = 0; j < p.h.size(); j++) {
+        rwkv_context * c = p.h[j];
+        if (hipSetDevice(c->model->device) != hipSuccess || !upload_tokens_for(c, first_tokens + j, 1)) { err->last_error |= c->last_error ? c->last_error : (int) RWKV_ERROR_GRAPH; return false; }
+    }
+    return true;
+}
+
+// drains every context of a part; a poll time-out of the persistent kernel invalidates the run
+bool drain(StagePart & p, rwkv_context * err) {
+    bool ok = true;
+    for (rwkv_context * c : p.h) {
+        if (hipSetDevice(c->model->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { ok = false; continue; }
+        if (c->mega && mega_v6_aborted(c->mega, c->stream)) { recover_from_abort(c); ok = false; }
+    }
+    if (!ok) err->last_error |= RWKV_ERROR_GRAPH;
+    return ok;
+}
+
+struct DevMem {
+    void * p = nullptr; int dev = 0;
+    ~DevMem() { if (p) { (void) hipSetDevice(dev); (void) hipFree(p); } }
+};
+
+}  // namespace
+
+namespace rwkvmi {
+
+// ---- the stage chain of one process (fronts[j]->stages, or plain one-device contexts = chains of one stage) ----
+bool pipeline_decode_greedy(rwkv_context * const * fronts, size_t n_streams, const uint32_t * first_tokens, size_t n_tokens, uint32_t * tokens_out, float * elapsed_ms) {
+    rwkv_context * f0 = fronts[0];
+    auto stage_of = [](rwkv_context * f, size_t s) { return f->stages.empty() ? f : f->stages[s]; };
+    const size_t S = f0->stages.empty() ? 1 : f0->stages.size();
+    for (size_t j = 0; j < n_streams; j++) {
+        rwkv_context * f = fronts[j];
+        RW_CTX_CHECK(f0, RWKV_ERROR_ARGS, false, f != nullptr && (f->stages.empty() ? 1 : f->stages.size()) == S, "decode stream %zu is not a context of the same chain", j);
+        for (size_t s = 0; s < S; s++) {
+            const Model & a = *stage_of(f, s)->model, & b = *stage_of(f0, s)->model;
+            RW_CTX_CHECK(f0, RWKV_ERROR_ARGS, false, a.device == b.device && a.layer_begin == b.layer_begin && a.layer_end == b.layer_end, "decode stream %zu is not a clone of stream 0", j);
+        }
+        RW_CTX_CHECK(f0, RWKV_ERROR_ARGS, false, first_tokens[j] < (uint32_t) f0->model->n_vocab(), "Token of stream %zu is out of range", j);
+    }
+    int prev_dev = 0;
+    (void) hipGetDevice(&prev_dev);
+    struct Restore { int d; ~Restore() { (void) hipSetDevice(d); } } restore{prev_dev};
+    std::vector<StagePart> parts(S);
+    std::vector<std::unique_ptr<Hop>> hops;
+    const size_t hb = (size_t) f0->model->n_embed() * sizeof(float);
+    for (size_t s = 0; s < S; s++) {
+        for (size_t j = 0; j < n_streams; j++) { rwkv_context * c = stage_of(fronts[j], s); c->last_error = 0; c->print_errors = f0->print_errors; parts[s].h.push_back(c); }
+        parts[s].n_tokens = n_tokens;
+    }
+    auto add_hop = [&](size_t from, size_t to, size_t bytes) -> Hop * {
+        bool ok = false;
+        hops.emplace_back(new LocalHop(parts[from].h[0]->model->device, parts[to].h[0]->model->device, (int) n_streams, bytes, ok));
+        return ok ? hops.back().get() : nullptr;
+    };
+    for (size_t s = 0; s + 1 < S; s++) {
+        Hop * h = add_hop(s, s + 1, hb);
+        RW_CTX_CHECK(f0, RWKV_ERROR_ALLOC, false, h != nullptr, "cannot allocate the hand-over buffers of stage %zu", s);
+        parts[s].out = h; parts[s + 1].in = h;
+    }
+    if (S > 1) {
+        Hop * h = add_hop(S - 1, 0, sizeof(uint32_t));
+        RW_CTX_CHECK(f0, RWKV_ERROR_ALLOC, false, h != nullptr, "cannot allocate the token feedback buffers");
+        parts[S - 1].tok_out = h; parts[0].tok_in = h;
+    }
+    DevMem hist; hist.dev = parts[S - 1].h[0]->model->device;
+    RW_CTX_CHECK(f0, RWKV_ERROR_ALLOC, false, hipSetDevice(hist.dev) == hipSuccess && hipMalloc(&hist.p, n_streams * n_tokens * sizeof(uint32_t)) == hipSuccess, "cannot allocate the token history");
+    parts[S - 1].d_hist = (uint32_t *) hist.p;
+    if (!seed_tokens(parts[0], f0, first_tokens)) return false;
+    for (size_t s = 0; s < S; s++) for (rwkv_context * c : parts[s].h) { if (hipSetDevice(c->model->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { f0->last_error |= RWKV_ERROR_GRAPH; return false; } }
+    const auto t0 = std::chrono::steady_clock::now();
+    bool ok = true;
+    for (size_t t = 0; t < n_tokens && ok; t++)
+        for (size_t j = 0; j < n_streams && ok; j++)
+            for (size_t s = 0; s < S && ok; s++) ok = stage_iteration(parts[s], f0, t, (int) j);
+    bool clean = true;
+    for (size_t s = 0; s < S; s++) clean = drain(parts[s], f0) && clean;   // (always: nothing may be in flight when the hops are freed)
+    const auto t1 = std::chrono::steady_clock::now();
+    RW_CTX_CHECK(f0, RWKV_ERROR_GRAPH, false, ok, "greedy decode through the stage chain failed: %s", hipGetErrorString(hipGetLastError()));
+    RW_CTX_CHECK(f0, RWKV_ERROR_GRAPH, false, clean, "the persistent decode kernel of a stage timed out; the stage continues on the per-layer launches");
+    if (elapsed_ms) *elapsed_ms = (float) std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (tokens_out) RUN_OK(f0, hipMemcpy(tokens_out, hist.p, n_streams * n_tokens * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return true;
+}
+
+// resident state of a chain: every stage owns the slice of its layers
+bool pipeline_state_load(rwkv_context * front, const float * state_in) {
+    for (rwkv_context * c : front->stages) {
+        Model & m = *c->model;
+        c->last_error = 0; c->print_errors = front->print_errors;
+        bool ok = hipSetDevice(m.device) == hipSuccess;
+        if (ok && state_in) {
+            const int64_t per = m.state_per_layer();
+            const int64_t off = (int64_t) m.layer_begin * per, cnt = (int64_t) (m.layer_end - m.layer_begin) * per;
+            ok = hipMemcpyAsync(c->state[c->cur] + off, state_in + off, (size_t) cnt * sizeof(float), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        } else if (ok) ok = state_from_host(c, nullptr);
+        ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+        if (!ok) { front->last_error |= c->last_error ? c->last_error : (int) RWKV_ERROR_GRAPH; return false; }
+    }
+    return true;
+}
+bool pipeline_state_store(rwkv_context * front, float * state_out) {
+    for (rwkv_context * c : front->stages) {
+        Model & m = *c->model;
+        const int64_t per = m.state_per_layer();
+        const int64_t off = (int64_t) m.layer_begin * per, cnt = (int64_t) (m.layer_end - m.layer_begin) * per;
+        const bool ok = hipSetDevice(m.device) == hipSuccess &&
+                        hipMemcpyAsync(state_out + off, c->state[c->cur] + off, (size_t) cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                        hipStreamSynchronize(c->stream) == hipSuccess;
+        if (!ok) { front->last_error |= RWKV_ERROR_GRAPH; return false; }
+    }
+    return true;
+}
+
+}  // namespace rwkvmi
+
+extern "C" {
+
+RWKV_API bool rwkv_mi_decode_greedy_streams(struct rwkv_context * const * ctxs, size_t n_streams, const uint32_t * first_tokens, size_t n_tokens,
+                                            uint32_t * tokens_out, float * elapsed_ms) {
+    if (!ctxs || n_streams == 0 || !ctxs[0]) return false;
+    ctxs[0]->last_error = RWKV_ERROR_NONE;
+    RW_CTX_CHECK(ctxs[0], RWKV_ERROR_ARGS, false, first_tokens != nullptr && n_tokens > 0, "first_tokens is NULL or n_tokens is 0");
+    return pipeline_decode_greedy(ctxs, n_streams, first_tokens, n_tokens, tokens_out, elapsed_ms);
+}
+
+// ---- one process per GPU: communicators of librccl.so ----
+RWKV_API bool rwkv_mi_comm_unique_id(void * id_out, size_t capacity) {
+    Rccl & r = rccl();
+    if (!r.ok() || !id_out || capacity < sizeof(UniqueId)) { if (!r.ok()) fprintf(stderr, "rwkv_mi_comm_unique_id: %s\n", r.why.c_str()); return false; }
+    UniqueId id;
+    if (r.GetUniqueId(&id) != 0) return false;
+    memcpy(id_out, &id, sizeof(id));
+    return true;
+}
+RWKV_API void * rwkv_mi_comm_init(const void * id128, int rank, int world) {
+    Rccl & r = rccl();
+    if (!r.ok() || !id128) { if (!r.ok()) fprintf(stderr, "rwkv_mi_comm_init: %s\n", r.why.c_str()); return nullptr; }
+    UniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    void * comm = nullptr;
+    const int e = r.CommInitRank(&comm, world, id, rank);
+    if (e != 0) { fprintf(stderr, "rwkv_mi_comm_init: ncclCommInitRank failed: %s\n", r.GetErrorString ? r.GetErrorString(e) : "?"); return nullptr; }
+    return comm;
+}
+RWKV_API void rwkv_mi_comm_free(void * comm) {
+    Rccl & r = rccl();
+    if (comm && r.ok()) (void) r.CommDestroy(comm);
+}
+RWKV_API bool rwkv_mi_comm_available(void) { return rccl().ok(); }
+
+// This rank's stage of the pipeline for n_tokens greedy tokens on n_streams decode streams (handles: contexts of rwkv_mi_init_stage and
+// its clones, bound to ONE stream with rwkv_mi_set_stream or on their own). comm_fwd carries the residual stream rank -> rank + 1,
+// comm_fb the chosen token from the last rank to rank 0 (two communicators: see RcclHop). tokens_out ([n_streams][n_tokens]) is
+// filled on the last rank. elapsed_ms: this rank's wall time of the loop including the final drain.
+RWKV_API bool rwkv_mi_stage_run(struct rwkv_context * const * handles, size_t n_streams, const uint32_t * first_tokens, size_t n_tokens,
+                                int rank, int world, void * comm_fwd, void * comm_fb, uint32_t * tokens_out, float * elapsed_ms) {
+    if (!handles || n_streams == 0 || !handles[0]) return false;
+    rwkv_context * c0 = handles[0];
+    c0->last_error = RWKV_ERROR_NONE;
+    RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, c0->stages.empty(), "rwkv_mi_stage_run takes stage contexts (rwkv_mi_init_stage), not a RWKV_MI_DEVICES chain");
+    RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, n_tokens > 0 && rank >= 0 && rank < world, "bad n_tokens / rank / world");
+    const Model & m = *c0->model;
+    RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, m.has_embed == (rank == 0) && m.has_head == (rank == world - 1), "the stage's layer range does not fit rank %d of %d", rank, world);
+    RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, world == 1 || (comm_fwd && comm_fb && rccl().ok()), "a pipeline of %d ranks needs two communicators (rwkv_mi_comm_init)", world);
+    RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, !m.has_embed || first_tokens != nullptr, "the first stage needs the seed tokens");
+    StagePart part;
+    for (size_t j = 0; j < n_streams; j++) {
+        RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, handles[j] && handles[j]->model->device == m.device, "decode stream %zu is not on this stage's device", j);
+        handles[j]->last_error = 0;
+        part.h.push_back(handles[j]);
+    }
+    part.n_tokens = n_tokens;
+    RUN_OK(c0, hipSetDevice(m.device));
+    std::unique_ptr<Hop> in, out, tin, tout;
+    bool ok = true, o = true;
+    if (rank > 0) { in.reset(new RcclHop(comm_fwd, rank - 1, false, o)); ok = ok && o; part.in = in.get(); }
+    if (rank + 1 < world) { out.reset(new RcclHop(comm_fwd, rank + 1, false, o)); ok = ok && o; part.out = out.get(); }
+    if (world > 1 && rank == 0) { tin.reset(new RcclHop(comm_fb, world - 1, true, o)); ok = ok && o; part.tok_in = tin.get(); }
+    if (world > 1 && rank == world - 1) { tout.reset(new RcclHop(comm_fb, 0, true, o)); ok = ok && o; part.tok_out = tout.get(); }
+    RW_CTX_CHECK(c0, RWKV_ERROR_ALLOC, false, ok, "cannot create the streams of the token feedback");
+    DevMem hist; hist.dev = m.device;
+    if (m.has_head) {
+        RUN_OK(c0, hipMalloc(&hist.p, n_streams * n_tokens * sizeof(uint32_t)));
+        part.d_hist = (uint32_t *) hist.p;
+    }
+    if (m.has_embed && !seed_tokens(part, c0, first_tokens)) return false;
+    for (rwkv_context * c : part.h) RUN_OK(c0, hipStreamSynchronize(c->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t t = 0; t < n_tokens && ok; t++)
+        for (size_t j = 0; j < n_streams && ok; j++) ok = stage_iteration(part, c0, t, (int) j);
+    const bool clean = drain(part, c0);
+    in.reset(); out.reset(); tin.reset(); tout.reset();   // (drains the feedback streams)
+    const auto t1 = std::chrono::steady_clock::now();
+    RW_CTX_CHECK(c0, RWKV_ERROR_GRAPH, false, ok, "the stage's decode loop failed: %s", hipGetErrorString(hipGetLastError()));
+    RW_CTX_CHECK(c0, RWKV_ERROR_GRAPH, false, clean, "the persistent decode kernel timed out; the stage continues on the per-layer launches");
+    if (elapsed_ms) *elapsed_ms = (float) std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (tokens_out && m.has_head) RUN_OK(c0, hipMemcpy(tokens_out, hist.p, n_streams * n_tokens * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return true;
+}
+
+}  // extern "C"

@@ -13,6 +13,7 @@ tests/test_pipeline_cpu.py plugs in the CPU oracle to check partitioning and pro
 """
 import ctypes
 import os
+import sys
 import time
 from typing import List, Optional, Sequence, Tuple
 
@@ -140,6 +141,64 @@ class LibStageExecutor(StageExecutor):
             self.L.rwkv_free(h)
         self.L.rwkv_free(self.ctx)
         self._handles = []
+
+
+class RcclComms:
+    """The two communicators of the C++ stage runner (runner.cpp): rank 0 draws the ids, torch.distributed carries them to the others,
+    every rank joins with rwkv_mi_comm_init (= ncclCommInitRank of the librccl.so the library dlopens)."""
+
+    def __init__(self, lib, dist, rank: int, world: int):
+        import numpy as np
+        import torch
+        L = lib.library
+        if not L.rwkv_mi_comm_available():
+            raise RuntimeError("librccl.so could not be loaded")
+        ids = np.zeros((2, 128), dtype=np.uint8)
+        if rank == 0:
+            for k in range(2):
+                if not L.rwkv_mi_comm_unique_id(ctypes.c_void_p(ids[k].ctypes.data), 128):
+                    raise RuntimeError("ncclGetUniqueId failed")
+        t = torch.from_numpy(ids)
+        if dist.get_backend() != "gloo":
+            t = t.cuda()
+        dist.broadcast(t, src=0)
+        ids = np.ascontiguousarray(t.cpu().numpy())
+        self.L = L
+        self.fwd = L.rwkv_mi_comm_init(ctypes.c_void_p(ids[0].ctypes.data), rank, world)
+        self.fb = L.rwkv_mi_comm_init(ctypes.c_void_p(ids[1].ctypes.data), rank, world)
+        if not self.fwd or not self.fb:
+            raise RuntimeError("ncclCommInitRank failed")
+
+    def close(self):
+        for c in (self.fwd, self.fb):
+            if c:
+                self.L.rwkv_mi_comm_free(ctypes.c_void_p(c))
+        self.fwd = self.fb = None
+
+
+def run_pipeline_native(ex: "LibStageExecutor", rank: int, world: int, first_tokens: Sequence[int], n_tokens: int, handles, comms: Optional[RcclComms],
+                        sync=None) -> Tuple[Optional[List[List[int]]], float]:
+    """run_pipeline with the loop inside librwkv.so (rwkv_mi_stage_run): this rank enqueues its stage's steps and the ncclSend / ncclRecv
+    of the hand-overs on the stage's stream from C++ -- no Python, no torch.distributed call per token."""
+    import numpy as np
+    S = len(first_tokens)
+    L = ex.L
+    arr = (ctypes.c_void_p * S)(*handles[:S])
+    first = (ctypes.c_uint32 * S)(*[int(t) for t in first_tokens])
+    out = np.zeros((S, n_tokens), dtype=np.uint32)
+    ms = ctypes.c_float(0.0)
+    if sync:
+        sync()
+    t0 = time.perf_counter()
+    with ex.stream_context():
+        ok = L.rwkv_mi_stage_run(arr, S, first, n_tokens, rank, world, ctypes.c_void_p(comms.fwd if comms else None), ctypes.c_void_p(comms.fb if comms else None),
+                                 out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ctypes.byref(ms))
+    if not ok:
+        raise ValueError("rwkv_mi_stage_run failed")
+    if sync:
+        sync()
+    elapsed = time.perf_counter() - t0
+    return ([[int(v) for v in row] for row in out] if ex.is_last else None), elapsed
 
 
 def run_pipeline(ex: StageExecutor, dist, rank: int, world: int, first_tokens: Sequence[int], n_tokens: int, handles=None,
@@ -274,12 +333,30 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
 
     red_dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
     fb = dist.new_group(list(range(world)))   # own communicator (and stream) for the token feedback
+    # The loop itself: inside librwkv.so (runner.cpp: ncclSend / ncclRecv on the stage's stream) whenever the job runs on RCCL;
+    # the Python loop over torch.distributed stays for gloo (CPU tests, one-GPU smoke runs) and as RWKV_MI_PIPELINE_RUNNER=py.
+    comms = None
+    if dist.get_backend() != "gloo" and os.environ.get("RWKV_MI_PIPELINE_RUNNER", "native") != "py":
+        try:
+            comms = RcclComms(lib, dist, rank, world)
+        except RuntimeError as e:
+            print(f"[bench] rank {rank}: native stage runner unavailable ({e}); using the torch.distributed loop", file=sys.stderr)
+        ok = torch.tensor([1.0 if comms else 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 0.5 and comms:
+            comms.close()
+            comms = None
+
+    def go(e, streams, n, hs):
+        if comms:
+            return run_pipeline_native(e, rank, world, streams, n, hs, comms, sync=sync)
+        return run_pipeline(e, dist, rank, world, streams, n, handles=hs, sync=sync, fb_group=fb)
 
     def probe(e, hs):
         for h in hs:
             e.reset(h)
-        run_pipeline(e, dist, rank, world, first, 2, handles=hs, sync=sync, fb_group=fb)
-        _, el = run_pipeline(e, dist, rank, world, first, 6, handles=hs, sync=sync, fb_group=fb)
+        go(e, first, 2, hs)
+        _, el = go(e, first, 6, hs)
         bad = 0.0 if all(e.healthy(h) for h in hs) else 1e9
         t = torch.tensor([el + bad], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -308,8 +385,8 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
         for h in hs:
             ex.reset(h)
         if warmup:
-            run_pipeline(ex, dist, rank, world, streams, warmup, handles=hs, sync=sync, fb_group=fb)
-        _, el = run_pipeline(ex, dist, rank, world, streams, steps, handles=hs, sync=sync, fb_group=fb)
+            go(ex, streams, warmup, hs)
+        _, el = go(ex, streams, steps, hs)
         t = torch.tensor([el], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -329,12 +406,15 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
         "dtype": "int8 x int4 dot, f32 accumulate (Q4_0 weights, Q8_0 activations); f16 head", "data": "synthetic",
         "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode through a layer pipeline of {world} GPUs (RCCL send/recv of the "
                                f"residual stream between stages), state resident in HBM",
-                   "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": f"pp{world}", "stage_layers": ranges, "stage_decode_path": path_used},
+                   "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": f"pp{world}", "stage_layers": ranges, "stage_decode_path": path_used,
+                   "decode_loop": "librwkv.so stage runner (ncclSend / ncclRecv on the stage stream)" if comms else "torch.distributed send / recv per token"},
         "multi_stream": {"streams": world, "tokens_per_s_aggregate": total_tok_s, "ms_per_step": multi * 1e3 / args.steps,
                          "note": f"{world} independent decode streams in flight through the same pipeline (one step = one token on every stream): "
                                  "aggregate throughput, weak scaling"},
         "hbm": {"algorithmic_bytes_per_token": int(bpt.item()), "achieved_GBps_single_stream": bpt.item() * single_tok_s / 1e9,
                 "achieved_GBps_aggregate": bpt.item() * total_tok_s / 1e9},
     }
+    if comms:
+        comms.close()
     ex.close()
     return result

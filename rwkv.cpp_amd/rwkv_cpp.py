@@ -125,6 +125,20 @@ class RWKVSharedLibrary:
         L.rwkv_mi_decode_sample.restype = ctypes.c_bool
         L.rwkv_mi_test_set_tag.argtypes = [c_ctx, ctypes.c_uint32]
         L.rwkv_mi_test_set_tag.restype = ctypes.c_bool
+        # the C++ decode loop of a pipeline (runner.cpp)
+        L.rwkv_mi_decode_greedy_streams.argtypes = [ctypes.POINTER(c_ctx), ctypes.c_size_t, P_UINT32, ctypes.c_size_t, P_UINT32, P_FLOAT]
+        L.rwkv_mi_decode_greedy_streams.restype = ctypes.c_bool
+        L.rwkv_mi_comm_available.argtypes = []
+        L.rwkv_mi_comm_available.restype = ctypes.c_bool
+        L.rwkv_mi_comm_unique_id.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.rwkv_mi_comm_unique_id.restype = ctypes.c_bool
+        L.rwkv_mi_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.rwkv_mi_comm_init.restype = ctypes.c_void_p
+        L.rwkv_mi_comm_free.argtypes = [ctypes.c_void_p]
+        L.rwkv_mi_comm_free.restype = None
+        L.rwkv_mi_stage_run.argtypes = [ctypes.POINTER(c_ctx), ctypes.c_size_t, P_UINT32, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                        P_UINT32, P_FLOAT]
+        L.rwkv_mi_stage_run.restype = ctypes.c_bool
 
     # --- rwkv.h ---------------------------------------------------------------------------------------------
 
@@ -321,6 +335,20 @@ class RWKVModel:
         ms = ctypes.c_float(0.0)
         if not self._library.library.rwkv_mi_decode_greedy(self._ctx.ptr, first_token, n_tokens, ctypes.cast(out.ctypes.data, P_UINT32), ctypes.byref(ms)):
             raise ValueError("rwkv_mi_decode_greedy failed")
+        return out, float(ms.value)
+
+    @staticmethod
+    def decode_greedy_streams(models: List["RWKVModel"], first_tokens: List[int], n_tokens: int) -> Tuple[np.ndarray, float]:
+        """Greedy decode of several resident-state contexts (a model and its clones; RWKV_MI_DEVICES chains included) interleaved by the
+        library's C++ loop: tokens [n_streams][n_tokens], wall milliseconds."""
+        n = len(models)
+        L = models[0]._library.library
+        arr = (ctypes.c_void_p * n)(*[m._ctx.ptr for m in models])
+        first = (ctypes.c_uint32 * n)(*first_tokens)
+        out = np.empty((n, n_tokens), dtype=np.uint32)
+        ms = ctypes.c_float(0.0)
+        if not L.rwkv_mi_decode_greedy_streams(arr, n, first, n_tokens, ctypes.cast(out.ctypes.data, P_UINT32), ctypes.byref(ms)):
+            raise ValueError("rwkv_mi_decode_greedy_streams failed")
         return out, float(ms.value)
 
     def sample(self, temperature: float = 1.0, top_p: float = 0.8, u: float = -1.0, seed: int = 0) -> int:

@@ -45,6 +45,8 @@ CONFIGS = {
     "test-v5.1": ModelSpec("5.1", 2, 256, 512, 896, 64, name="test-v5.1"),
     "test-v5.2": ModelSpec("5.2", 2, 256, 512, 896, 64, name="test-v5.2"),
     "test-v6": ModelSpec("6", 2, 256, 512, 896, 64, 32, 64, name="test-v6"),
+    # many thin layers: the layer chain with one stage per GPU of an eight-GPU node (tests: eight stages on one device)
+    "chain-v6-32x256": ModelSpec("6", 32, 256, 512, 896, 64, 32, 64, name="chain-v6-32x256"),
     # geometries the persistent RWKV-6 decode kernel is built for (mega_v6.hip), with few layers and a small vocabulary
     "mega-v6-2048": ModelSpec("6", 3, 2048, 512, 7168, 64, 32, 64, name="mega-v6-2048"),
     "mega-v6-4096": ModelSpec("6", 2, 4096, 512, 14336, 64, 64, 128, name="mega-v6-4096"),

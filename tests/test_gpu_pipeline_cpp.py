@@ -94,3 +94,86 @@ def test_bad_device_list_is_an_argument_error(tmp_path):
                 model(p)
         finally:
             del os.environ["RWKV_MI_DEVICES"]
+
+
+def test_eight_stages_on_one_device(tmp_path):
+    """An eight-GPU node's chain (RWKV_MI_DEVICES=0-7) with every stage on device 0: a 32-layer model in eight stages of four layers.
+    rwkv.h entry points, the resident-state extensions and the C++ greedy loop (runner.cpp) must all equal the oracle / the one-device
+    context bit for bit -- single stream and several clones interleaved."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS["chain-v6-32x256"]
+    synth.write_model(p, spec, "Q4_0", seed=37)
+    om = O.OracleModel(p)
+    pm = _pipeline_model(p, "0,0,0,0,0,0,0,0")
+    one = model(p)
+    ost, st = om.init_state(), None
+    for i, t in enumerate(TOKENS):
+        ol, ost = om.eval(t, ost)
+        lg, st = pm.eval(t, st)
+        assert np.array_equal(lg, ol) and np.array_equal(st, ost), i
+    # resident state on the chain: load, greedy loop in C++, store
+    one.state_load(ost)
+    pm.state_load(ost)
+    ref, _ = one.decode_greedy(7, 40)
+    got, ms = pm.decode_greedy(7, 40)
+    assert list(got) == list(ref) and ms > 0
+    assert np.array_equal(pm.state_store(), one.state_store())
+    # three decode streams through the same chain, interleaved by the library
+    clones = [pm, pm.clone(), pm.clone()]
+    firsts = [7, 8, 300]
+    for m in clones:
+        m.state_load(None)
+    toks, _ = type(pm).decode_greedy_streams(clones, firsts, 24)
+    for j, f in enumerate(firsts):
+        one.state_load(None)
+        ref, _ = one.decode_greedy(f, 24)
+        assert list(toks[j]) == list(ref), j
+        assert np.array_equal(clones[j].state_store(), one.state_store()), j
+    # the same entry point on plain one-device contexts (chains of one stage)
+    pair = [one, one.clone()]
+    for m in pair:
+        m.state_load(None)
+    toks2, _ = type(pm).decode_greedy_streams(pair, firsts[:2], 24)
+    assert np.array_equal(toks2, toks[:2])
+    pair[1].free()
+    for m in clones[1:]:
+        m.free()
+    pm.free()
+    one.free()
+    om.free()
+
+
+def test_native_stage_runner_on_one_rank(tmp_path):
+    """rwkv_mi_stage_run (the loop one process per GPU runs, ncclSend / ncclRecv on the stage's stream) with a world of one: no hop,
+    same iteration. And librccl.so can be bound at run time: an id, a communicator of one rank."""
+    import ctypes
+    lib = library()
+    L = lib.library
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS["test-v6"]
+    synth.write_model(p, spec, "Q5_1", seed=41)
+    one = model(p)
+    one.state_load(None)
+    ref, _ = one.decode_greedy(9, 16)
+    ctx = L.rwkv_mi_init_stage(p.encode(), 1, 0, spec.n_layer)
+    assert ctx
+    assert L.rwkv_mi_state_load(ctx, None)
+    arr = (ctypes.c_void_p * 1)(ctx)
+    first = (ctypes.c_uint32 * 1)(9)
+    out = np.zeros((1, 16), dtype=np.uint32)
+    ms = ctypes.c_float(0.0)
+    assert L.rwkv_mi_stage_run(arr, 1, first, 16, 0, 1, None, None, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ctypes.byref(ms))
+    assert list(out[0]) == list(ref)
+    # a stage that is not the whole model refuses a world of one
+    half = L.rwkv_mi_init_stage(p.encode(), 1, 0, 1)
+    assert half and not L.rwkv_mi_stage_run((ctypes.c_void_p * 1)(half), 1, first, 4, 0, 1, None, None, None, None)
+    L.rwkv_free(half)
+    L.rwkv_free(ctx)
+    assert L.rwkv_mi_comm_available()
+    uid = np.zeros(128, dtype=np.uint8)
+    assert L.rwkv_mi_comm_unique_id(ctypes.c_void_p(uid.ctypes.data), 128) and uid.any()
+    comm = L.rwkv_mi_comm_init(ctypes.c_void_p(uid.ctypes.data), 0, 1)
+    assert comm
+    L.rwkv_mi_comm_free(ctypes.c_void_p(comm))
+    one.free()
