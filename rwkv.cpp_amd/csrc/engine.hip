@@ -512,7 +512,9 @@ struct Runner {
             mm(L.att_v2, b.lr1, b.sx, epi(EPI_BIAS_SIGMOID, f(L.att_v0)));
             launch_v7_vmix(b.v, b.v_first, b.sx, T * D, st);
         }
-        launch_wkv7(b.r, b.w, b.t0, b.v, b.t1, b.t2, sin + 2 * D, sout + 2 * D, b.out, T, H, S, st);
+        static const bool no_seq7 = getenv("RWKV_MI_NO_WKV7_SEQ") != nullptr;   // (measurement aid: the single-token form over the whole sequence)
+        if (S == 64 && T >= k_mfma_min_tokens && !no_seq7) launch_wkv7_seq(b.r, b.w, b.t0, b.v, b.t1, b.t2, sin + 2 * D, sout + 2 * D, b.out, T, H, st);
+        else launch_wkv7(b.r, b.w, b.t0, b.v, b.t1, b.t2, sin + 2 * D, sout + 2 * D, b.out, T, H, S, st);
         launch_groupnorm(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), 64e-5f, b.g, b.t0, b.r, b.v, f(L.att_r_k), T, H, S, st);
         mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
     }

@@ -90,6 +90,9 @@ void launch_wkv6(const float * r, const float * k, const float * v, const float 
 // RWKV-7 WKV recurrence (rwkv_operators_wkv_v7.inc:37-107). state[h][i=value][j=key]; a = -kk, b = kk*a_gate.
 void launch_wkv7(const float * r, const float * w, const float * k, const float * v, const float * a, const float * b,
                  const float * state_in, float * state_out, float * out, int64_t T, int64_t H, int64_t S, hipStream_t st);
+// sequence form, head size 64 (prefill.hip): four rows per wave, the row's two ordered sums as DPP chains
+bool launch_wkv7_seq(const float * r, const float * w, const float * k, const float * v, const float * a, const float * b,
+                     const float * state_in, float * state_out, float * out, int64_t T, int64_t H, hipStream_t st);
 
 // Per-head group norm * ln_x.w + ln_x.b, optional v7 bonus (+ v * sum_head(k*r*r_k)), optional gate multiply
 // (rwkv_graph.inc:280-289, 375-382, 465-479). In place on x[T][H*S].

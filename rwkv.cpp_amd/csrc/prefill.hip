@@ -856,6 +856,157 @@ bool launch_wkv6_seq(const float * r, const float * k, const float * v, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// WKV-7 over a sequence (rwkv_wkv_v7_impl, rwkv_operators_wkv_v7.inc:37-107).
+//
+// Per token, head and value row i:  sa = sum_j a_j s_ij  (j = 0 .. 63 IN THAT ORDER, from 0),  s_ij <- (s_ij w_j + v_i k_j) + sa b_j,
+// out_i = sum_j s_ij r_j (same order, from 0). The first sum needs the whole row before any element of it may change, so -- unlike
+// WKV-6 -- tokens cannot be skewed across the lanes of a row: every token costs one 64-step dependent chain per row, whatever the
+// layout. The single-token form (k_wkv7: lane = row, the row's 64 elements in registers) pays that chain once per 64 rows but also
+// runs the 64-element update and the second chain serially in every lane: ~580 instructions per token on H waves (40 of the chip's
+// 1024 SIMDs at 2.9B). Here a wave owns FOUR rows, lane = 16 * row + q with q = elements 4 q .. 4 q + 3 of the row:
+//   * the update is 4 elements per lane (28 instructions instead of 448);
+//   * the sa chain runs down the 16 lanes of a DPP row: step q adds lane q's four products, in order, onto what lane q - 1 produced
+//     in the step before (row_shr:1, lane 0 receives 0.0f like the reference's `sa = 0`); lanes other than q compute values nobody
+//     reads. 64 dependent adds per token -- the floor -- then one ds_bpermute hands lane 15's sum to the row;
+//   * the out chain IS skewed: it only reads. Lane q parks its four products s_ij r_j of token t in an LDS ring (own column, used as an
+//     indexed register file: no barrier) and at step sigma adds those of token sigma - q onto the sum it receives from lane q - 1;
+//     lane 15 emits out[sigma - 15]. Four adds per token instead of 64.
+// ~130 instructions per token and wave, 16 H workgroups of 4 waves. Per-token operands are staged through LDS in chunks of 32 tokens
+// (global loads of chunk c + 1 in flight during chunk c), read as one 16-byte vector per array and token, one token ahead.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int W7_CH = 32;                                                     // tokens per staged chunk (the staging loops assume 32)
+constexpr int W7_LDS = (2 * W7_CH * (5 * 64 + 16) + 4 * 16 * 64 * 4) * 4;     // two chunk buffers (r w k a b: 64 each, v: 16 rows) + the out-chain rings
+
+__global__ __launch_bounds__(256) void k_wkv7_seq(const float * __restrict__ r, const float * __restrict__ w, const float * __restrict__ k,
+                                                  const float * __restrict__ v, const float * __restrict__ a, const float * __restrict__ b,
+                                                  const float * __restrict__ state_in, float * __restrict__ state_out, float * __restrict__ out,
+                                                  int T, int H) {
+    constexpr int S = 64, CH = W7_CH, TOKF = 5 * 64 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float * l_tok = reinterpret_cast<float *>(lds_raw);                       // [2][CH][r 64 | w 64 | k 64 | a 64 | b 64 | v 16]
+    float4 * l_ring = reinterpret_cast<float4 *>(l_tok + 2 * CH * TOKF);      // [4 waves][16 tokens][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t h = blockIdx.x >> 2;
+    const int rg = (int) (blockIdx.x & 3);                                    // 16 rows of the head per workgroup
+    const int q = lane & 15, rr = lane >> 4;
+    const int row_wg = 4 * wave + rr, i = 16 * rg + row_wg;
+    const int64_t D = (int64_t) H * S;
+    float4 * const ring = l_ring + wave * 16 * 64 + lane;
+
+    float s0, s1, s2, s3;
+    {
+        const float4 q4 = *reinterpret_cast<const float4 *>(state_in + h * S * S + (int64_t) i * S + 4 * q);
+        s0 = q4.x; s1 = q4.y; s2 = q4.z; s3 = q4.w;
+    }
+    // staging: chunk c = tokens [CH c, CH c + CH): five arrays of CH x 16 float4 = ten per thread; v: CH x 16 floats = two per thread
+    static_assert(CH == 32, "the staging below is written for chunks of 32 tokens");
+    float4 g0, g1, g2, g3, g4, g5, g6, g7, g8, g9;     // (named registers: an array indexed inside the lambdas ended up in scratch)
+    float gva, gvb;
+    auto ld4 = [&](const float * __restrict__ src, int c, int half) __attribute__((always_inline)) -> float4 {
+        const int rem = half * 256 + tid;                       // (token, float4) of the chunk: 16 float4 per token
+        int t = CH * c + (rem >> 4);
+        t = t < T ? t : T - 1;                                  // (clamped tokens are never consumed)
+        return *reinterpret_cast<const float4 *>(src + (int64_t) t * D + h * S + (rem & 15) * 4);
+    };
+    auto ldv = [&](int c, int half) __attribute__((always_inline)) -> float {
+        const int e = half * 256 + tid;
+        int t = CH * c + (e >> 4);
+        t = t < T ? t : T - 1;
+        return v[(int64_t) t * D + h * S + 16 * rg + (e & 15)];
+    };
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        g0 = ld4(r, c, 0); g1 = ld4(r, c, 1); g2 = ld4(w, c, 0); g3 = ld4(w, c, 1); g4 = ld4(k, c, 0); g5 = ld4(k, c, 1);
+        g6 = ld4(a, c, 0); g7 = ld4(a, c, 1); g8 = ld4(b, c, 0); g9 = ld4(b, c, 1);
+        gva = ldv(c, 0); gvb = ldv(c, 1);
+    };
+    auto st4 = [&](float * buf, int arr, int half, const float4 & val) __attribute__((always_inline)) {
+        const int rem = half * 256 + tid;
+        *reinterpret_cast<float4 *>(buf + (rem >> 4) * TOKF + arr * 64 + (rem & 15) * 4) = val;
+    };
+    auto commit = [&](int c) __attribute__((always_inline)) {
+        float * buf = l_tok + (c & 1) * CH * TOKF;
+        st4(buf, 0, 0, g0); st4(buf, 0, 1, g1); st4(buf, 1, 0, g2); st4(buf, 1, 1, g3); st4(buf, 2, 0, g4); st4(buf, 2, 1, g5);
+        st4(buf, 3, 0, g6); st4(buf, 3, 1, g7); st4(buf, 4, 0, g8); st4(buf, 4, 1, g9);
+        buf[(tid >> 4) * TOKF + 320 + (tid & 15)] = gva;
+        buf[((256 + tid) >> 4) * TOKF + 320 + (tid & 15)] = gvb;
+    };
+    struct Tok { float4 r, w, k, a, b; float v; };
+    auto read_tok = [&](int c, int tt, Tok & o) __attribute__((always_inline)) {
+        const float * bt = l_tok + ((c & 1) * CH + tt) * TOKF + 4 * q;
+        o.r = *reinterpret_cast<const float4 *>(bt);
+        o.w = *reinterpret_cast<const float4 *>(bt + 64);
+        o.k = *reinterpret_cast<const float4 *>(bt + 128);
+        o.a = *reinterpret_cast<const float4 *>(bt + 192);
+        o.b = *reinterpret_cast<const float4 *>(bt + 256);
+        o.v = l_tok[((c & 1) * CH + tt) * TOKF + 320 + row_wg];
+    };
+    float o_run = 0.0f;                                          // the out chain's running sum as this lane last produced it
+    // one step: `upd` = a token is consumed (state update + its products into the ring); the out chain always advances
+    auto step = [&](int sigma, bool upd, const Tok & tk) __attribute__((always_inline)) {
+        if (upd) {
+            const float p0 = tk.a.x * s0, p1 = tk.a.y * s1, p2 = tk.a.z * s2, p3 = tk.a.w * s3;
+            // independent of sa: v k, s w and their sum
+            const float kv0 = tk.v * tk.k.x, kv1 = tk.v * tk.k.y, kv2 = tk.v * tk.k.z, kv3 = tk.v * tk.k.w;
+            const float t0 = s0 * tk.w.x + kv0, t1 = s1 * tk.w.y + kv1, t2 = s2 * tk.w.z + kv2, t3 = s3 * tk.w.w + kv3;
+            float x = 0.0f, y = 0.0f;
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x111 /* row_shr:1 */, 0xF, 0xF, false)) + p0;
+                x += p1; x += p2; x += p3;
+                y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xF, 0xF, false)) + p0;
+                y += p1; y += p2; y += p3;
+            }
+            // lane q's sum is final after step q: even q in x, odd q in y; lane 15 (odd) holds the row's sa in y
+            const float sa = __int_as_float(__builtin_amdgcn_ds_bpermute((lane | 15) << 2, __float_as_int(y)));
+            const float n0 = t0 + sa * tk.b.x, n1 = t1 + sa * tk.b.y, n2 = t2 + sa * tk.b.z, n3 = t3 + sa * tk.b.w;
+            s0 = n0; s1 = n1; s2 = n2; s3 = n3;
+            ring[(sigma & 15) * 64] = make_float4(n0 * tk.r.x, n1 * tk.r.y, n2 * tk.r.z, n3 * tk.r.w);
+        }
+        const float4 pq = ring[((sigma - q) & 15) * 64];
+        float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o_run), 0x111, 0xF, 0xF, false)) + pq.x;
+        o += pq.y; o += pq.z; o += pq.w;
+        o_run = o;
+        const int te = sigma - 15;
+        if (q == 15 && te >= 0 && te < T) out[(int64_t) te * D + h * S + i] = o;
+    };
+
+    const int n_chunks = (T + CH - 1) / CH;
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const bool more = c + 1 < n_chunks;
+        if (more) issue(c + 1);
+        const int n = T - CH * c < CH ? T - CH * c : CH;
+        Tok ta, tb;
+        read_tok(c, 0, ta);
+        for (int tt = 0; tt < n; tt += 2) {
+            if (tt + 1 < CH) read_tok(c, tt + 1, tb);
+            step(CH * c + tt, true, ta);
+            if (tt + 1 < n) {
+                if (tt + 2 < CH) read_tok(c, tt + 2, ta);
+                step(CH * c + tt + 1, true, tb);
+            }
+        }
+        if (more) commit(c + 1);
+        __syncthreads();
+    }
+    {
+        Tok none{};
+        for (int sigma = T; sigma < T + 15; sigma++) step(sigma, false, none);   // drain the out chain
+    }
+    *reinterpret_cast<float4 *>(state_out + h * S * S + (int64_t) i * S + 4 * q) = make_float4(s0, s1, s2, s3);
+}
+
+bool launch_wkv7_seq(const float * r, const float * w, const float * k, const float * v, const float * a, const float * b,
+                     const float * state_in, float * state_out, float * out, int64_t T, int64_t H, hipStream_t st) {
+    prefill_prepare_current_device();
+    hipLaunchKernelGGL(k_wkv7_seq, dim3((unsigned) (H * 4)), dim3(256), W7_LDS, st, r, w, k, v, a, b, state_in, state_out, out, (int) T, (int) H);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -1036,6 +1187,7 @@ void prefill_prepare_current_device() {
     (void) hipFuncSetAttribute((const void *) k_wkv6_seq<0>, hipFuncAttributeMaxDynamicSharedMemorySize, wkv_lds);
     (void) hipFuncSetAttribute((const void *) k_wkv6_seq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wkv_lds);
     (void) hipFuncSetAttribute((const void *) k_wkv6_seq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wkv_lds);
+    (void) hipFuncSetAttribute((const void *) k_wkv7_seq, hipFuncAttributeMaxDynamicSharedMemorySize, W7_LDS);
     (void) hipGetLastError();
 }
 

@@ -63,6 +63,34 @@ def test_sequence_pass_matches_oracle_and_serial(tmp_path, name, fmt, T):
     om.free()
 
 
+@pytest.mark.parametrize("fmt", ["FP32", "Q5_1"])
+def test_wkv7_sequence_kernel_at_chunk_edges(tmp_path, fmt):
+    """k_wkv7_seq stages 32 tokens per chunk and drains its out chain 15 steps behind the last token: lengths around the chunk size,
+    one past it, a multiple, and a long ragged one. Logits only see the last token, so the whole state (every row's recurrence over
+    every token) is compared too, and a second pass continues from the first one's state."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS["test-v7"]
+    if fmt == "FP32":
+        synth.write_model(p, spec, "FP32", seed=43)
+    else:
+        src = str(tmp_path / "f.bin")
+        synth.write_model(src, spec, "FP32", seed=43)
+        O.quantize_file(src, p, fmt)
+    om = O.OracleModel(p)
+    m = model(p)
+    for T in (32, 33, 47, 64, 65, 250):
+        toks = [int((1103515245 * (i + T) + 12345) % spec.n_vocab) for i in range(T)]
+        ol, ost = om.eval_sequence(toks, om.init_state())
+        gl, gst = m.eval_sequence(toks, None)
+        assert np.array_equal(gl, ol) and np.array_equal(gst, ost), (fmt, T, float(np.abs(gst - ost).max()))
+        ol2, ost2 = om.eval_sequence(toks[:40], ost)
+        gl2, gst2 = m.eval_sequence(toks[:40], gst)
+        assert np.array_equal(gl2, ol2) and np.array_equal(gst2, ost2), (fmt, T, "continued")
+    m.free()
+    om.free()
+
+
 def test_sequence_pass_on_the_real_head_geometry(tmp_path):
     """RWKV-6 with D = 2048 (32 heads of 64, 64 leaves per row, ffn rows of 3.5 blocks per leaf): 3 layers, 200 tokens."""
     library()
