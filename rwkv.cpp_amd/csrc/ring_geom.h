@@ -15,8 +15,10 @@
 //
 // Layer block of workgroup b (phases in consumption order; record j of a phase goes to consumer wave (j + rot) % 6):
 //     W1    time_maa_w1 rows b, b + 256, ...              (R = 1, K = D)     -> tanh -> tl
-//     DW1   time_decay_w1 row b                           (R = 1, K = D)     -> tanh -> dl
 //     C     two-row sets of ONE of receptance/key/value/gate (R = 2, K = D)  -> r, k, v, g
+//     DW1   time_decay_w1 row b                           (R = 1, K = D)     -> tanh -> dl   (behind C, on a wave with the fewest sets:
+//           in front of them it held that wave -- and with it the ring position the loader may refill -- back by 1.2 us on half of the
+//           workgroups, exactly those that finished their r/k/v/g sets last)
 //     E     output rows                                   (R = 1, K = D)     -> x += ...
 //     FK    two-row sets of ffn.key                       (R = 2, K = D)     -> relu^2 -> k
 //     FR    ffn.receptance rows                           (R = 1, K = D)
@@ -37,7 +39,7 @@ constexpr int RG_NBLK = 256;   // workgroups = CUs of an MI355X
 constexpr int RG_NC = 6;       // consumer waves per workgroup
 constexpr int RG_CHUNK = 1024; // bytes of one LDS-DMA instruction
 
-enum { RG_W1 = 0, RG_DW1 = 1, RG_C = 2, RG_E = 3, RG_FK = 4, RG_FR = 5, RG_G = 6, RG_NPHASE = 7 };
+enum { RG_W1 = 0, RG_C = 1, RG_DW1 = 2, RG_E = 3, RG_FK = 4, RG_FR = 5, RG_G = 6, RG_NPHASE = 7 };   // (= the order in the stream)
 
 struct RingShape {
     int D, F, R5, DR;        // n_embed, ffn size, 5 x mix rank (rows of time_maa_w1), decay rank (rows of time_decay_w1)

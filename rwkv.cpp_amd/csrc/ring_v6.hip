@@ -315,15 +315,22 @@ struct R6 {
     // many bytes per layer as the weight stream itself, on a handful of memory channels, and the stream crawled during every gather.
     // Here every wave first watches ONE unit (a different one per wave and workgroup: 64 bytes per attempt) until its tag turns or until
     // another wave of the workgroup has seen its own turn (LDS word); only then the wide sweeps start.
-    static __device__ __forceinline__ void gather_hint(Poll & pl, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap) {
+    // idle(): called once per watch round (the consumers use the wait to take their first record of the coming phase out of the ring
+    // as soon as it has landed: rows_pre)
+    template <typename Idle>
+    static __device__ __forceinline__ void gather_hint(Poll & pl, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap, Idle && idle) {
         for (unsigned spin = 0;; spin++) {
             if (fl_ld(go) >= gen || pl.dead) break;
             asm volatile("" ::: "memory");
             const v4u v = tg_load(xr, unit);
             if (__builtin_amdgcn_readfirstlane((int) tg_ok(v, tag))) { fl_st(go, gen); break; }
+            idle();
             if (poll_backoff(pl, spin)) break;
             for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
         }
+    }
+    static __device__ __forceinline__ void gather_hint(Poll & pl, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap) {
+        gather_hint(pl, xr, unit, tag, go, gen, nap, [] {});
     }
     // every gathering wave, after staging its share: arrive, then wait for the others' shares (gen = gathers of this kind so far)
     static __device__ __forceinline__ void gather_meet(Poll & pl, unsigned * f, unsigned gen) {
@@ -520,6 +527,10 @@ struct R6 {
         unsigned stalls = 0, rounds = 0;
         unsigned long long sb = ((unsigned long long) s_hi << 32) | s_lo;
         unsigned * const fland = l.fl + FL_LANDED;
+        // (tracing) workgroups 0 and 131 sample their rounds behind the phase stamps: [2][512][4] after the n_blocks * 8 * 32 stamp slots
+        long long * const lsamp = (p.trace && (blockIdx.x == 0 || blockIdx.x == 131)) ? p.trace + (size_t) gridDim.x * 8 * 32 + (blockIdx.x == 0 ? 0 : 2048) : nullptr;
+        const unsigned samp_lo = (unsigned) p.trace_layer * cu.layer_bytes, samp_hi = samp_lo + cu.layer_bytes;
+        unsigned nsamp = 0;
         for (unsigned spin = 0; issued < total;) {
             const unsigned lim0 = min_done >= total * 1024u ? total : ((min_done + RB) >> 12) << 2;
             const unsigned lim = lim0 < total ? lim0 : total;
@@ -529,6 +540,14 @@ struct R6 {
             const v4u dh = *reinterpret_cast<const v4u *>(l.fl);   // {landed, sweeps begun, sweeps ended, -}
             const int w = thin ? w_thin : w_norm;
             rounds++;
+            if (lsamp && nsamp < 512u && issued * 1024u + 4096u > samp_lo && landed * 1024u < samp_hi) {   // (tracing: this workgroup's rounds around the traced layer)
+                if (lane == 0) {
+                    long long * o = lsamp + (size_t) nsamp * 4;
+                    o[0] = (long long) __builtin_amdgcn_s_memrealtime(); o[1] = (long long) issued * 1024 - samp_lo; o[2] = (long long) landed * 1024 - samp_lo;
+                    o[3] = (long long) min_done - samp_lo;
+                }
+                nsamp++;
+            }
             if (issued < lim) {
                 spin = 0;
                 unsigned n = (lim - issued) >> 2;
@@ -577,6 +596,8 @@ struct R6 {
         unsigned RB;
         unsigned landed;       // chunks known to have landed
         int c, lane;
+        int dbg;               // RWKV_MI_RING_DBG (bit 5: timing experiment, the records' arithmetic replaced by an xor of what was read)
+        long long waited;      // (tracing) cycles spent waiting for the loader
     };
     template <int T, int TE> struct Unroll {
         template <typename F> static __device__ __forceinline__ void run(F && f) { f(std::integral_constant<int, T>{}); Unroll<T + 1, TE>::run(f); }
@@ -590,8 +611,48 @@ struct R6 {
     // epi(integral_constant<t>, j, res) receives the row sums of the wave's t-th record (record j of the phase).
     // (The first version walked the records in a loop with the cursor in a struct: ~300 overhead instructions per record -- half of
     //  them scalar, forty branches -- around ~140 useful ones; a C phase took 13.7 k cycles for 3.6 k cycles of arithmetic.)
+    // A wave's FIRST record of a phase can leave the ring before the hand-over that the phase waits for: the ring is full by then
+    // (the loader ran ahead during the previous phase's tail), nothing is in flight, and every byte the consumers free only comes
+    // back a memory latency later. Taking the first record into registers in front of the gather gives the loader that room -- six
+    // records per workgroup -- while the workgroup exchanges. Never waits: a record that has not landed yet is read by rows() as before.
+    template <int R, int U> struct Pre { RawRec<FMT, R, U> w; bool have; };
+    // which phases do it (1: r/k/v/g, 2: output, 4: ffn key, 8: ffn value). D = 4096: the prologue parameters in flight across the
+    // same hand-overs leave registers for two of them (Q4_0) or one (kernel-resource-usage: any more spills); same-box A/B on the 7B
+    // file +2.2 % tokens/s. D = 2048: none -- a layer block (130 KB per workgroup) nearly fits the ring as it is, and the extra ring
+    // checks in the watch loops cost 2.5 %.
+    static constexpr int PRE_MASK = EPT > 4 ? (FMT == T_Q4_0 ? 9 : 8) : 0;
+    template <int PH, int R, int U, int TF>
+    static __device__ __forceinline__ void rows_pre(Cons & cs, const Lds & l, Pre<R, U> & pre) {
+        constexpr unsigned RECB = (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0));
+        constexpr unsigned STRIDE = NC * RECB;
+        pre.have = false;
+        if (cs.dbg & 64) return;                                   // (A/B switch)
+        const unsigned n = cs.cu.n[PH];
+        const unsigned j0 = rg_first_j(cs.cu, PH, cs.c);
+        if (j0 >= n) return;
+        const unsigned pos = __builtin_amdgcn_readfirstlane(cs.lbase + cs.cu.off[PH] + j0 * RECB);
+        const unsigned ro = __builtin_amdgcn_readfirstlane(pos - (pos / cs.RB) * cs.RB);
+        const unsigned need = (pos + RECB + 1023u) >> 10;
+        if (cs.landed < need) cs.landed = fl_ld(l.fl + FL_LANDED);
+        if (cs.landed < need) return;
+        const bool only = !(j0 + NC < n);
+        const unsigned nxt = rg_next_own_in_layer(cs.cu, cs.c, PH + 1);
+        const unsigned after = nxt != RG_NONE ? cs.lbase + nxt : cs.next_block;
+        asm volatile("" ::: "memory");
+        rec_load<FMT, R, U>(pre.w, l.ring, ro, opq(cs.lane));
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(l.fl + FL_DONE + 2 + cs.c, only ? after : pos + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pre.have = true;
+    }
+
     template <int PH, int R, int U, int TF, bool PIPE_, typename EpiF>
     static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, EpiF && epi) {
+        Pre<R, U> none;
+        none.have = false;
+        rows<PH, R, U, TF, PIPE_>(cs, pl, l, act, nbk, none, epi);
+    }
+    template <int PH, int R, int U, int TF, bool PIPE_, typename EpiF>
+    static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, Pre<R, U> & pre, EpiF && epi) {
         constexpr bool PIPE = PIPE_ && QF<FMT>::QS == 16;   // (Q8_0 records are twice the registers: one buffer)
         constexpr unsigned RECB = (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0));
         constexpr unsigned STRIDE = NC * RECB;
@@ -609,16 +670,19 @@ struct R6 {
         ActRegs<U> ar;
         act_load<U>(ar, act, nbk, ln);
         unsigned * const dn = l.fl + FL_DONE + 2 + cs.c;
-        RawRec<FMT, R, U> w[PIPE ? 2 : 1];
+        RawRec<FMT, R, U> w1;                                      // (second buffer; the first one is pre.w)
+        auto wbuf = [&](int i) -> RawRec<FMT, R, U> & { return (PIPE && (i & 1)) ? w1 : pre.w; };
         // ring reads + release of the record at (pos, ro); last = no further record of this wave in the phase
         auto load = [&](RawRec<FMT, R, U> & wr, bool last) {
             const unsigned need = (pos + RECB + 1023u) >> 10;
             if (cs.landed < need) {
+                const long long t0 = (long long) __builtin_readcyclecounter();
                 for (unsigned spin = 0;; spin++) {
                     cs.landed = fl_ld(l.fl + FL_LANDED);
                     if (cs.landed >= need || pl.dead) break;
                     if (lds_backoff(pl, spin)) break;
                 }
+                cs.waited += (long long) __builtin_readcyclecounter() - t0;
             }
             asm volatile("" ::: "memory");
             rec_load<FMT, R, U>(wr, l.ring, ro, ln);
@@ -635,37 +699,46 @@ struct R6 {
         for (int i = 0; i < (TF + 1) * R; i++) part[i] = 0.0f;
         auto finish = [&](auto tc, const RawRec<FMT, R, U> & wr) {
             constexpr int t = decltype(tc)::value;
+            if (cs.dbg & 32) {
+                unsigned x = 0;
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int r = 0; r < R; r++) { x ^= (unsigned) wr.raw[u][r].q[0].x ^ (unsigned) wr.raw[u][r].q[0].y ^ (unsigned) wr.raw[u][r].q[0].z ^ (unsigned) wr.raw[u][r].q[0].w ^ wr.raw[u][r].sc; }
+                part[t * R] = __uint_as_float(x & 0x3FFFFFu);
+            } else
             rec_acc<FMT, R, U>(wr, ar, nbk, ln, part + t * R);
             // (anchor: the arithmetic of record t stays in front of the ring reads of record t + 2 -- volatile statements keep their
             //  order; without it the compiler issues every record's reads first and all the arithmetic behind the last landed check)
 #pragma unroll
             for (int r = 0; r < R; r++) asm volatile("" :: "v"(part[t * R + r]));
         };
+        // (the wave's first record may already be in pre.w: rows_pre)
         if constexpr (PIPE) {
             if constexpr (TF > 0) {
-                load(w[0], TF == 1 && !tail);
+                if (!pre.have) load(pre.w, TF == 1 && !tail);
                 Unroll<0, TF>::run([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
-                    if constexpr (t + 1 < TF) { advance(); load(w[(t + 1) & 1], t + 2 == TF && !tail); }
-                    else if (tail) { advance(); load(w[(t + 1) & 1], true); }
-                    finish(tc, w[t & 1]);
+                    if constexpr (t + 1 < TF) { advance(); load(wbuf(t + 1), t + 2 == TF && !tail); }
+                    else if (tail) { advance(); load(wbuf(t + 1), true); }
+                    finish(tc, wbuf(t));
                 });
-                if (tail) finish(std::integral_constant<int, TF>{}, w[TF & 1]);
+                if (tail) finish(std::integral_constant<int, TF>{}, wbuf(TF));
             } else {
-                load(w[0], true);
-                finish(std::integral_constant<int, 0>{}, w[0]);
+                if (!pre.have) load(pre.w, true);
+                finish(std::integral_constant<int, 0>{}, pre.w);
             }
         } else {
             Unroll<0, TF>::run([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 if constexpr (t > 0) advance();
-                load(w[0], t + 1 == TF && !tail);
-                finish(tc, w[0]);
+                if (t > 0 || !pre.have) load(pre.w, t + 1 == TF && !tail);
+                finish(tc, pre.w);
             });
             if (tail) {
                 if constexpr (TF > 0) advance();
-                load(w[0], true);
-                finish(std::integral_constant<int, TF>{}, w[0]);
+                if (TF > 0 || !pre.have) load(pre.w, true);
+                finish(std::integral_constant<int, TF>{}, pre.w);
             }
         }
         wave_sum_n<(TF + 1) * R>(part);
@@ -698,7 +771,7 @@ struct R6 {
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         const RingShape sh = shape(p);
         Cons cs;
-        cs.cu = rg_cu(sh, blk); cs.lbase = 0; cs.landed = 0; cs.RB = __builtin_amdgcn_readfirstlane(p.ring_bytes); cs.c = c; cs.lane = lane;
+        cs.cu = rg_cu(sh, blk); cs.lbase = 0; cs.landed = 0; cs.RB = __builtin_amdgcn_readfirstlane(p.ring_bytes); cs.c = c; cs.lane = lane; cs.dbg = __builtin_amdgcn_readfirstlane(p.dbg); cs.waited = 0;
         const int mat = (blk * (4 * D / NBLK)) / D;   // which of r, k, v, g this workgroup's sets belong to
         const int cbase = (blk * (4 * D / NBLK)) % D;
         const bool has_dw1 = blk < p.DR;
@@ -723,6 +796,7 @@ struct R6 {
             cs.lbase = (unsigned) li * cs.cu.layer_bytes;
             cs.next_block = li + 1 < p.n_layers ? cs.lbase + cs.cu.layer_bytes + first_own : head_first;
             R6STAMP(0);
+            if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 23] = cs.waited;
             // (per-lane offsets are derived from an opaque copy of the lane index in every phase: left alone, the compiler hoists a
             //  hundred loop-invariant address registers of the gathers out of the layer loop and spills them)
             // ---- A: x, LN1 + mix + quantise, W1 rows ----
@@ -745,9 +819,13 @@ struct R6 {
             });
             R6STAMP(3);
             // ---- C: the mixed inputs (this workgroup's matrix reads ONE of the five), decay row, r/k/v/g sets ----
+            Pre<2, UD> pc;
+            pc.have = false;
+            auto try_c = [&]() { if constexpr ((PRE_MASK & 1) != 0) { if (!pc.have) rows_pre<RG_C, 2, UD, 0>(cs, l, pc); } };
+            try_c();
             {
                 const int img = (0x4213 >> (4 * mat)) & 0xF;   // r, k, v, g -> mix image (w, k, v, r, g order)
-                gather_hint(pl, xr, p.act5 + img * p.act_stride + ((blk * 7 + c * 19) & 127), tagL + SLOT_ACT, l.fl + FL_HACT, g1, p.nap);
+                gather_hint(pl, xr, p.act5 + img * p.act_stride + ((blk * 7 + c * 19) & 127), tagL + SLOT_ACT, l.fl + FL_HACT, g1, p.nap, try_c);
                 sweep_begin(l);
                 gather_qvec<DSL>(pl, xr, p.act5 + img * p.act_stride, D, tagL + SLOT_ACT, c, opq(lane), l.act);
                 if (has_dw1) gather_qvec<DSL>(pl, xr, p.act5, D, tagL + SLOT_ACT, c, opq(lane), l.actw);
@@ -755,9 +833,6 @@ struct R6 {
                 sweep_end(l);
             }
             R6STAMP(4);
-            rows<RG_DW1, 1, UD, 0, false>(cs, pl, l, qvec_at(l.actw, D), nb, [&](auto, int, const float (&res)[1]) {
-                if (lane == 0) tg_store(xr, p.dl + blk, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
-            });
             {
                 // all row sums first, then ONE epilogue: lane 2 t + r finishes row r of this wave's t-th set (the gate's silu is a double-
                 // precision exp: once per phase, not once per record) and lanes 0, 2, 4, ... store their set's unit with one instruction
@@ -767,7 +842,8 @@ struct R6 {
                 for (int t = 0; t < 2 * MAXT; t++) all[t] = 0.0f;
                 const int j0 = (int) rg_first_j(cs.cu, RG_C, c);
                 if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 20] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_C]);
-                rows<RG_C, 2, UD, NSET / NC, true>(cs, pl, l, qvec_at(l.act, D), nb, [&](auto tc, int, const float (&res)[2]) {
+                R6RSTAMP(26);
+                rows<RG_C, 2, UD, NSET / NC, true>(cs, pl, l, qvec_at(l.act, D), nb, pc, [&](auto tc, int, const float (&res)[2]) {
                     constexpr int t = decltype(tc)::value;
                     all[2 * t] = res[0]; all[2 * t + 1] = res[1];
                 });
@@ -779,24 +855,37 @@ struct R6 {
                 if (ln < 2 * MAXT && (ln & 1) == 0 && j < (int) cs.cu.n[RG_C])
                     tg_store(xr, p.rkvg + ((mat * D + cbase + 2 * j) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
             }
-            R6STAMP(5);
+            // the decay row (one wave of the first DR workgroups), behind the sets in the stream
+            rows<RG_DW1, 1, UD, 0, false>(cs, pl, l, qvec_at(l.actw, D), nb, [&](auto, int, const float (&res)[1]) {
+                if (lane == 0) tg_store(xr, p.dl + blk, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
+            });
+            R6STAMP(5); R6RSTAMP(27);
+            if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 24] = cs.waited;
             issue_pf(pf, ar, L, sin_l, opq(ppt));
             __builtin_amdgcn_sched_barrier(0);
             // ---- E: output projection + residual ----
-            gather_hint(pl, xr, p.yq + ((blk * 7 + c * 19) & 127), tagL + SLOT_YQ, l.fl + FL_HYQ, g1, p.nap);
+            Pre<1, UD> pe;
+            pe.have = false;
+            auto try_e = [&]() { if constexpr ((PRE_MASK & 2) != 0) { if (!pe.have) rows_pre<RG_E, 1, UD, 0>(cs, l, pe); } };
+            try_e();
+            gather_hint(pl, xr, p.yq + ((blk * 7 + c * 19) & 127), tagL + SLOT_YQ, l.fl + FL_HYQ, g1, p.nap, try_e);
             sweep_begin(l);
             gather_qvec<DSL>(pl, xr, p.yq, D, tagL + SLOT_YQ, c, opq(lane), l.yq);
             gather_meet(pl, l.fl + FL_GYQ, g1);
             sweep_end(l);
             R6STAMP(6);
-            rows<RG_E, 1, UD, RE / NC, true>(cs, pl, l, qvec_at(l.yq, D), nb, [&](auto tc, int, const float (&res)[1]) {
+            rows<RG_E, 1, UD, RE / NC, true>(cs, pl, l, qvec_at(l.yq, D), nb, pe, [&](auto tc, int, const float (&res)[1]) {
                 constexpr int t = decltype(tc)::value;
                 xown[t] = xown[t] + res[0];
             });
             if (lane == 0) tg_store(xr, p.xatt + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XATT);
             R6STAMP(7);
             // ---- F: x, LN2 + mixes + quantise, key sets (-> comm quantises them), receptance rows ----
-            gather_hint(pl, xr, p.xatt + ((blk * 37 + c * 211) & 1023), tagL + SLOT_XATT, l.fl + FL_HX, 2u * li + 2u, p.nap);
+            Pre<2, UD> pk;
+            pk.have = false;
+            auto try_k = [&]() { if constexpr ((PRE_MASK & 4) != 0) { if (!pk.have) rows_pre<RG_FK, 2, UD, 0>(cs, l, pk); } };
+            try_k();
+            gather_hint(pl, xr, p.xatt + ((blk * 37 + c * 211) & 1023), tagL + SLOT_XATT, l.fl + FL_HX, 2u * li + 2u, p.nap, try_k);
             sweep_begin(l);
             gather_x(pl, xr, p.xatt, tagL + SLOT_XATT, c, opq(lane), l.x);
             gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
@@ -804,9 +893,9 @@ struct R6 {
             R6STAMP(8);
             if (pro) prologue_F(pl, l, pf, sout_l, blk == 0, opq(pt), opq(lane), 2u * li + 2u);
             fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 2u));
-            R6STAMP(9);
+            R6STAMP(9); R6RSTAMP(28);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 21] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_FK]);
-            rows<RG_FK, 2, UD, (UF * 64 > NBLK ? 32 : 16) / NC, true>(cs, pl, l, qvec_at(l.q1, D), nb, [&](auto, int j, const float (&res)[2]) {
+            rows<RG_FK, 2, UD, (UF * 64 > NBLK ? 32 : 16) / NC, true>(cs, pl, l, qvec_at(l.q1, D), nb, pk, [&](auto, int j, const float (&res)[2]) {
                 const float v = lane == 1 ? res[1] : res[0];
                 const float t = v > 0.0f ? v : 0.0f;
                 if (lane < 2) l.out[2 * j + lane] = t * t;
@@ -817,16 +906,21 @@ struct R6 {
                 constexpr int t = decltype(tc)::value;
                 rrow[t] = res[0];
             });
-            R6STAMP(11);
+            R6STAMP(11); R6RSTAMP(29);
             // ---- G: value projection, x += sigmoid(r) * (Wv k) ----
-            gather_hint(pl, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap);
+            Pre<1, UF> pg;
+            pg.have = false;
+            // (registers: not the long Q8_0 rows of the 7B geometry)
+            auto try_g = [&]() { if constexpr ((PRE_MASK & 8) != 0 && sizeof(RawRec<FMT, 1, UF>) <= 48 * 4) { if (!pg.have) rows_pre<RG_G, 1, UF, 0>(cs, l, pg); } };
+            try_g();
+            gather_hint(pl, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap, try_g);
             sweep_begin(l);
             gather_qvec<KSL>(pl, xr, p.kq, F, tagL + SLOT_KQ, c, opq(lane), l.kq);
             gather_meet(pl, l.fl + FL_GKQ, g1);
             sweep_end(l);
-            R6STAMP(12);
+            R6STAMP(12); R6RSTAMP(30);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 22] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_G]);
-            rows<RG_G, 1, UF, RE / NC, false>(cs, pl, l, qvec_at(l.kq, F), nbF, [&](auto tc, int j, const float (&res)[1]) {
+            rows<RG_G, 1, UF, RE / NC, false>(cs, pl, l, qvec_at(l.kq, F), nbF, pg, [&](auto tc, int j, const float (&res)[1]) {
                 constexpr int t = decltype(tc)::value;
                 const float gte = sigmoid_f(rrow[t]) * res[0];
                 xown[t] = xown[t] + gte;
@@ -834,6 +928,7 @@ struct R6 {
             });
             if (lane == 0) tg_store(xr, p.xffn + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
             R6STAMP(13); R6RSTAMP(14);
+            if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 25] = cs.waited;
             if (li + 1 < p.n_layers) {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
                 issue_pa(pa, ar, p.layers[li + 1], p.sin + (long long) (li + 1) * p.state_stride, opq(ppt));
             }
@@ -1242,6 +1337,7 @@ __global__ __launch_bounds__(512) void k6_ring(R6P p) {
         else fl_st(l.fl + FL_DONE + wave, 0xFFFFFFFFu);
         return;
     }
+    if (p.trace && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 31] = (long long) __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11));   // HW_ID[15:0]: wave, SIMD, pipe, CU, SH, SE
     if (wave == 0) { if (R6_ROLES & 1) K::loader_main(p, l, lane); }
     else if (wave == 1) { if (R6_ROLES & 2) K::comm_main(p, l, lane, base); }
     else { if (R6_ROLES & 4) K::consumer_main(p, l, lane, wave, base); }
@@ -1531,10 +1627,18 @@ void * ring_v6_create(const Model & m) {
 
 bool ring_v6_trace(void * h, int layer, long long * out, bool fetch) {
     RingV6 * rg = (RingV6 *) h;
-    const size_t n = (size_t) rg->n_blocks * 8 * 32;
-    if (!rg->trace) { if (hipMalloc((void **) &rg->trace, n * 8) != hipSuccess) return false; (void) hipMemset(rg->trace, 0, n * 8); }
+    const size_t n = (size_t) rg->n_blocks * 8 * 32, extra = 2 * 512 * 4;   // (+ the loader's round samples of two workgroups)
+    if (!rg->trace) { if (hipMalloc((void **) &rg->trace, (n + extra) * 8) != hipSuccess) return false; (void) hipMemset(rg->trace, 0, (n + extra) * 8); }
     rg->proto.trace = rg->trace; rg->proto.trace_layer = layer;
-    if (fetch) return hipMemcpy(out, rg->trace, n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    if (fetch) {
+        if (const char * path = getenv("RWKV_MI_RING_LTRACE")) {   // measurement aid: the loader samples as raw int64 [2][512][4]
+            std::vector<long long> buf(extra);
+            if (hipMemcpy(buf.data(), rg->trace + n, extra * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                if (FILE * f = fopen(path, "wb")) { fwrite(buf.data(), 8, extra, f); fclose(f); }
+            }
+        }
+        return hipMemcpy(out, rg->trace, n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    }
     return true;
 }
 

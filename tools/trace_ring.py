@@ -55,4 +55,35 @@ end = R[:, 2:, 14].max(); start = rt(1, 17).min()
 print('layer wall: (x_ffn stored, max over consumers) - (x staged, min over comm): %.2f us' % ((end - start) / 100))
 by = (R[:, 2:, 14].max(axis=1) - R[:, 2:, 14].min()) / 100
 print('x_ffn stored lateness by XCD:', ' '.join('%.2f' % by[x::8].mean() for x in range(8)), ' by consumer:', ' '.join('%.2f' % ((R[:, 2 + c, 14] - R[:, 2:, 14].min()) / 100).mean() for c in range(6)))
+lt = os.environ.get('RWKV_MI_RING_LTRACE')
+if lt and os.path.exists(lt):
+    smp = np.fromfile(lt, dtype=np.int64).reshape(2, 512, 4)
+    for wi, b in ((0, 0), (1, 131)):
+        sm = smp[wi]; sm = sm[sm[:, 0] > 0]
+        if not len(sm): continue
+        t0 = sm[0, 0]
+        ph = out.reshape(NB, 8, 32)[b]
+        print('LOADER rounds of workgroup %d around layer %d (us since the first sample; KiB relative to the layer block): %d samples' % (b, layer, len(sm)))
+        marks = {'C.rows start': ph[2:, 26], 'C.rows end': ph[2:, 27], 'keys start': ph[2:, 28], 'rec end': ph[2:, 29], 'G start': ph[2:, 30], 'G end': ph[2:, 14]}
+        for k, v in marks.items(): print('   consumers %-13s %s' % (k, ' '.join('%.2f' % ((x - t0) / 100) for x in v)))
+        cu_off = None
+        step = max(1, len(sm) // 70)
+        for r in sm[::step]: print('   t %6.2f  issued %7.1f  landed %7.1f  min_done %7.1f' % ((r[0] - t0) / 100, r[1] / 1024, r[2] / 1024, r[3] / 1024))
+wt = t[:, 2:, 23:26]
+print('waiting for the loader inside the layer (cycles, mean over consumer waves): W1 + C rows %.0f   E + keys + rec + G rows %.0f   by consumer (whole layer): %s' % (
+    (wt[:, :, 1] - wt[:, :, 0]).mean(), (wt[:, :, 2] - wt[:, :, 1]).mean(), ' '.join('%.0f' % (wt[:, c, 2] - wt[:, c, 0]).mean() for c in range(6))))
+raw = out.reshape(NB, 8, 32).astype(float)
+for nm, st_, en_ in (('C.rows', 26, 27), ('keys+rec', 28, 29), ('G.rows', 30, 14)):
+    st = raw[:, 2:, st_]; en = raw[:, 2:, en_]
+    dur = (en.max(axis=1) - st.min(axis=1)) / 100          # per workgroup: first consumer in -> last consumer out
+    late = (en.max(axis=1) - en.max(axis=1).min()) / 100
+    order = np.argsort(-late)[:12]
+    print('%s per workgroup (us): duration mean %.2f min %.2f max %.2f; start spread %.2f; end spread %.2f' % (nm, dur.mean(), dur.min(), dur.max(), (st.min(axis=1).max() - st.min(axis=1).min()) / 100, late.max()))
+    print('   by XCD (wg %% 8): ' + ' '.join('%.2f' % dur[x::8].mean() for x in range(8)) + '   by quarter: ' + ' '.join('%.2f' % dur[q * 64:(q + 1) * 64].mean() for q in range(4)))
+    print('   latest workgroups (wg: lateness, duration): ' + ' '.join('%d: %.2f %.2f |' % (b, late[b], dur[b]) for b in order))
+hw = out.reshape(NB, 8, 32)[:, :, 31]
+simd = (hw >> 4) & 3
+print('SIMD of waves 0..7 (workgroups 0..3):', ' | '.join(' '.join(str(int(v)) for v in simd[b]) for b in range(4)))
+import collections
+print('wave -> SIMD patterns over all workgroups:', collections.Counter(tuple(int(v) for v in simd[b]) for b in range(NB)).most_common(4))
 sys.stdout.flush(); os._exit(0)
