@@ -118,6 +118,7 @@ static void calibrate_decode_path(rwkv_context * ctx) {
     const bool keep = ok && !bad[best] && !(t_fused < 0.97f * t[best]);
     for (int i = 0; i < 2; i++) if (cand[i] && !(keep && i == best)) mega_v6_destroy(cand[i]);
     ctx->mega = keep ? cand[best] : nullptr;
+    if (ok) m.decode_choice.store(keep ? mega_v6_kind(cand[best]) : 3);
     if (!keep) { mega_chain_forget(ctx); mega_chain_count(ctx, -1); }
 }
 
@@ -169,10 +170,11 @@ rwkv_context * create_context(Model * m, uint32_t n_threads) {
         if ((e = hipMalloc(&ctx->fused_scratch, fused_v6_scratch_bytes(*m))) != hipSuccess) return fail(e);
         ctx->fused_v6 = true;
         const char * nm = getenv("RWKV_MI_NO_MEGA");
-        if (!(nm && nm[0] == '1')) ctx->mega = mega_v6_create(*m);
+        const int known = m->decode_choice.load();      // (what an earlier context of this model measured)
+        if (!(nm && nm[0] == '1') && known != 3) ctx->mega = known ? mega_v6_create_kind(*m, known) : mega_v6_create(*m);
         // a second persistent context on this device: launches the first one made while it was alone carry no completion event
         if (ctx->mega && mega_chain_count(ctx.get(), +1) > 1) (void) hipDeviceSynchronize();
-        calibrate_decode_path(ctx.get());
+        if (!known) calibrate_decode_path(ctx.get());
     }
     if (!(nf && nf[0] == '1') && fused_v7_supported(*m)) {
         if ((e = hipMalloc(&ctx->fused_scratch, fused_v7_scratch_bytes(*m))) != hipSuccess) return fail(e);

@@ -35,6 +35,10 @@ struct Model {
     int arch_major = 4, arch_minor = 0;
     int64_t head_count = 0, head_size = 0, ffn_size = 0;
     int64_t max_lowrank = 0;  // widest intermediate of a low-rank pair (v6 5*r, decay rank; v7 ranks)
+    // Single-token path the first context of this model measured as fastest on its device (engine.hip, calibrate_decode_path):
+    // 0 not measured, 1 persistent kernel on register prefetch, 2 persistent kernel on the LDS-DMA ring, 3 seven launches per layer.
+    // Clones reuse it instead of timing every path again.
+    mutable std::atomic<int> decode_choice{0};
 
     std::vector<std::unique_ptr<DevTensor>> tensors;
     std::unordered_map<std::string, DevTensor *> by_name;
