@@ -102,6 +102,76 @@ __device__ __forceinline__ float lr_row16(LrBatch<F16> & first, const void * __r
     return (ps[0] + ps[1]) + (ps[2] + ps[3]);
 }
 
+// The same dot with EIGHT lanes per row (lane = 8 * row + q; lane q keeps partials 4q .. 4q+3 of ggml's 32) for the long rows of the
+// first low-rank stages (K = n_embed): a partial is a chain of K / 32 single FMAs in increasing k, so a row cannot be split along k,
+// but its 32 chains can be spread over more lanes. At 8 bytes per lane and step (F16) two batches of 24 steps (48 of the 80 steps of a 2560-long row)
+// are in flight before the prologue within the registers the quantised row groups of the same launch use anyway, where four lanes per
+// row (16 bytes per step, 2 x 16 steps) paid three more memory round trips
+// behind it; and a wave carries 8 rows instead of 16, so the rows spread over twice the waves.
+template <bool F16> struct Lr8Batch { static constexpr int UB = F16 ? 24 : 12; typename std::conditional<F16, int2, int4>::type r[UB]; };
+
+template <bool F16>
+__device__ __forceinline__ void lr8_issue(Lr8Batch<F16> & bt, const void * __restrict__ W, int64_t row, int K, int s0, int q) {
+    const int nsteps = K / 32;
+#pragma unroll
+    for (int u = 0; u < Lr8Batch<F16>::UB; u++) {
+        const int sidx = s0 + u < nsteps ? s0 + u : nsteps - 1;
+        const int64_t e0 = row * K + 32 * sidx + 4 * q;
+        if constexpr (F16) bt.r[u] = *reinterpret_cast<const int2 *>(reinterpret_cast<const uint16_t *>(W) + e0);
+        else bt.r[u] = ldw16(reinterpret_cast<const float *>(W) + e0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool F16>
+__device__ __forceinline__ void lr8_consume(const Lr8Batch<F16> & bt, int K, int s0, int q, const float * l_x, float (&acc)[4]) {
+    const int nsteps = K / 32;
+#pragma unroll
+    for (int u = 0; u < Lr8Batch<F16>::UB; u++) {
+        if (s0 + u < nsteps) {
+            const int sidx = s0 + u;
+            float w[4];
+            if constexpr (F16) {
+                const unsigned u0 = (unsigned) bt.r[u].x, u1 = (unsigned) bt.r[u].y;
+                w[0] = h2f_bits((uint16_t) (u0 & 0xFFFFu)); w[1] = h2f_bits((uint16_t) (u0 >> 16));
+                w[2] = h2f_bits((uint16_t) (u1 & 0xFFFFu)); w[3] = h2f_bits((uint16_t) (u1 >> 16));
+            } else {
+                w[0] = __int_as_float(bt.r[u].x); w[1] = __int_as_float(bt.r[u].y); w[2] = __int_as_float(bt.r[u].z); w[3] = __int_as_float(bt.r[u].w);
+            }
+            const float4 xa = *reinterpret_cast<const float4 *>(l_x + 32 * sidx + 4 * q);
+            acc[0] = fmaf(w[0], xa.x, acc[0]); acc[1] = fmaf(w[1], xa.y, acc[1]); acc[2] = fmaf(w[2], xa.z, acc[2]); acc[3] = fmaf(w[3], xa.w, acc[3]);
+        }
+    }
+}
+
+// `first` and `second` hold steps [0, UB) and [UB, 2 UB), already in flight (issued before the caller's prologue)
+template <bool F16>
+__device__ __forceinline__ float lr8_row(Lr8Batch<F16> & first, Lr8Batch<F16> & second, const void * __restrict__ W, int64_t row, int K, const float * l_x, int lane) {
+    constexpr int UB = Lr8Batch<F16>::UB;
+    const int q = lane & 7;
+    const int nsteps = K / 32;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s0 = 0;; s0 += 2 * UB) {
+        lr8_consume<F16>(first, K, s0, q, l_x, acc);
+        if (s0 + UB >= nsteps) break;
+        if (s0 + 2 * UB < nsteps) lr8_issue<F16>(first, W, row, K, s0 + 2 * UB, q);
+        lr8_consume<F16>(second, K, s0 + UB, q, l_x, acc);
+        if (s0 + 2 * UB >= nsteps) break;
+        if (s0 + 3 * UB < nsteps) lr8_issue<F16>(second, W, row, K, s0 + 3 * UB, q);
+    }
+    // ggml's fold of the 32 partials: ps[i] += ps[i + 16], ps[i] += ps[i + 8], ps[i] += ps[i + 4], (ps0 + ps1) + (ps2 + ps3)
+    float ps[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float v = acc[e];
+        v += __shfl_xor(v, 4, WAVE);
+        v += __shfl_xor(v, 2, WAVE);
+        v += __shfl_xor(v, 1, WAVE);
+        ps[e] = v;
+    }
+    return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // A: LN1 + shift + one mix -> R / K / V rows or first low-rank stage rows
 // ---------------------------------------------------------------------------------------------------------------
@@ -132,14 +202,14 @@ __global__ __launch_bounds__(256) void k7_att_in(P7A p) {
     double * red = reinterpret_cast<double *>(l_qv + ((qvec_bytes(D) + 15) / 16) * 16);
     const QVec lq = qvec_at(l_qv, D);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // job of this workgroup: quantised groups of 32 rows (r, k, v), then low-rank groups of 64 rows
+    // job of this workgroup: quantised groups of 32 rows (r, k, v), then low-rank groups of 32 rows (8 per wave)
     const int64_t G = D / 32;
     int mat = -1, lrm = -1;
     int64_t grp = blockIdx.x;
     if (grp >= p.lr_groups) { grp -= p.lr_groups; mat = (int) (grp / G); grp -= (int64_t) mat * G; if (mat > 2) return; }
     else {
         for (int m = 0; m < 4; m++) {
-            const int64_t g = p.lr[m] ? (p.rank[m] + 63) / 64 : 0;
+            const int64_t g = p.lr[m] ? (p.rank[m] + 31) / 32 : 0;
             if (grp < g) { lrm = m; break; }
             grp -= g;
         }
@@ -150,11 +220,14 @@ __global__ __launch_bounds__(256) void k7_att_in(P7A p) {
     // weights of the quantised job go in flight before the prologue
     const int64_t row0 = grp * 32 + wave * 8;
     Batch<FMT, 8, 2> bt;
-    LrBatch<LRF16> lb0;
-    const int64_t lr_row = grp * 64 + wave * 16 + (lane >> 2);
+    Lr8Batch<LRF16> lb0, lb1;
+    const int64_t lr_row = grp * 32 + wave * 8 + (lane >> 3);
     const int64_t lr_rowc = lrm >= 0 ? (lr_row < p.rank[lrm] ? lr_row : p.rank[lrm] - 1) : 0;
     if (mat >= 0) batch_issue<FMT, 8, 2>(bt, p.wq[mat].qs, p.wq[mat].qh, p.wq[mat].sc, row0, D, nb, 0, lane);
-    else lr_issue<LRF16>(lb0, p.lr[lrm], lr_rowc, (int) D, 0, lane & 3);
+    else {
+        lr8_issue<LRF16>(lb0, p.lr[lrm], lr_rowc, (int) D, 0, lane & 7);
+        lr8_issue<LRF16>(lb1, p.lr[lrm], lr_rowc, (int) D, Lr8Batch<LRF16>::UB, lane & 7);
+    }
 
     fill_row(l_row, p.x, D);
     __syncthreads();
@@ -207,10 +280,10 @@ __global__ __launch_bounds__(256) void k7_att_in(P7A p) {
             for (int r = 0; r < 8; r++) if (row0 + r < D) p.out_q[mat][row0 + r] = p.epi_q[mat] == 1 ? sigmoid_f(res[r]) : res[r];
         }
     } else {
-        float v = lr_row16<LRF16>(lb0, p.lr[lrm], lr_rowc, (int) D, l_row, lane);
+        float v = lr8_row<LRF16>(lb0, lb1, p.lr[lrm], lr_rowc, (int) D, l_row, lane);
         if (lrm == 0) v = det_tanhf(v);
         else if (lrm == 2) v = sigmoid_f(v);
-        if ((lane & 3) == 0 && lr_row < p.rank[lrm]) p.out_lr[lrm][lr_row] = v;
+        if ((lane & 7) == 0 && lr_row < p.rank[lrm]) p.out_lr[lrm][lr_row] = v;
     }
 }
 
@@ -408,7 +481,7 @@ static void fused_v7_layer_t(const Model & m, const LayerW & L, int layer, float
     uint64_t lr_bytes = 0;
     for (int i = 0; i < 4; i++) {
         a.lr[i] = l1[i] ? l1[i]->data : nullptr; a.rank[i] = l1[i] ? (int) l1[i]->ne[1] : 0; a.out_lr[i] = lr[i];
-        lr_groups += l1[i] ? (a.rank[i] + 63) / 64 : 0;
+        lr_groups += l1[i] ? (a.rank[i] + 31) / 32 : 0;
         lr_bytes += l1[i] ? l1[i]->nbytes : 0;
     }
     a.out_q[0] = r; a.out_q[1] = k; a.out_q[2] = v; a.D = D;
