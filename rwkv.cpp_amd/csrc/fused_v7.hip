@@ -320,6 +320,19 @@ __global__ __launch_bounds__(512) void k7_head(P7B p) {
         lr_issue<LRF16>(lbA, p.lr2[mtx], h * S + (2 * half) * 16 + (lane >> 2), p.rank[mtx], 0, lane & 3);
         lr_issue<LRF16>(lbB, p.lr2[mtx], h * S + (2 * half + 1) * 16 + (lane >> 2), p.rank[mtx], 0, lane & 3);
     }
+    // per-channel operands of the second stages' epilogues and of wave 0's recurrence: in flight now, not behind the phase that uses them
+    // (each of those loads was a memory round trip of its own on the head's critical path)
+    float e0[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) {
+        const int64_t ci = h * S + (2 * half + ps) * 16 + (lane >> 2);
+        e0[ps] = mtx == 0 ? p.w0[ci] : (mtx == 1 ? p.a0[ci] : ((mtx == 3 && p.lr2[3]) ? p.v0[ci] : 0.0f));
+    }
+    float rv = 0.0f, kv0 = 0.0f, vv = 0.0f, c_kk = 0.0f, c_ka = 0.0f, c_rk = 0.0f, c_lw = 0.0f, c_lb = 0.0f, vf = 0.0f;
+    if (wave == 0) {
+        rv = p.r[c]; kv0 = p.k[c]; vv = p.v[c]; c_kk = p.k_k[c]; c_ka = p.k_a[c]; c_rk = p.r_k[c]; c_lw = p.lnx_w[c]; c_lb = p.lnx_b[c];
+        if (!p.layer0) vf = p.v_first[c];
+    }
     // the state row of this lane's value index goes in flight early (wave 0 only)
     float s[S];
     if (wave == 0) {
@@ -342,9 +355,9 @@ __global__ __launch_bounds__(512) void k7_head(P7B p) {
             for (int ps = 0; ps < 2; ps++) {
                 const int i = (2 * half + ps) * 16 + (lane >> 2);
                 float v = lr_row16<LRF16, false>(ps == 0 ? lbA : lbB, p.lr2[mtx], h * S + i, p.rank[mtx], l_lr[mtx], lane);
-                if (mtx == 0) v = det_expf(sigmoid_f(v + p.w0[h * S + i]) * -0.606531f);
-                else if (mtx == 1) v = sigmoid_f(v + p.a0[h * S + i]);
-                else if (mtx == 3) v = sigmoid_f(v + p.v0[h * S + i]);
+                if (mtx == 0) v = det_expf(sigmoid_f(v + e0[ps]) * -0.606531f);
+                else if (mtx == 1) v = sigmoid_f(v + e0[ps]);
+                else if (mtx == 3) v = sigmoid_f(v + e0[ps]);
                 if ((lane & 3) == 0) l_ch[mtx][i] = v;
             }
         }
@@ -352,17 +365,16 @@ __global__ __launch_bounds__(512) void k7_head(P7B p) {
     __syncthreads();
     if (wave != 0) return;
     // ---- key path, value residual (lane = channel) ----
-    const float rv = p.r[c], kv0 = p.k[c], av = l_ch[1][lane], wv = l_ch[0][lane], gv = l_ch[2][lane];
-    const float kkr = kv0 * p.k_k[c];
+    const float av = l_ch[1][lane], wv = l_ch[0][lane], gv = l_ch[2][lane];
+    const float kkr = kv0 * c_kk;
     const float ssum = wave_sum_f(kkr * kkr);
     const float kscale = 1.0f / fmaxf(sqrtf(ssum), 1e-12f);
     const float kk = kkr * kscale;
-    const float ka = kv0 * p.k_a[c];
+    const float ka = kv0 * c_ka;
     const float aka = av * ka;
     const float kn = kv0 + (aka - ka);
-    float vv = p.v[c];
     if (p.layer0) p.v_first[c] = vv;
-    else { const float dv = (p.v_first[c] - vv) * l_ch[3][lane]; vv = vv + dv; }
+    else { const float dv = (vf - vv) * l_ch[3][lane]; vv = vv + dv; }
     l_r[lane] = rv; l_w[lane] = wv; l_k[lane] = kn; l_a[lane] = -kk; l_b[lane] = kk * av;
     __builtin_amdgcn_wave_barrier();
     // ---- WKV7 (rwkv_operators_wkv_v7.inc:37-107): lane i = value row i of state[h][i][:] ----
@@ -385,10 +397,10 @@ __global__ __launch_bounds__(512) void k7_head(P7B p) {
     const float dv2 = res - mean;
     const float var = (float) (wave_sum_d((double) (dv2 * dv2)) / (double) S);
     const float scale = 1.0f / sqrtf(var + 64e-5f);
-    const float bonus = wave_sum_f((kn * rv) * p.r_k[c]);
+    const float bonus = wave_sum_f((kn * rv) * c_rk);
     float y = dv2 * scale;
-    y = y * p.lnx_w[c];
-    y = y + p.lnx_b[c];
+    y = y * c_lw;
+    y = y + c_lb;
     y += vv * bonus;
     y *= gv;
     int qi, isum; float d16, s16;
