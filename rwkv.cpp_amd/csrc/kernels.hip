@@ -309,6 +309,7 @@ struct EmbView {
     const uint8_t * qs;
     const uint32_t * qh;
     const void * sc;
+    int64_t rows;      // n_vocab: a token id that comes from device memory (on-device argmax / sampling, a pipeline's feedback) is clamped to it
 };
 
 __device__ __forceinline__ float emb_elem(const EmbView & e, int64_t row, int64_t D, int64_t k) {
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(256) void k_embed_ln0(EmbView emb, const uint32_t *
     extern __shared__ __attribute__((aligned(16))) float l_row[];
     __shared__ double red[257];
     const int64_t t = blockIdx.x;
-    const int64_t row = tokens[t];
+    const int64_t tok = tokens[t];
+    const int64_t row = tok < emb.rows ? tok : 0;     // (host-side token ids are range-checked by the API; this guards device-side ones)
     int64_t i = threadIdx.x;
     if (emb.type == T_F16 || emb.type == T_F32) {
         for (; i + 3 * 256 < D; i += 4 * 256) {   // 4 loads in flight per trip
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x,
 }
 
 void launch_embed_ln0(const DevTensor & emb, const uint32_t * tokens, int64_t T, int64_t D, const float * w, const float * b, float * x, hipStream_t st) {
-    EmbView e{emb.type, emb.data, emb.qs, emb.qh, emb.sc};
+    EmbView e{emb.type, emb.data, emb.qs, emb.qh, emb.sc, emb.rows()};
     hipLaunchKernelGGL(k_embed_ln0, dim3((unsigned) T), dim3(256), (size_t) D * sizeof(float), st, e, tokens, D, w, b, x);
 }
 
@@ -796,7 +798,9 @@ __global__ __launch_bounds__(1024) void k_argmax(const float * __restrict__ logi
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); w++)
             if (l_v[w] > best || (l_v[w] == best && l_i[w] < bi)) { best = l_v[w]; bi = l_i[w]; }
-        *out = (uint32_t) bi;
+        // (no element compared greater than -inf: every logit is NaN or -inf, e.g. after a poll time-out of the persistent kernel on a
+        //  shared GPU. The token feeds the next embedding lookup on the device: it must stay a row of the table.)
+        *out = bi == 0x7fffffff ? 0u : (uint32_t) bi;
     }
 }
 void launch_argmax(const float * logits, int64_t n, uint32_t * out, hipStream_t st) {

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(1024) void k_sample(const float * __restrict__ logi
         pick = l_pick;
         if (tid == 0 && counter) *counter = ctr + 1;
     }
+    if (pick < 0 || pick >= n) pick = 0;   // (all-NaN probabilities: the token must stay a row of the embedding table)
     if (tid == 0) { *out_token = (uint32_t) pick; if (hist) hist[hist_pos] = (uint32_t) pick; }
 }
 

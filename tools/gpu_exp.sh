@@ -1,10 +1,5 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"
-timeout 400 python -m pytest tests/test_gpu_fused.py tests/test_gpu_synthetic.py -q -x -m gpu -p no:cacheprovider 2>&1 | tail -3
-for rep in 1 2; do
-for lib in lib_base lib; do
-  for cfg in "rwkv7-2b9 Q5_1" "rwkv4-169m Q5_1"; do set -- $cfg
-  RWKV_LIB_DIR=$lib timeout 300 python bench.py --config $1 --dtype $2 --steps 128 --warmup 16 --cpu-seconds 0 --parity-tokens 0 --abi-tokens 0 2>/dev/null | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print('$1 $lib', round(d['value'],1), 'tok/s')"
-  done
-done; done
+cd "$GRAFT_REPO_ROOT"; export RWKV_BENCH_DIR=/tmp
+run() { echo "== $*"; env "$@" RWKV_BENCH_BACKEND=gloo timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --config rwkv6-1b6 --steps 16 --warmup 4 2>&1 | grep -E "Memory access|^\{|Traceback|Error" | cut -c1-130 | head -3; }
+run A=1; run A=2; run RWKV_MI_PERSIST=ring RWKV_MI_RING_NO_HEAD=1; run A=3; run RWKV_MI_PERSIST=ring RWKV_MI_RING_NO_HEAD=1
+timeout 300 python -m pytest tests/test_gpu_sampling.py tests/test_gpu_api_semantics.py -q -x -m gpu -p no:cacheprovider 2>&1 | tail -2
