@@ -90,7 +90,8 @@ static void calibrate_decode_path(rwkv_context * ctx) {
     void * cand[2] = {ctx->mega, nullptr};
     const char * pk = getenv("RWKV_MI_PERSIST");
     if (!(pk && pk[0]) && mega_v6_kind(cand[0]) == 2) cand[1] = mega_v6_create_kind(m, 1);
-    auto run = [&](void * h, int n) { ctx->mega = h; for (int i = 0; i < n && ok; i++) ok = forward(ctx, 1, false); };
+    // (with logits: the ring kernel runs ln_out + head inside its launch, the other paths as launches of their own -- part of what is compared)
+    auto run = [&](void * h, int n) { ctx->mega = h; for (int i = 0; i < n && ok; i++) ok = forward(ctx, 1, m.has_head); };
     auto timed = [&](void * h) -> float {
         run(h, 2);
         ok = ok && hipEventRecord(ctx->ev0, ctx->stream) == hipSuccess;
