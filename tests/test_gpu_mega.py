@@ -242,3 +242,27 @@ def test_new_context_starts_from_the_fresh_state(tmp_path):
     assert list(toks_c) == list(toks_r) == list(toks_m)
     c.free()
     m.free()
+
+
+@pytest.mark.parametrize("name", ["mega-v6-2048-v8k", "test-v6"])
+def test_device_side_tokens_stay_inside_the_vocabulary(tmp_path, name, persist):
+    """The greedy loop feeds the device's own argmax into the next embedding lookup. With a state of NaNs every logit is NaN and no
+    element compares greater than anything: the chosen token must still be a row of the embedding table (0, like numpy's argmax of
+    all-NaN), not the reduction's initial index -- that read far outside the table and ended the process with a GPU memory fault
+    (seen when two processes shared the GPU and a persistent kernel timed out). The context stays usable afterwards."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS[name]
+    synth.write_model(p, spec, "Q4_0", seed=47)
+    m = model(p)
+    m.state_load(np.full(m.state_len, np.nan, dtype=np.float32))
+    toks, _ = m.decode_greedy(3, 12)
+    assert all(int(t) < spec.n_vocab for t in toks)
+    assert int(m.sample(temperature=1.0, top_p=0.5, u=0.3)) < spec.n_vocab
+    m.state_load(None)
+    om = O.OracleModel(p)
+    ol, _ = om.eval(5, om.init_state())
+    lg, _ = m.eval(5, None)
+    assert np.array_equal(lg, ol)
+    m.free()
+    om.free()

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export RWKV_BENCH_DIR=/tmp
-run() { echo "== $*"; env "$@" RWKV_BENCH_BACKEND=gloo timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --config rwkv6-1b6 --steps 16 --warmup 4 2>&1 | grep -E "Memory access|^\{|Traceback|Error" | cut -c1-130 | head -3; }
-run A=1; run A=2; run RWKV_MI_PERSIST=ring RWKV_MI_RING_NO_HEAD=1; run A=3; run RWKV_MI_PERSIST=ring RWKV_MI_RING_NO_HEAD=1
-timeout 300 python -m pytest tests/test_gpu_sampling.py tests/test_gpu_api_semantics.py -q -x -m gpu -p no:cacheprovider 2>&1 | tail -2
+timeout 300 python -m pytest tests/test_gpu_mega.py -q -x -m gpu -p no:cacheprovider -k "device_side or new_context or concurrent" 2>&1 | tail -3
+for i in 1 2 3; do timeout 300 python bench.py --steps 128 --warmup 16 --cpu-seconds 0 --parity-tokens 0 --abi-tokens 0 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('7b', round(d['value'],1), 'kind', d['config']['persist_kind'], round(r['avg_launch_us'],1), round(r['frac'],4), 'traffic', r.get('traffic'), str(r.get('traffic_source'))[:50])"; done
