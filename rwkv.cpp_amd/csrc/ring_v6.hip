@@ -42,6 +42,7 @@ struct R6P {
     unsigned * ctl;                                    // [0] tag generation, [1] abort
     const unsigned char * stream; const R6Cu * cus;     // the per-workgroup weight streams
     int F, DR, R, H;
+    int head_wg0;                                      // first of the H workgroups whose comm wave runs a WKV head
     unsigned ring_bytes, mirror_bytes;                 // LDS ring (multiple of 4 KiB) and how much of its head is repeated behind its end
     int inflight, thin;                                // loader: DMA instructions in flight (normal / while the workgroup gathers)
     int nap;                                           // extra 64-cycle sleeps between two looks at a gather's sentinel unit
@@ -1055,8 +1056,10 @@ struct R6 {
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         const int mat = (blk * (4 * D / NBLK)) / D;
         const bool has_dw1 = blk < DR;
-        const bool d_has = blk < H;
-        const int d_head = blk;
+        // the WKV heads run on workgroups hw0 .. hw0 + H - 1
+        const int hw0 = __builtin_amdgcn_readfirstlane(p.head_wg0);
+        const bool d_has = blk >= hw0 && blk < hw0 + H;
+        const int d_head = blk - hw0;
         const int gpb = (nbF + NBLK - 1) / NBLK;
         // B: 64-element chunks of the five mixes; chunk ch < NBLK on workgroup ch, the rest on workgroups NBLK/4.. (the first quarter
         // runs the WKV heads)
@@ -1613,6 +1616,11 @@ void * ring_v6_create(const Model & m) {
     q.stream = rg->stream; q.cus = rg->d_cus;
     q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;
     q.ring_bytes = (unsigned) ring; q.mirror_bytes = (unsigned) mirror;
+    // on the workgroups of the value matrix: their r/k/v/g phase is the shortest (no decay row, 5.0 us against 5.8 - 6.4 us), and the
+    // hand-over behind that phase waits for the slowest workgroup -- which the head's state loads and polls made the receptance ones
+    // (same-box A/B: +0.7 %)
+    q.head_wg0 = env_int("RWKV_MI_RING_HEAD_WG", NB / 2);
+    if (q.head_wg0 < 0 || q.head_wg0 + (int) m.head_count > NB) q.head_wg0 = 0;
     q.logits = nullptr; q.lnout_w = lnw_off; q.lnout_b = lnb_off; q.n_vocab = (int) m.n_vocab();
     auto snap = [](int w) { w &= ~3; return w < 4 ? 4 : (w > 52 ? 52 : w); };
     q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 48));

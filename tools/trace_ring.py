@@ -35,7 +35,8 @@ cn = ['A.gather x', 'A.W2+pro wait', 'B.poll tl', 'B.mix', 'C.gather act', 'D.he
 dc = np.diff(comm, axis=1)
 print('COMM wave: mean / min / max cycles')
 for i, n in enumerate(cn): print('%-14s %8.0f %8.0f %8.0f   %.2f' % (n, dc[:, i].mean(), dc[:, i].min(), dc[:, i].max(), dc[:, i].mean() / 2400))
-print('comm D.head on head workgroups only:', dc[:64, 5].mean(), ' others:', dc[64:, 5].mean())
+hw = np.argsort(-dc[:, 5])[:int((dc[:, 5] > 4 * np.median(dc[:, 5])).sum())]
+print('comm D.head on the head workgroups (%d of them, first %d):' % (len(hw), hw.min() if len(hw) else -1), dc[hw, 5].mean() if len(hw) else 0, ' others:', np.delete(dc[:, 5], hw).mean())
 if os.environ.get('RWKV_MI_RING_DBG', '0') != '0' and int(os.environ['RWKV_MI_RING_DBG']) & 16:
     pr = t[:, 2:, 16:20]
     print('C.rows split (cycles, mean over consumer waves): load+wait %.0f  arithmetic+butterfly %.0f  epilogue %.0f' % (pr[:, :, 0].mean(), pr[:, :, 2].mean(), pr[:, :, 3].mean()))
