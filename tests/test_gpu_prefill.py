@@ -129,3 +129,25 @@ def test_full_length_pass_matches_the_oracle(tmp_path, fmt):
     assert np.array_equal(cl, ol) and np.array_equal(cst, ost)
     m.free()
     om.free()
+
+
+def test_full_length_rwkv7_pass_matches_the_oracle(tmp_path):
+    """RWKV-7 at the length the prefill bench times (1024 tokens = 32 staged chunks of k_wkv7_seq, the F16 low-rank stages on the token
+    tiles, the quantised projections on the matrix cores): logits and the whole state bit for bit, in one pass and in chunks of 300."""
+    library()
+    O.lib().orc_set_fast(1)
+    src, p = str(tmp_path / "f.bin"), str(tmp_path / "m.bin")
+    spec = synth.CONFIGS["test-v7"]
+    synth.write_model(src, spec, "FP32", seed=53)
+    O.quantize_file(src, p, "Q5_1")
+    toks = [int((1103515245 * i + 12345) % spec.n_vocab) for i in range(1024)]
+    om = O.OracleModel(p)
+    ol, ost = om.eval_sequence(toks, om.init_state())
+    m = model(p)
+    gl, gst = m.eval_sequence(toks, None)
+    assert np.array_equal(gl, ol), float(np.abs(gl - ol).max())
+    assert np.array_equal(gst, ost), float(np.abs(gst - ost).max())
+    cl, cst = m.eval_sequence_in_chunks(toks, None, chunk_size=300)
+    assert np.array_equal(cl, ol) and np.array_equal(cst, ost)
+    m.free()
+    om.free()
