@@ -16,9 +16,9 @@
 // Layer block of workgroup b (phases in consumption order; record j of a phase goes to consumer wave (j + rot) % 6):
 //     W1    time_maa_w1 rows b, b + 256, ...              (R = 1, K = D)     -> tanh -> tl
 //     C     two-row sets of ONE of receptance/key/value/gate (R = 2, K = D)  -> r, k, v, g
-//     DW1   time_decay_w1 row b                           (R = 1, K = D)     -> tanh -> dl   (behind C, on a wave with the fewest sets:
-//           in front of them it held that wave -- and with it the ring position the loader may refill -- back by 1.2 us on half of the
-//           workgroups, exactly those that finished their r/k/v/g sets last)
+//     DW1   (empty: time_decay_w1 row b does not travel through the ring. On a consumer wave it cost the 128 workgroups that own one
+//           0.6 - 1.2 us of their r/k/v/g phase -- in front of the sets it also held the loader's window back -- and the hand-over behind
+//           that phase waits for the last workgroup; the comm wave of the workgroup, idle there, reads the row from the planes instead.)
 //     E     output rows                                   (R = 1, K = D)     -> x += ...
 //     FK    two-row sets of ffn.key                       (R = 2, K = D)     -> relu^2 -> k
 //     FR    ffn.receptance rows                           (R = 1, K = D)
@@ -73,7 +73,7 @@ RG_HD RingCu rg_cu(const RingShape & s, int b) {
     const int gpb = rg_gpb(s);
     const int key0 = b * gpb * 32;
     c.n[RG_W1] = (uint32_t) (s.R5 > b ? (s.R5 - b + RG_NBLK - 1) / RG_NBLK : 0);
-    c.n[RG_DW1] = (uint32_t) (b < s.DR ? 1 : 0);
+    c.n[RG_DW1] = 0;   // (the decay row of workgroup b < DR is read from the planes by its comm wave, beside the consumers' r/k/v/g sets: ring_v6.hip)
     c.n[RG_C] = (uint32_t) (rg_rows_c(s) / 2);
     c.n[RG_E] = (uint32_t) rg_rows_e(s);
     c.n[RG_FK] = (uint32_t) (key0 < s.F ? ((s.F - key0 < gpb * 32 ? s.F - key0 : gpb * 32) / 2) : 0);

@@ -856,10 +856,6 @@ struct R6 {
                 if (ln < 2 * MAXT && (ln & 1) == 0 && j < (int) cs.cu.n[RG_C])
                     tg_store(xr, p.rkvg + ((mat * D + cbase + 2 * j) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
             }
-            // the decay row (one wave of the first DR workgroups), behind the sets in the stream
-            rows<RG_DW1, 1, UD, 0, false>(cs, pl, l, qvec_at(l.actw, D), nb, [&](auto, int, const float (&res)[1]) {
-                if (lane == 0) tg_store(xr, p.dl + blk, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
-            });
             R6STAMP(5); R6RSTAMP(27);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 24] = cs.waited;
             issue_pf(pf, ar, L, sin_l, opq(ppt));
@@ -1102,6 +1098,14 @@ struct R6 {
                 wBmaa[q] = ar.f(L.maa[bf[q]])[bd[q]];
                 cw[q] = ar.f(L.ln1_w)[bd[q]]; cb_[q] = ar.f(L.ln1_b)[bd[q]]; cpv[q] = sin_l[D + bd[q]];
             }
+            // the decay row of this workgroup (time_decay_w1 row blk, blk < DR): lane l holds blocks l, l + 64, ... like a ring record
+            RawRec<FMT, 1, UD> dwr;
+            {
+                const WPl dw1 = ar.w(L.dw1);
+                const int drow = has_dw1 ? blk : 0;
+#pragma unroll
+                for (int u = 0; u < UD; u++) { const int bb = u * 64 + lnA; load_raw<FMT>(dwr.raw[u][0], dw1.qs, dw1.qh, dw1.sc, (long long) drow * nb + (bb < nb ? bb : nb - 1)); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 1u));   // l.x holds x - mean, l.misc[0] the scale
             R6STAMP(2);
@@ -1121,32 +1125,33 @@ struct R6 {
                 poll_units<5, 64>(pl, xr, p.tl, 5 * R, tagL + SLOT_TL, ln, [&](int i, const v4u & v) { l.tl[i] = __uint_as_float(v.x); });
                 __builtin_amdgcn_wave_barrier();
                 R6STAMP(3); R6RSTAMP(18);
+                // both chunks' sums in ONE loop: a sum is a chain of R dependent adds (its order is the reference's), and the second
+                // chain runs in the issue slots the first one leaves empty -- a workgroup with two chunks stores its second image
+                // about when the others store their only one, and the act hand-over waits for the last store. (Workgroups without a
+                // second chunk run the loop on a copy of chunk 0 and store nothing for it.)
+                {
+                    const float4 * tla = reinterpret_cast<const float4 *>(l.tl + bf[0] * R), * tlb = reinterpret_cast<const float4 *>(l.tl + bf[1] * R);
+                    float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const bool has = q == 0 ? blk < NCH : b_chunk2 >= 0;
-                    if (has) {
-                        const float * tlf = l.tl + bf[q] * R;
-                        const float4 * tl4 = reinterpret_cast<const float4 *>(tlf);
-                        float acc = 0.0f;
-                        {
-                            float4 t4[8];
+                    for (int h = 0; h < (R > 32 ? 2 : 1); h++) {
+                        float4 ta[8], tb[8];
 #pragma unroll
-                            for (int j = 0; j < 8; j++) t4[j] = tl4[j];
+                        for (int j = 0; j < 8; j++) { ta[j] = tla[8 * h + j]; tb[j] = tlb[8 * h + j]; }
 #pragma unroll
-                            for (int m = 0; m < 32; m++) acc += (&wB4[q][m >> 2].x)[m & 3] * (&t4[m >> 2].x)[m & 3];
+                        for (int m = 0; m < 32; m++) {
+                            acc0 += (&wB4[0][8 * h + (m >> 2)].x)[m & 3] * (&ta[m >> 2].x)[m & 3];
+                            acc1 += (&wB4[1][8 * h + (m >> 2)].x)[m & 3] * (&tb[m >> 2].x)[m & 3];
                         }
-                        if (R > 32) {
-                            float4 t4[8];
+                    }
+                    const float accq[2] = {acc0, acc1};
 #pragma unroll
-                            for (int j = 0; j < 8; j++) t4[j] = tl4[8 + j];
-#pragma unroll
-                            for (int m = 0; m < 32; m++) acc += (&wB4[q][8 + (m >> 2)].x)[m & 3] * (&t4[m >> 2].x)[m & 3];
-                        }
-                        const float mm = (acc + wBmaa[q]) * csx[q];
+                    for (int q = 0; q < 2; q++) {
+                        const bool has = q == 0 ? blk < NCH : b_chunk2 >= 0;
+                        const float mm = (accq[q] + wBmaa[q]) * csx[q];
                         const float o = mm + cxn[q];
                         int qi, isum; float d16, s16;
                         quant_block32(o, qi, d16, s16, isum);
-                        tq_store_block(xr, p.act5 + bf[q] * p.act_stride, bd[q] >> 5, ln & 31, qi, d16, s16, isum, tagL + SLOT_ACT);
+                        if (has) tq_store_block(xr, p.act5 + bf[q] * p.act_stride, bd[q] >> 5, ln & 31, qi, d16, s16, isum, tagL + SLOT_ACT);
                     }
                 }
             }
@@ -1162,6 +1167,16 @@ struct R6 {
                 sweep_end(l);
             }
             R6STAMP(5); R6RSTAMP(20);
+            // ---- the decay row against the w mix (rows<> of a consumer wave: per-lane block sums in increasing order, one butterfly) ----
+            if (has_dw1) {
+                const int ln = opq(lane);
+                ActRegs<UD> arw;
+                act_load<UD>(arw, qvec_at(l.actw, D), nb, ln);
+                float part[1];
+                rec_acc<FMT, 1, UD>(dwr, arw, nb, ln, part);
+                wave_sum_n<1>(part);
+                if (ln == 0) tg_store(xr, p.dl + blk, __float_as_uint(det_tanhf(part[0])), 0u, 0u, 0u, tagL + SLOT_RKVG);
+            }
             // ---- D: WKV head of this workgroup ----
             if (d_has) {
                 const int ln = opq(lane);
