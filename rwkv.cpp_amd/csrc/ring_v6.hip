@@ -56,7 +56,8 @@ struct R6P {
 // monotonic words in LDS
 enum { FL_LANDED = 0, FL_SWB = 1, FL_SWE = 2 /* wide sweeps begun / ended (the loader keeps fewer fills in flight while they differ) */, FL_DONE = 4 /* [8], 16-byte aligned */, FL_GX = 12, FL_GACT = 13, FL_GYQ = 14, FL_GKQ = 15,
        FL_RED1 = 16, FL_RED2 = 17, FL_PRO = 18, FL_KEYS = 19,
-       FL_HX = 20, FL_HACT = 21, FL_HYQ = 22, FL_HKQ = 23, FL_HTL = 24 /* "some wave saw its sentinel turn" per gather kind */, FL_WORDS = 32 };
+       FL_HX = 20, FL_HACT = 21, FL_HYQ = 22, FL_HKQ = 23, FL_HTL = 24 /* "some wave saw its sentinel turn" per gather kind */,
+       FL_PROX = 25 /* consumer waves 4, 5 are done with their share of a prologue's elementwise part */, FL_WORDS = 32 };
 
 struct R6Lds { size_t x, q1, q2, u, tl, bc, red, out, dl, misc, fl, ring, fixed; };
 __host__ __device__ inline R6Lds r6_lds(int D, int F) {
@@ -347,22 +348,36 @@ struct R6 {
     // -----------------------------------------------------------------------------------------------------------
     // prologues (consumer waves 0..3 = 256 threads)
     // -----------------------------------------------------------------------------------------------------------
-    struct PA { float4 lw[V4], lb[V4], pv[V4], mx[V4]; };
-    struct PF { float4 lw[V4], lb[V4], pv[V4], mk[V4], mr[V4]; };
-    static __device__ __forceinline__ void issue_pa(PA & pa, const M6Arena & ar, const M6Layer & L, const float * sin_l, int pt) {
+    // The statistics run on consumer waves 0..3 (the reduction tree is defined over 256 partials). The elementwise
+    // part behind them -- LayerNorm affine, token-shift mixes, quantisation: most of a prologue -- is spread over all six consumer waves
+    // where the row divides that way (D = 4096: 1024 groups of four elements = three per thread of waves 0..3 + two per thread of
+    // waves 4, 5, which used to idle through the prologue); every 32-block stays inside eight consecutive lanes.
+    static constexpr int SLO = V4 == 4 ? 3 : V4;        // groups of four elements per thread of consumer waves 0..3
+    static constexpr int SHI = V4 == 4 ? 2 : 0;         // ... of consumer waves 4, 5
+    static constexpr int SMAX = SLO > SHI ? SLO : SHI;
+    static __device__ __forceinline__ int pslots(int c) { return c < 4 ? SLO : SHI; }
+    // element index of slot k of consumer wave c (a missing slot repeats slot 0: loads stay unconditional)
+    static __device__ __forceinline__ int pelem(int c, int lane, int k) {
+        const int kk = k < pslots(c) ? k : 0;
+        if (SHI == 0 && c >= 4) return 4 * lane;        // (waves 4, 5 take no part: any valid address)
+        return 4 * (c < 4 ? c * 64 + lane + 256 * kk : 256 * SLO + (c - 4) * 64 * SHI + 64 * kk + lane);
+    }
+    struct PA { float4 lw[SMAX], lb[SMAX], pv[SMAX], mx[SMAX]; };
+    struct PF { float4 lw[SMAX], lb[SMAX], pv[SMAX], mk[SMAX], mr[SMAX]; };
+    static __device__ __forceinline__ void issue_pa(PA & pa, const M6Arena & ar, const M6Layer & L, const float * sin_l, int c, int lane) {
         const float * ln1_w = ar.f(L.ln1_w), * ln1_b = ar.f(L.ln1_b), * maa_x = ar.f(L.maa_x);
 #pragma unroll
-        for (int u = 0; u < V4; u++) {
-            const int i = pt * 4 + u * 1024;
+        for (int u = 0; u < SMAX; u++) {
+            const int i = pelem(c, lane, u);
             pa.lw[u] = *reinterpret_cast<const float4 *>(ln1_w + i); pa.lb[u] = *reinterpret_cast<const float4 *>(ln1_b + i);
             pa.pv[u] = *reinterpret_cast<const float4 *>(sin_l + D + i); pa.mx[u] = *reinterpret_cast<const float4 *>(maa_x + i);
         }
     }
-    static __device__ __forceinline__ void issue_pf(PF & pf, const M6Arena & ar, const M6Layer & L, const float * sin_l, int pt) {
+    static __device__ __forceinline__ void issue_pf(PF & pf, const M6Arena & ar, const M6Layer & L, const float * sin_l, int c, int lane) {
         const float * ln2_w = ar.f(L.ln2_w), * ln2_b = ar.f(L.ln2_b), * fmaa_k = ar.f(L.fmaa_k), * fmaa_r = ar.f(L.fmaa_r);
 #pragma unroll
-        for (int u = 0; u < V4; u++) {
-            const int i = pt * 4 + u * 1024;
+        for (int u = 0; u < SMAX; u++) {
+            const int i = pelem(c, lane, u);
             pf.lw[u] = *reinterpret_cast<const float4 *>(ln2_w + i); pf.lb[u] = *reinterpret_cast<const float4 *>(ln2_b + i);
             pf.pv[u] = *reinterpret_cast<const float4 *>(sin_l + i);
             pf.mk[u] = *reinterpret_cast<const float4 *>(fmaa_k + i); pf.mr[u] = *reinterpret_cast<const float4 *>(fmaa_r + i);
@@ -393,14 +408,22 @@ struct R6 {
         const float var = (float) (wave_sum_d(t2) / (double) D);
         return 1.0f / sqrtf(var + 1e-5f);
     }
+    // the same scale on a wave that owns no partial (consumer waves 4, 5): behind the second reduction round x - mean is in l.x
+    static __device__ __forceinline__ float ln_scale(Poll & pl, const Lds & l, int lane, unsigned gen) {
+        fl_wait(pl, l.fl + FL_RED2, 4u * gen);
+        const double t2 = (l.red[256 + lane] + l.red[256 + lane + 128]) + (l.red[256 + lane + 64] + l.red[256 + lane + 192]);
+        const float var = (float) (wave_sum_d(t2) / (double) D);
+        return 1.0f / sqrtf(var + 1e-5f);
+    }
     // A: LN1 + token shift + maa_x mix + quantise -> l.q1
-    static __device__ __forceinline__ void prologue_A(Poll & pl, const Lds & l, const PA & pa, float * sout_l, bool write_state, int pt, int lane, unsigned gen) {
-        const float scale = ln_stats(pl, l, pt, lane, gen);
-        if (pt == 0) l.misc[0] = scale;
+    static __device__ __forceinline__ void prologue_A(Poll & pl, const Lds & l, const PA & pa, float * sout_l, bool write_state, int c, int lane, unsigned gen) {
+        const float scale = c < 4 ? ln_stats(pl, l, c * 64 + lane, lane, gen) : ln_scale(pl, l, lane, gen);
+        if (c == 0 && lane == 0) l.misc[0] = scale;
         const QVec lq = qvec_at(l.q1, D);
 #pragma unroll
-        for (int u = 0; u < V4; u++) {
-            const int i = pt * 4 + u * 1024;
+        for (int u = 0; u < SMAX; u++) {
+            if (u >= pslots(c)) break;
+            const int i = pelem(c, lane, u);
             const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
             const float xs[4] = {xc.x, xc.y, xc.z, xc.w};
             const float lw[4] = {pa.lw[u].x, pa.lw[u].y, pa.lw[u].z, pa.lw[u].w}, lb[4] = {pa.lb[u].x, pa.lb[u].y, pa.lb[u].z, pa.lb[u].w};
@@ -420,15 +443,16 @@ struct R6 {
             quant_vec4(xxx, packed, d16, s16, isum);
             qvec_store4(lq, nb, i, packed, d16, s16, isum);
         }
-        fl_add(l.fl + FL_PRO, 1u);
+        fl_add(l.fl + (c < 4 ? FL_PRO : FL_PROX), 1u);
     }
     // F: LN2 + token shift + the two mixes + quantise -> l.q1 (key input), l.q2 (receptance input)
-    static __device__ __forceinline__ void prologue_F(Poll & pl, const Lds & l, const PF & pf, float * sout_l, bool write_state, int pt, int lane, unsigned gen) {
-        const float scale = ln_stats(pl, l, pt, lane, gen);
+    static __device__ __forceinline__ void prologue_F(Poll & pl, const Lds & l, const PF & pf, float * sout_l, bool write_state, int c, int lane, unsigned gen) {
+        const float scale = c < 4 ? ln_stats(pl, l, c * 64 + lane, lane, gen) : ln_scale(pl, l, lane, gen);
         const QVec qk = qvec_at(l.q1, D), qr = qvec_at(l.q2, D);
 #pragma unroll
-        for (int u = 0; u < V4; u++) {
-            const int i = pt * 4 + u * 1024;
+        for (int u = 0; u < SMAX; u++) {
+            if (u >= pslots(c)) break;
+            const int i = pelem(c, lane, u);
             const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
             const float xs[4] = {xc.x, xc.y, xc.z, xc.w};
             const float lw[4] = {pf.lw[u].x, pf.lw[u].y, pf.lw[u].z, pf.lw[u].w}, lb[4] = {pf.lb[u].x, pf.lb[u].y, pf.lb[u].z, pf.lb[u].w};
@@ -453,7 +477,12 @@ struct R6 {
             quant_vec4(xr, packed, d16, s16, isum);
             qvec_store4(qr, nb, i, packed, d16, s16, isum);
         }
-        fl_add(l.fl + FL_PRO, 1u);
+        fl_add(l.fl + (c < 4 ? FL_PRO : FL_PROX), 1u);
+    }
+    // everything a prologue leaves in LDS is there (gen = prologues so far)
+    static __device__ __forceinline__ void prologue_wait(Poll & pl, const Lds & l, unsigned gen) {
+        fl_wait(pl, l.fl + FL_PRO, 4u * gen);
+        if constexpr (SHI > 0) fl_wait(pl, l.fl + FL_PROX, 2u * gen);
     }
 
     // -----------------------------------------------------------------------------------------------------------
@@ -617,11 +646,11 @@ struct R6 {
     // back a memory latency later. Taking the first record into registers in front of the gather gives the loader that room -- six
     // records per workgroup -- while the workgroup exchanges. Never waits: a record that has not landed yet is read by rows() as before.
     template <int R, int U> struct Pre { RawRec<FMT, R, U> w; bool have; };
-    // which phases do it (1: r/k/v/g, 2: output, 4: ffn key, 8: ffn value). D = 4096: the prologue parameters in flight across the
-    // same hand-overs leave registers for two of them (Q4_0) or one (kernel-resource-usage: any more spills); same-box A/B on the 7B
-    // file +2.2 % tokens/s. D = 2048: none -- a layer block (130 KB per workgroup) nearly fits the ring as it is, and the extra ring
-    // checks in the watch loops cost 2.5 %.
-    static constexpr int PRE_MASK = EPT > 4 ? (FMT == T_Q4_0 ? 9 : 8) : 0;
+    // which phases do it (1: r/k/v/g, 2: output, 4: ffn key, 8: ffn value). D = 4096: as many as the registers hold without spilling
+    // (kernel-resource-usage): all four for Q4_0, three for Q4_1 / Q5_0, r/k/v/g (+ ffn value where its record is small enough) for
+    // Q5_1 / Q8_0. D = 2048: none -- a layer block (130 KB per workgroup) nearly fits the ring as it is, and the extra ring checks in
+    // the watch loops cost 2.5 %.
+    static constexpr int PRE_MASK = EPT > 4 ? (FMT == T_Q4_0 ? 15 : ((FMT == T_Q4_1 || FMT == T_Q5_0) ? 13 : 9)) : 0;
     template <int PH, int R, int U, int TF>
     static __device__ __forceinline__ void rows_pre(Cons & cs, const Lds & l, Pre<R, U> & pre) {
         constexpr unsigned RECB = (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0));
@@ -761,11 +790,9 @@ struct R6 {
     static __device__ __forceinline__ void consumer_main(const R6P & p, const Lds & l, int lane, int wave, unsigned base) {
         const int blk = blockIdx.x;
         const int c = wave - 2;                       // consumer index = gather share
-        const int pt = c * 64 + lane;                 // prologue thread (c < 4)
-        const bool pro = c < 4;
-        // The prologue parameters are loaded by EVERY consumer wave (waves 4, 5 re-read wave 0's and 1's): a load under `if (pro)` is a
-        // conditional definition, and the compiler then waits for it and copies it right where it is issued.
-        const int ppt = pro ? pt : lane;
+        const bool pro = c < 4 || SHI > 0;            // takes part in the prologues' elementwise part
+        // (The prologue parameters are loaded by EVERY consumer wave, also where waves 4, 5 take no part: a load under `if (pro)` is a
+        //  conditional definition, and the compiler then waits for it and copies it right where it is issued.)
         const int F = p.F, nbF = F / 32;
         Poll pl{p.ctl, false};
         const M6Arena ar{p.arena};
@@ -786,7 +813,7 @@ struct R6 {
 #pragma unroll
         for (int t = 0; t < XT; t++) { const int row = c + NC * t; xown[t] = row < RE ? p.x[blk * RE + row] : 0.0f; rrow[t] = 0.0f; }
         PA pa; PF pf;
-        issue_pa(pa, ar, p.layers[0], p.sin, opq(ppt));
+        issue_pa(pa, ar, p.layers[0], p.sin, c, opq(lane));
 
         for (int li = 0; li < p.n_layers; li++) {
             const M6Layer & L = p.layers[li];
@@ -812,8 +839,8 @@ struct R6 {
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
             sweep_end(l);
             R6STAMP(1);
-            if (pro) prologue_A(pl, l, pa, sout_l, blk == 0, opq(pt), opq(lane), 2u * li + 1u);
-            fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 1u));
+            if (pro) prologue_A(pl, l, pa, sout_l, blk == 0, c, opq(lane), 2u * li + 1u);
+            prologue_wait(pl, l, 2u * li + 1u);
             R6STAMP(2);
             rows<RG_W1, 1, UD, 0, false>(cs, pl, l, qvec_at(l.q1, D), nb, [&](auto, int j, const float (&res)[1]) {
                 if (lane == 0) tg_store(xr, p.tl + blk + NBLK * j, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
@@ -858,7 +885,7 @@ struct R6 {
             }
             R6STAMP(5); R6RSTAMP(27);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 24] = cs.waited;
-            issue_pf(pf, ar, L, sin_l, opq(ppt));
+            issue_pf(pf, ar, L, sin_l, c, opq(lane));
             __builtin_amdgcn_sched_barrier(0);
             // ---- E: output projection + residual ----
             Pre<1, UD> pe;
@@ -888,8 +915,8 @@ struct R6 {
             gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
             sweep_end(l);
             R6STAMP(8);
-            if (pro) prologue_F(pl, l, pf, sout_l, blk == 0, opq(pt), opq(lane), 2u * li + 2u);
-            fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 2u));
+            if (pro) prologue_F(pl, l, pf, sout_l, blk == 0, c, opq(lane), 2u * li + 2u);
+            prologue_wait(pl, l, 2u * li + 2u);
             R6STAMP(9); R6RSTAMP(28);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 21] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_FK]);
             rows<RG_FK, 2, UD, (UF * 64 > NBLK ? 32 : 16) / NC, true>(cs, pl, l, qvec_at(l.q1, D), nb, pk, [&](auto, int j, const float (&res)[2]) {
@@ -927,7 +954,7 @@ struct R6 {
             R6STAMP(13); R6RSTAMP(14);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 25] = cs.waited;
             if (li + 1 < p.n_layers) {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
-                issue_pa(pa, ar, p.layers[li + 1], p.sin + (long long) (li + 1) * p.state_stride, opq(ppt));
+                issue_pa(pa, ar, p.layers[li + 1], p.sin + (long long) (li + 1) * p.state_stride, c, opq(lane));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
