@@ -151,7 +151,7 @@ def abi_rate(model, first_token, n):
             "note": "rwkv_eval(ctx, token, state, state, logits): host state in + out and logits out on every call, numpy argmax on the host"}
 
 
-def cpu_baseline(path, first_token, budget_s):
+def cpu_baseline(path, first_token, budget_s, snapshot_at=64):
     """Times the CPU oracle (oracle/rwkv_oracle.c: ggml's CPU algorithm restated, OpenMP) on the same file and the same
     greedy decode. Bounded sample; reported, never the target. The greedy tokens are kept: main() compares them with the GPU's."""
     import numpy as np
@@ -166,15 +166,17 @@ def cpu_baseline(path, first_token, budget_s):
     state = om.init_state()
     tok, n, t_start = first_token, 0, time.time()
     toks = []
+    final = None
     while True:
         logits, state = om.eval(tok, state)
         tok = int(np.argmax(logits))
         toks.append(tok)
         n += 1
+        if n <= max(1, snapshot_at):     # logits and state behind the LAST token the parity leg compares (it compares the first min(n, snapshot_at))
+            final = (np.array(logits, copy=True), np.array(state, copy=True))
         el = time.time() - t_start
         if n >= 2 and (el + el / n > budget_s or n >= 64):
             break
-    final = (np.array(logits, copy=True), np.array(state, copy=True))
     om.free()
     return {"value": n / el, "unit": "tokens/s", "cores": cores, "kind": "port", "simd": simd,
             "sample": f"{n} greedy decode tokens of the same model file on the host CPU ({el:.1f}s, load {load_s:.1f}s); "
@@ -257,15 +259,29 @@ def bench_decode(args, pkg, lib, path, spec, torch):
                                   "avg_bytes_per_launch": p["bytes"] / p["launches"]}
     if args.abi_tokens > 0:
         result["abi"] = abi_rate(model, first, args.abi_tokens)
+    if args.cpu_seconds <= 0:
+        result["parity"] = {"skipped": "--cpu-seconds 0: the CPU oracle did not run"}
     if args.cpu_seconds > 0:
         # The CPU oracle (checker and reported baseline) decodes n greedy tokens of the same file within its budget; the GPU then decodes
         # exactly n tokens from a fresh state -- on the persistent path with the rolling hand-over tag preset so that they cross its
         # 16-bit wrap (it advances 8 per layer: every 256 tokens at 32 layers) -- and tokens, the last token's LOGITS and the whole
         # recurrent STATE must be equal bit for bit (argmax alone would hide low-order differences).
-        result["cpu_baseline"], cpu_toks, (cpu_logits, cpu_state) = cpu_baseline(path, first, args.cpu_seconds)
+        result["cpu_baseline"], cpu_toks, (cpu_logits, cpu_state) = cpu_baseline(path, first, args.cpu_seconds, args.parity_tokens)
         n = min(len(cpu_toks), args.parity_tokens)
-        if n > 0 and n == len(cpu_toks):
-            wrap = path_id == 2 and model.test_set_tag(0x10000 - 8 * spec.n_layer * max(1, n // 2))
+        if n <= 0:
+            result["parity"] = {"skipped": "--parity-tokens 0"}
+        else:
+            wrap = False
+            if path_id == 2:
+                # place the n compared tokens across the 16-bit wrap of the hand-over tag: throw-away tokens until the generation
+                # (rwkv_mi_decode_generation: +8 per layer and launch) is n / 2 tokens below it
+                per = 8 * spec.n_layer
+                left = (0x10000 - (model.decode_generation() & 0xFFFF)) // per     # whole tokens before the wrap
+                burn = (left - max(1, n // 2)) % (0x10000 // per)
+                if burn > 0:
+                    model.decode_greedy(first, burn)
+                g0 = model.decode_generation() & 0xFFFF
+                wrap = g0 + n * per > 0x10000
             model.state_load(None)
             gpu_toks, _ = model.decode_greedy(first, n)
             gpu_logits, gpu_state = model.logits_store(), model.state_store()
@@ -396,8 +412,19 @@ def bench_chain(args, pkg, lib, path, spec, torch):
         ct, _ = front.decode_greedy(first, k)
         cs = front.state_store()
         equal = bool(np.array_equal(rt, ct) and np.array_equal(rs, cs) and np.array_equal(toks[:k], rt) and np.array_equal(mtoks[0][:k], rt))
-        result["parity"] = {"tokens_checked": int(k), "equal": equal, "what": "tokens and recurrent state, stage chain vs one-device context, bit for bit"}
+        result["parity"] = {"tokens_checked": int(k), "equal": equal,
+                            "what": "tokens and recurrent state, stage chain vs a one-device context of the same file, bit for bit (transitive: the "
+                                    "one-device context is what the N = 1 line and tests/ compare with the CPU oracle)"}
         ref.free()
+        if args.cpu_seconds > 0:
+            # ... and directly against the CPU oracle for the first tokens its budget allows
+            _, cpu_toks, (cpu_logits, cpu_state) = cpu_baseline(path, first, args.cpu_seconds, k)
+            kk = min(k, len(cpu_toks))
+            front.state_load(None)
+            ot, _ = front.decode_greedy(first, kk)
+            o_eq = bool(list(ot[:kk]) == list(cpu_toks[:kk]) and np.array_equal(front.state_store(), cpu_state))
+            result["parity"]["oracle"] = {"tokens_checked": int(kk), "equal": o_eq, "what": "tokens and recurrent state, stage chain vs the CPU oracle"}
+            equal = equal and o_eq
         if not equal:
             print(json.dumps(result))
             raise SystemExit("[bench] PARITY FAILURE: the stage chain differs from the one-device context")
@@ -415,9 +442,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and not args.chain:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1", file=sys.stderr)
     import torch
+    if world == 1 and args.gpus > 1 and not args.chain:
+        # a bare `bench.py --gpus N` (no torch.distributed.run): the one-process layer chain needs no launcher. Never a 1-GPU line under an
+        # N-GPU flag: with fewer than N devices visible the run stops here.
+        have = torch.cuda.device_count()
+        if have < args.gpus and not args.chain_devices:
+            raise SystemExit(f"[bench] --gpus {args.gpus} but {have} device(s) visible and no torch.distributed.run world: nothing to measure "
+                             f"(use --chain-devices 0,0,... to run the stages on fewer devices)")
+        print(f"[bench] --gpus {args.gpus} without torch.distributed.run: running the one-process layer chain (RWKV_MI_DEVICES=0-{args.gpus - 1})", file=sys.stderr)
+        args.chain = True
+    elif world > 1 and world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}")
 
     backend = os.environ.get("RWKV_BENCH_BACKEND", "nccl")   # "gloo" only for smoke-testing the N > 1 path on a single GPU
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))

@@ -122,20 +122,9 @@ RWKV_API bool rwkv_mi_logits_store(struct rwkv_context * ctx, float * logits_out
 /* Device pointer of the context's logits (n_vocab floats), valid after a step that produced logits. */
 RWKV_API const float * rwkv_mi_logits_device_ptr(const struct rwkv_context * ctx);
 
-/* Test hook (used by tests/ and bench.py's parity leg only): presets the rolling hand-over tag of decode path 2 (the kernel
- * compares its low 16 bits; it advances by 8 per layer), so that a short run crosses the 16-bit wrap. false if path 2 is off. */
-RWKV_API bool rwkv_mi_test_set_tag(struct rwkv_context * ctx, uint32_t base);
-
-/* Test hook (used by tests/ only): the activation quantiser; n multiple of 32; d, s, isum have n/32 entries. */
-RWKV_API bool rwkv_mi_test_quantize_act(const float * x, int64_t n, int8_t * q, float * d, float * s, int32_t * isum);
-
-/* Test hook (used by tests/ only): y[i] = f(x[i]) with the kernels' deterministic scalar routines.
- * op: 0 exp, 1 tanh, 2 sigmoid, 3 silu, 4 exp(-exp(x)), 5 exp(-0.606531*sigmoid(x)), 6 1/sqrt(x + 1e-5). */
-RWKV_API bool rwkv_mi_test_unary(int op, const float * x, float * y, int64_t n);
-
-/* Test hook (used by tests/ only): y[T][N] = W[N][K] . x[T][K] through the production projection kernels. `w` holds N rows
- * in the FILE layout of `type` (rwkv.cpp type id: 0 FP32, 1 FP16, 2 Q4_0, 3 Q4_1, 7 Q5_0, 8 Q5_1, 9 Q8_0). */
-RWKV_API bool rwkv_mi_test_mul_mat(int type, const void * w, int64_t K, int64_t N, const float * x, int64_t T, float * y);
+/* The hand-over generation of decode path 2 (the persistent kernel compares its low 16 bits; it advances by 8 per layer and launch).
+ * Diagnostic, read-only: bench.py places its parity run across the 16-bit wrap with it. 0 if path 2 is off. */
+RWKV_API uint32_t rwkv_mi_decode_generation(struct rwkv_context * ctx);
 
 #if defined(__cplusplus)
 }

@@ -4,6 +4,7 @@ The directory name contains a dot, so import it through `__graft_entry__.load_pa
 repo root to sys.path and use `importlib.import_module("rwkv.cpp_amd")` is NOT possible; see __graft_entry__.py.
 """
 from .rwkv_cpp import (  # noqa: F401
+    HOOKS_LIB_PATH,
     LIB_PATH,
     RWKVContext,
     RWKVModel,

@@ -976,6 +976,11 @@ bool mega_v6_clear_abort(void * h, hipStream_t st) {
     mg->h_ctl[1] = 0u;
     return hipMemsetAsync(mg->ctl + 1, 0, sizeof(unsigned), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
 }
+// the tag generation the next launch starts from (ctl[0]), through the pinned mirror
+unsigned mega_v6_generation(void * h, hipStream_t st) {
+    if (!mega_v6_ctl_fetch(h, st) || hipStreamSynchronize(st) != hipSuccess) return 0;
+    return is_ring(h) ? ring_v6_generation_cached(h) : ((MegaV6 *) h)->h_ctl[0];
+}
 // Test hook: presets the rolling tag generation (ctl[0]; the kernel compares its low 16 bits), e.g. just below a 16-bit wrap.
 bool mega_v6_set_tag(void * h, unsigned base, hipStream_t st) {
     if (is_ring(h)) return ring_v6_set_tag(h, base, st);

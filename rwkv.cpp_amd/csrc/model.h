@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 
 #include "common.h"
 #include "kernels.h"
@@ -39,6 +40,11 @@ struct Model {
     // 0 not measured, 1 persistent kernel on register prefetch, 2 persistent kernel on the LDS-DMA ring, 3 seven launches per layer.
     // Clones reuse it instead of timing every path again.
     mutable std::atomic<int> decode_choice{0};
+
+    // Device images a decode path derives from the weights alone (ring_v6.hip: the per-workgroup weight streams, the blocked W2, the
+    // layer table): built by the first context that needs them, shared by every context of the model, freed with the last holder.
+    mutable std::mutex derived_mu;
+    mutable void * ring_shared = nullptr;
 
     std::vector<std::unique_ptr<DevTensor>> tensors;
     std::unordered_map<std::string, DevTensor *> by_name;
@@ -215,6 +221,7 @@ bool     mega_v6_aborted_cached(void * h);                  // the mirror's abor
 bool     mega_v6_aborted(void * h, hipStream_t st);         // fetch + synchronise + check
 bool     mega_v6_clear_abort(void * h, hipStream_t st);
 bool     mega_v6_set_tag(void * h, unsigned base, hipStream_t st);
+unsigned mega_v6_generation(void * h, hipStream_t st);   // the hand-over generation the next launch starts from
 uint64_t mega_v6_bytes(void * h);
 bool     mega_v6_trace(void * h, int layer, long long * out, bool fetch);
 int      mega_v6_kind(void * h);            // 1: register prefetch (mega_v6.hip), 2: LDS-DMA weight ring (ring_v6.hip)
@@ -225,6 +232,7 @@ void     ring_v6_forward(void * h, float * x, const float * sin, float * sout, h
 bool     ring_v6_folds_head(void * h);
 bool     ring_v6_ctl_fetch(void * h, hipStream_t st);
 bool     ring_v6_aborted_cached(void * h);
+unsigned ring_v6_generation_cached(void * h);
 bool     ring_v6_clear_abort(void * h, hipStream_t st);
 bool     ring_v6_set_tag(void * h, unsigned base, hipStream_t st);
 uint64_t ring_v6_bytes(void * h);

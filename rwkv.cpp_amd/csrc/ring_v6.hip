@@ -1463,22 +1463,35 @@ __global__ void k_block_w2_ring(const float * __restrict__ src, float * __restri
     }
 }
 
-struct RingV6 {
-    int kind = 2;                 // (first member: mega_v6.hip's entry points dispatch on it)
+// What a context's ring kernel derives from the WEIGHTS alone -- the per-workgroup streams (3.9 GB + 0.5 GB of head for the 7B Q4_0),
+// the chunk-blocked W2, the layer table -- is built once per Model and shared by every context of it (rwkv_clone_context, the decode
+// streams of a pipeline stage: the reference's clones share their weights too, rwkv.cpp:109-143). Round 3 built it per context:
+// N decode streams cost N x the model in HBM and re-ran k_ring_pack for all layers. Refcounted by the handles; the Model keeps the
+// pointer (Model::ring_shared, under Model::derived_mu) only while a handle holds it.
+struct RingShared {
+    int ref = 0;
     float * w2b = nullptr;
     M6Layer * d_layers = nullptr;
     R6Cu * d_cus = nullptr;
     unsigned char * stream = nullptr;
+    int variant = -1, n_blocks = 0, n_layers = 0;
+    size_t lds = 0, ring = 0, mirror = 0;
+    uint64_t bytes = 0;
+    bool head = false;            // the head projection is folded into the launch (F16 head.weight, vocabulary a multiple of 4096)
+    uint64_t bytes_head = 0;      // its algorithmic bytes: head.weight, ln_out, the logits written
+    long long lnw_off = 0, lnb_off = 0;
+    int64_t D = 0, F = 0, DR = 0, R = 0;
+};
+
+struct RingV6 {
+    int kind = 2;                 // (first member: mega_v6.hip's entry points dispatch on it)
+    const Model * model = nullptr;
+    RingShared * sh = nullptr;
     void * xch = nullptr;
     unsigned * ctl = nullptr;
     unsigned * h_ctl = nullptr;
     R6P proto{};
     long long * trace = nullptr;
-    int variant = -1, n_blocks = 0;
-    size_t lds = 0;
-    uint64_t bytes = 0;
-    bool head = false;            // the head projection is folded into the launch (F16 head.weight, vocabulary a multiple of 4096)
-    uint64_t bytes_head = 0;      // its algorithmic bytes: head.weight, ln_out, the logits written
 };
 
 typedef void (*RingKernel)(R6P);
@@ -1515,24 +1528,19 @@ static int ring_variant(const Model & m, int n_cu) {
     return -1;
 }
 
-void ring_v6_destroy(void * h) {
-    RingV6 * rg = (RingV6 *) h;
-    if (!rg) return;
-    if (rg->d_layers) (void) hipFree(rg->d_layers);
-    if (rg->d_cus) (void) hipFree(rg->d_cus);
-    if (rg->w2b) (void) hipFree(rg->w2b);
-    if (rg->stream) (void) hipFree(rg->stream);
-    if (rg->xch) (void) hipFree(rg->xch);
-    if (rg->ctl) (void) hipFree(rg->ctl);
-    if (rg->h_ctl) (void) hipHostFree(rg->h_ctl);
-    if (rg->trace) (void) hipFree(rg->trace);
-    delete rg;
+static void ring_shared_free(RingShared * sh) {
+    if (!sh) return;
+    if (sh->d_layers) (void) hipFree(sh->d_layers);
+    if (sh->d_cus) (void) hipFree(sh->d_cus);
+    if (sh->w2b) (void) hipFree(sh->w2b);
+    if (sh->stream) (void) hipFree(sh->stream);
+    delete sh;
 }
 
 static int env_int(const char * name, int dflt) { const char * e = getenv(name); return e && e[0] ? atoi(e) : dflt; }
 
-// Returns nullptr when the model / device does not qualify (the caller tries the register-prefetch kernel, then the seven launches).
-void * ring_v6_create(const Model & m) {
+// builds the shared images of model m on the current device (nullptr: the model / device does not qualify, or out of memory -- said on stderr)
+static RingShared * ring_shared_build(const Model & m) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, m.device) != hipSuccess) return nullptr;
     const int NB = prop.multiProcessorCount;
@@ -1544,24 +1552,25 @@ void * ring_v6_create(const Model & m) {
     RingShape sh; sh.D = (int) D; sh.F = (int) F; sh.R5 = (int) (5 * R); sh.DR = (int) DR;
     sh.qs = fmt == T_Q8_0 ? 32 : 16; sh.scb = (fmt == T_Q4_1 || fmt == T_Q5_1) ? 4 : 2; sh.qhb = (fmt == T_Q5_0 || fmt == T_Q5_1) ? 4 : 0;
     const int n_layers = (int) (m.layer_end - m.layer_begin);
-    RingV6 * rg = new RingV6();
-    rg->variant = v; rg->n_blocks = NB;
+    RingShared * rs = new RingShared();
+    rs->variant = v; rs->n_blocks = NB; rs->n_layers = n_layers;
+    rs->D = D; rs->F = F; rs->DR = DR; rs->R = R;
     const R6Lds lo = r6_lds((int) D, (int) F);
     const size_t lds_max = 160 * 1024;
     // the ring is filled in 4-KiB groups of four DMA instructions; its head is repeated behind its end for the longest record (rec_load)
     const size_t max_rec_bytes = rg_rec_bytes(sh, 1, (int) F) > rg_rec_bytes(sh, 2, (int) D) ? rg_rec_bytes(sh, 1, (int) F) : rg_rec_bytes(sh, 2, (int) D);
     const size_t mirror = ((max_rec_bytes > RG_HREC ? max_rec_bytes : RG_HREC) + 4095) / 4096 * 4096;
     size_t ring = (size_t) env_int("RWKV_MI_RING_KB", 1024) * 1024;
-    if (lo.fixed + mirror + 32 * 1024 > lds_max) { delete rg; return nullptr; }
+    if (lo.fixed + mirror + 32 * 1024 > lds_max) { delete rs; return nullptr; }
     if (ring > lds_max - lo.fixed - mirror) ring = lds_max - lo.fixed - mirror;
     ring = ring / 4096 * 4096;
     if (ring < 32 * 1024) ring = 32 * 1024;
-    rg->lds = lo.fixed + ring + mirror;
-    if (hipFuncSetAttribute((const void *) g_ring_variants[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rg->lds) != hipSuccess) { delete rg; return nullptr; }
+    rs->lds = lo.fixed + ring + mirror; rs->ring = ring; rs->mirror = mirror;
+    if (hipFuncSetAttribute((const void *) g_ring_variants[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rs->lds) != hipSuccess) { delete rs; return nullptr; }
     // the head behind the last layer: F16 head.weight of a stage that owns it, rows divisible into 16-row groups per workgroup
     const bool fold_head = m.has_head && m.head && m.head->type == T_F16 && m.head->cols() == D && m.n_vocab() % (RG_NBLK * 16) == 0 && m.ln_out_w && m.ln_out_b
                            && !(getenv("RWKV_MI_RING_NO_HEAD") && getenv("RWKV_MI_RING_NO_HEAD")[0] == '1');
-    rg->head = fold_head;
+    rs->head = fold_head;
     // per-workgroup streams
     std::vector<R6Cu> hc(RG_NBLK);
     uint64_t total = 0;
@@ -1571,19 +1580,24 @@ void * ring_v6_create(const Model & m) {
         int nr = 0; for (int ph = 0; ph < RG_NPHASE; ph++) nr += (int) cu.n[ph];
         max_rec = nr > max_rec ? nr : max_rec;
         const uint64_t bytes = (uint64_t) cu.layer_bytes * n_layers;
-        if (bytes + (1u << 20) > 0xFFFFFFFFull) { delete rg; return nullptr; }   // stream positions are 32-bit
+        if (bytes + (1u << 20) > 0xFFFFFFFFull) { delete rs; return nullptr; }   // stream positions are 32-bit
         const uint64_t hbytes = fold_head ? rg_head((int) m.n_vocab(), (int) D).bytes : 0;
-        if (bytes + hbytes + (1u << 20) > 0xFFFFFFFFull) { delete rg; return nullptr; }
+        if (bytes + hbytes + (1u << 20) > 0xFFFFFFFFull) { delete rs; return nullptr; }
         hc[b].base = total; hc[b].chunks = (unsigned) ((bytes + 4 * RG_CHUNK - 1) / (4 * RG_CHUNK)) * 4u;
         hc[b].chunks_head = (unsigned) ((bytes + hbytes + 4 * RG_CHUNK - 1) / (4 * RG_CHUNK)) * 4u; hc[b].layer_bytes = cu.layer_bytes; hc[b].pad = 0;
         total += (uint64_t) hc[b].chunks_head * RG_CHUNK;
     }
     const size_t w2_layer = (size_t) 5 * R * D;
-    bool ok = R % 4 == 0 && hipMalloc((void **) &rg->w2b, w2_layer * n_layers * sizeof(float)) == hipSuccess
-           && hipMalloc((void **) &rg->stream, total + 4 * RG_CHUNK) == hipSuccess
-           && hipMalloc((void **) &rg->d_cus, hc.size() * sizeof(R6Cu)) == hipSuccess
-           && hipMemcpy(rg->d_cus, hc.data(), hc.size() * sizeof(R6Cu), hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) { ring_v6_destroy(rg); return nullptr; }
+    bool ok = R % 4 == 0 && hipMalloc((void **) &rs->w2b, w2_layer * n_layers * sizeof(float)) == hipSuccess
+           && hipMalloc((void **) &rs->stream, total + 4 * RG_CHUNK) == hipSuccess
+           && hipMalloc((void **) &rs->d_cus, hc.size() * sizeof(R6Cu)) == hipSuccess
+           && hipMemcpy(rs->d_cus, hc.data(), hc.size() * sizeof(R6Cu), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        (void) hipGetLastError();
+        fprintf(stderr, "librwkv: no room for the ring kernel's weight streams (%.2f GB): this model continues on the per-layer launches\n", (double) total / 1e9);
+        ring_shared_free(rs);
+        return nullptr;
+    }
     std::vector<M6Layer> hl;
     const unsigned char * abase = (const unsigned char *) m.arena;
     bool in_arena = true;
@@ -1608,9 +1622,9 @@ void * ring_v6_create(const Model & m) {
         d.dw1 = pl3(L.att_time_decay_w1); d.dw2 = pl3(L.att_time_decay_w2); d.wo = pl3(L.att_output);
         d.fk = pl3(L.ffn_key); d.fr = pl3(L.ffn_receptance); d.fv = pl3(L.ffn_value);
         if (!in_arena) break;
-        hipLaunchKernelGGL(k_block_w2_ring, dim3(512), dim3(256), 0, 0, (const float *) L.att_time_maa_w2->data, rg->w2b + hl.size() * w2_layer, (int) D, (int) R);
+        hipLaunchKernelGGL(k_block_w2_ring, dim3(512), dim3(256), 0, 0, (const float *) L.att_time_maa_w2->data, rs->w2b + hl.size() * w2_layer, (int) D, (int) R);
         PackMat pm; pm.w1 = d.w1; pm.dw1 = d.dw1; for (int q = 0; q < 4; q++) pm.rkvg[q] = d.rkvg[q]; pm.wo = d.wo; pm.fk = d.fk; pm.fr = d.fr; pm.fv = d.fv;
-        hipLaunchKernelGGL(k_ring_pack, dim3((unsigned) max_rec, RG_NBLK), dim3(64), 0, 0, abase, pm, sh, rg->d_cus, rg->stream, (int) hl.size(), max_rec);
+        hipLaunchKernelGGL(k_ring_pack, dim3((unsigned) max_rec, RG_NBLK), dim3(64), 0, 0, abase, pm, sh, rs->d_cus, rs->stream, (int) hl.size(), max_rec);
         hl.push_back(d);
         const DevTensor * all[] = {L.ln1_w, L.ln1_b, L.att_time_maa_x, L.att_time_maa_w, L.att_time_maa_k, L.att_time_maa_v, L.att_time_maa_r, L.att_time_maa_g,
                                    L.att_time_maa_w1, L.att_time_maa_w2, L.att_time_decay, L.att_time_faaaa, L.att_time_decay_w1, L.att_time_decay_w2,
@@ -1619,16 +1633,56 @@ void * ring_v6_create(const Model & m) {
         for (const DevTensor * t : all) if (t) bytes += t->nbytes;
         bytes += 2 * (uint64_t) m.state_per_layer() * sizeof(float);
     }
-    rg->bytes = bytes;
-    long long lnw_off = 0, lnb_off = 0;
+    rs->bytes = bytes;
     if (fold_head && in_arena) {
-        lnw_off = off(m.ln_out_w->data); lnb_off = off(m.ln_out_b->data);
+        rs->lnw_off = off(m.ln_out_w->data); rs->lnb_off = off(m.ln_out_b->data);
         const RingHead hd = rg_head((int) m.n_vocab(), (int) D);
         hipLaunchKernelGGL(k_ring_pack_head, dim3((unsigned) (hd.hg * hd.chunks), RG_NBLK), dim3(64), 0, 0, (const unsigned short *) m.head->data, (int) m.n_vocab(), (int) D,
-                           rg->d_cus, rg->stream, n_layers);
-        rg->bytes_head = m.head->nbytes + m.ln_out_w->nbytes + m.ln_out_b->nbytes + (uint64_t) m.n_vocab() * 4;
+                           rs->d_cus, rs->stream, n_layers);
+        rs->bytes_head = m.head->nbytes + m.ln_out_w->nbytes + m.ln_out_b->nbytes + (uint64_t) m.n_vocab() * 4;
     }
-    if (!in_arena) { ring_v6_destroy(rg); return nullptr; }
+    ok = in_arena && hipMalloc((void **) &rs->d_layers, hl.size() * sizeof(M6Layer)) == hipSuccess
+      && hipMemcpy(rs->d_layers, hl.data(), hl.size() * sizeof(M6Layer), hipMemcpyHostToDevice) == hipSuccess
+      && hipDeviceSynchronize() == hipSuccess;
+    if (!ok) { ring_shared_free(rs); return nullptr; }
+    return rs;
+}
+
+static RingShared * ring_shared_acquire(const Model & m) {
+    std::lock_guard<std::mutex> lk(m.derived_mu);
+    RingShared * rs = (RingShared *) m.ring_shared;
+    if (!rs) { rs = ring_shared_build(m); m.ring_shared = rs; }
+    if (rs) rs->ref++;
+    return rs;
+}
+static void ring_shared_release(const Model & m, RingShared * rs) {
+    if (!rs) return;
+    std::lock_guard<std::mutex> lk(m.derived_mu);
+    if (--rs->ref > 0) return;
+    if (m.ring_shared == rs) m.ring_shared = nullptr;
+    ring_shared_free(rs);
+}
+
+void ring_v6_destroy(void * h) {
+    RingV6 * rg = (RingV6 *) h;
+    if (!rg) return;
+    if (rg->xch) (void) hipFree(rg->xch);
+    if (rg->ctl) (void) hipFree(rg->ctl);
+    if (rg->h_ctl) (void) hipHostFree(rg->h_ctl);
+    if (rg->trace) (void) hipFree(rg->trace);
+    if (rg->model) ring_shared_release(*rg->model, rg->sh);
+    delete rg;
+}
+
+// Returns nullptr when the model / device does not qualify (the caller tries the register-prefetch kernel, then the seven launches).
+// Per context: the exchange arena, the control words, the trace buffer. Everything derived from the weights is shared (RingShared).
+void * ring_v6_create(const Model & m) {
+    RingShared * rs = ring_shared_acquire(m);
+    if (!rs) return nullptr;
+    RingV6 * rg = new RingV6();
+    rg->model = &m; rg->sh = rs;
+    const int64_t D = rs->D, F = rs->F;
+    const int NB = rs->n_blocks;
     const int64_t nbD = D / 32, nbF = F / 32;
     const int64_t PAD = 2048;   // polls read whole rounds of 7 x 64 lanes: keep every buffer readable past its end
     auto up = [](int64_t v) { return (v + 63) / 64 * 64; };
@@ -1636,9 +1690,7 @@ void * ring_v6_create(const Model & m) {
     const int64_t sizes[8] = {up(1280) + PAD, 5 * act_stride + PAD, 2 * D + PAD, 256 + PAD, act_stride + PAD, xunits + PAD, up(3 * nbF) + PAD, xunits + PAD};
     int64_t units = 0;
     for (int64_t z : sizes) units += z;
-    ok = hipMalloc((void **) &rg->d_layers, hl.size() * sizeof(M6Layer)) == hipSuccess
-      && hipMemcpy(rg->d_layers, hl.data(), hl.size() * sizeof(M6Layer), hipMemcpyHostToDevice) == hipSuccess
-      && hipMalloc(&rg->xch, (size_t) units * 16) == hipSuccess && hipMemset(rg->xch, 0, (size_t) units * 16) == hipSuccess
+    bool ok = hipMalloc(&rg->xch, (size_t) units * 16) == hipSuccess && hipMemset(rg->xch, 0, (size_t) units * 16) == hipSuccess
       && hipMalloc((void **) &rg->ctl, 256) == hipSuccess
       && hipHostMalloc((void **) &rg->h_ctl, 64, hipHostMallocDefault) == hipSuccess;
     if (ok) { rg->h_ctl[0] = 8u; rg->h_ctl[1] = 0u; }
@@ -1646,8 +1698,8 @@ void * ring_v6_create(const Model & m) {
     ok = ok && hipMemcpy(rg->ctl, init, sizeof(init), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok || hipDeviceSynchronize() != hipSuccess) { ring_v6_destroy(rg); return nullptr; }
     R6P & q = rg->proto;
-    q.layers = rg->d_layers; q.n_layers = (int) hl.size();
-    q.arena = abase; q.w2b = rg->w2b;
+    q.layers = rs->d_layers; q.n_layers = rs->n_layers;
+    q.arena = (const unsigned char *) m.arena; q.w2b = rs->w2b;
     q.state_stride = m.state_per_layer();
     q.xch = rg->xch; q.xch_bytes = (unsigned) (units * 16);
     int u = 0;
@@ -1655,15 +1707,15 @@ void * ring_v6_create(const Model & m) {
     for (int i = 0; i < 8; i++) { *slots[i] = u; u += (int) sizes[i]; }
     q.act_stride = (int) act_stride;
     q.ctl = rg->ctl;
-    q.stream = rg->stream; q.cus = rg->d_cus;
-    q.F = (int) F; q.DR = (int) DR; q.R = (int) R; q.H = (int) m.head_count;
-    q.ring_bytes = (unsigned) ring; q.mirror_bytes = (unsigned) mirror;
+    q.stream = rs->stream; q.cus = rs->d_cus;
+    q.F = (int) F; q.DR = (int) rs->DR; q.R = (int) rs->R; q.H = (int) m.head_count;
+    q.ring_bytes = (unsigned) rs->ring; q.mirror_bytes = (unsigned) rs->mirror;
     // on the workgroups of the value matrix: their r/k/v/g phase is the shortest (no decay row, 5.0 us against 5.8 - 6.4 us), and the
     // hand-over behind that phase waits for the slowest workgroup -- which the head's state loads and polls made the receptance ones
     // (same-box A/B: +0.7 %)
     q.head_wg0 = env_int("RWKV_MI_RING_HEAD_WG", NB / 2);
     if (q.head_wg0 < 0 || q.head_wg0 + (int) m.head_count > NB) q.head_wg0 = 0;
-    q.logits = nullptr; q.lnout_w = lnw_off; q.lnout_b = lnb_off; q.n_vocab = (int) m.n_vocab();
+    q.logits = nullptr; q.lnout_w = rs->lnw_off; q.lnout_b = rs->lnb_off; q.n_vocab = (int) m.n_vocab();
     auto snap = [](int w) { w &= ~3; return w < 4 ? 4 : (w > 52 ? 52 : w); };
     q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 48));
     q.thin = snap(env_int("RWKV_MI_RING_THIN", 16));
@@ -1677,7 +1729,7 @@ void * ring_v6_create(const Model & m) {
 
 bool ring_v6_trace(void * h, int layer, long long * out, bool fetch) {
     RingV6 * rg = (RingV6 *) h;
-    const size_t n = (size_t) rg->n_blocks * 8 * 32, extra = 2 * 512 * 4;   // (+ the loader's round samples of two workgroups)
+    const size_t n = (size_t) rg->sh->n_blocks * 8 * 32, extra = 2 * 512 * 4;   // (+ the loader's round samples of two workgroups)
     if (!rg->trace) { if (hipMalloc((void **) &rg->trace, (n + extra) * 8) != hipSuccess) return false; (void) hipMemset(rg->trace, 0, (n + extra) * 8); }
     rg->proto.trace = rg->trace; rg->proto.trace_layer = layer;
     if (fetch) {
@@ -1692,28 +1744,28 @@ bool ring_v6_trace(void * h, int layer, long long * out, bool fetch) {
     return true;
 }
 
-uint64_t ring_v6_bytes(void * h) { return ((RingV6 *) h)->bytes; }
+uint64_t ring_v6_bytes(void * h) { return ((RingV6 *) h)->sh->bytes; }
 
-bool ring_v6_folds_head(void * h) { return ((RingV6 *) h)->head; }
+bool ring_v6_folds_head(void * h) { return ((RingV6 *) h)->sh->head; }
 
 // logits != nullptr (only when ring_v6_folds_head): ln_out + head run inside the launch and the logits land there
 void ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits) {
     RingV6 * rg = (RingV6 *) h;
     R6P q = rg->proto;
     q.x = x; q.sin = sin; q.sout = sout;
-    q.logits = rg->head ? logits : nullptr;
-    const RingKernel fn = g_ring_variants[rg->variant].fn;
+    q.logits = rg->sh->head ? logits : nullptr;
+    const RingKernel fn = g_ring_variants[rg->sh->variant].fn;
     if (pf && pf->on) {
         if (pf->used * 2 + 2 > pf->events.size()) {
             hipEvent_t a = nullptr, c = nullptr;
             (void) hipEventCreate(&a); (void) hipEventCreate(&c);
             pf->events.push_back(a); pf->events.push_back(c); pf->bytes.push_back(0);
         }
-        pf->bytes[pf->used] = rg->bytes + (q.logits ? rg->bytes_head : 0);
-        hipExtLaunchKernelGGL(fn, dim3((unsigned) rg->n_blocks), dim3(512), (uint32_t) rg->lds, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, q);
+        pf->bytes[pf->used] = rg->sh->bytes + (q.logits ? rg->sh->bytes_head : 0);
+        hipExtLaunchKernelGGL(fn, dim3((unsigned) rg->sh->n_blocks), dim3(512), (uint32_t) rg->sh->lds, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, q);
         pf->used++;
     } else {
-        hipLaunchKernelGGL(fn, dim3((unsigned) rg->n_blocks), dim3(512), rg->lds, st, q);
+        hipLaunchKernelGGL(fn, dim3((unsigned) rg->sh->n_blocks), dim3(512), rg->sh->lds, st, q);
     }
 }
 
@@ -1722,6 +1774,7 @@ bool ring_v6_ctl_fetch(void * h, hipStream_t st) {
     return hipMemcpyAsync(rg->h_ctl, rg->ctl, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess;
 }
 bool ring_v6_aborted_cached(void * h) { return ((RingV6 *) h)->h_ctl[1] != 0; }
+unsigned ring_v6_generation_cached(void * h) { return ((RingV6 *) h)->h_ctl[0]; }
 bool ring_v6_clear_abort(void * h, hipStream_t st) {
     RingV6 * rg = (RingV6 *) h;
     rg->h_ctl[1] = 0u;

@@ -33,17 +33,22 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 struct Hop {
     virtual ~Hop() {}
-    // message of decode stream j; both calls only enqueue. The sender's call for a message is made before the receiver's.
-    virtual bool send(int j, const void * src, size_t bytes, hipStream_t st) = 0;   // current device = the sender's
-    virtual bool recv(int j, void * dst, size_t bytes, hipStream_t st) = 0;         // current device = the receiver's
+    // message `msg` (0: the residual stream / the token, 1: RWKV-7's v_first) of decode stream j; both calls only enqueue. The sender's
+    // call for a message is made before the receiver's.
+    virtual bool send(int j, int msg, const void * src, size_t bytes, hipStream_t st) = 0;   // current device = the sender's
+    virtual bool recv(int j, int msg, void * dst, size_t bytes, hipStream_t st) = 0;         // current device = the receiver's
 };
+constexpr int k_hop_msgs = 2;
 
 struct LocalHop : Hop {
     int src_dev, dst_dev;
     struct Slot { void * box = nullptr; hipEvent_t ready = nullptr, taken = nullptr; bool used = false; };
-    std::vector<Slot> slots;
+    // One mailbox and one event pair PER MESSAGE of a stream's iteration: a stage of an RWKV-7 chain sends x and then v_first. Through
+    // one box the second send only waited for the previous ITERATION's `taken` and overwrote x before the receiver had run -- both
+    // receives then read v_first (round-3 review; tests/test_gpu_pipeline_cpp.py::test_rwkv7_greedy_loop_through_a_chain).
+    std::vector<Slot> slots;   // [stream][message]
     size_t cap;
-    LocalHop(int sdev, int ddev, int n_streams, size_t bytes, bool & ok) : src_dev(sdev), dst_dev(ddev), slots((size_t) n_streams), cap(bytes) {
+    LocalHop(int sdev, int ddev, int n_streams, size_t bytes, bool & ok) : src_dev(sdev), dst_dev(ddev), slots((size_t) n_streams * k_hop_msgs), cap(bytes) {
         ok = hipSetDevice(ddev) == hipSuccess;
         for (Slot & s : slots) {
             ok = ok && hipMalloc(&s.box, bytes) == hipSuccess;
@@ -58,17 +63,18 @@ struct LocalHop : Hop {
             if (s.taken) (void) hipEventDestroy(s.taken);
         }
     }
-    bool send(int j, const void * src, size_t bytes, hipStream_t st) override {
-        Slot & s = slots[(size_t) j];
-        if (bytes > cap) return false;
+    bool send(int j, int msg, const void * src, size_t bytes, hipStream_t st) override {
+        if (msg < 0 || msg >= k_hop_msgs || bytes > cap) return false;
+        Slot & s = slots[(size_t) j * k_hop_msgs + (size_t) msg];
         if (s.used && hipStreamWaitEvent(st, s.taken, 0) != hipSuccess) return false;   // the previous message has left the mailbox
         if (hipMemcpyPeerAsync(s.box, dst_dev, src, src_dev, bytes, st) != hipSuccess) return false;
         s.used = true;
         return hipEventRecord(s.ready, st) == hipSuccess;
     }
-    bool recv(int j, void * dst, size_t bytes, hipStream_t st) override {
-        Slot & s = slots[(size_t) j];
-        if (!s.used || bytes > cap) return false;
+    bool recv(int j, int msg, void * dst, size_t bytes, hipStream_t st) override {
+        if (msg < 0 || msg >= k_hop_msgs || bytes > cap) return false;
+        Slot & s = slots[(size_t) j * k_hop_msgs + (size_t) msg];
+        if (!s.used) return false;
         if (hipStreamWaitEvent(st, s.ready, 0) != hipSuccess) return false;
         if (hipMemcpyAsync(dst, s.box, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
         return hipEventRecord(s.taken, st) == hipSuccess;
@@ -128,14 +134,14 @@ struct RcclHop : Hop {
         if (ev_a) (void) hipEventDestroy(ev_a);
         if (ev_b) (void) hipEventDestroy(ev_b);
     }
-    bool send(int, const void * src, size_t bytes, hipStream_t st) override {
+    bool send(int, int, const void * src, size_t bytes, hipStream_t st) override {   // (point-to-point calls of one communicator and stream are ordered: no mailbox)
         Rccl & r = rccl();
         if (!side) return r.Send(src, bytes, k_nccl_uint8, peer, comm, st) == 0;
         // behind the producer of src; the stage's stream does not wait for the transfer (src is next written a whole round trip later)
         if (hipEventRecord(ev_a, st) != hipSuccess || hipStreamWaitEvent(own, ev_a, 0) != hipSuccess) return false;
         return r.Send(src, bytes, k_nccl_uint8, peer, comm, own) == 0;
     }
-    bool recv(int, void * dst, size_t bytes, hipStream_t st) override {
+    bool recv(int, int, void * dst, size_t bytes, hipStream_t st) override {
         Rccl & r = rccl();
         if (!side) return r.Recv(dst, bytes, k_nccl_uint8, peer, comm, st) == 0;
         // not before the stage's stream has reached this point (dst is still read by what is queued ahead; and a receive that sits on
@@ -167,10 +173,10 @@ bool stage_iteration(StagePart & p, rwkv_context * err, size_t t, int j) {
     auto fail = [&]() { err->last_error |= c->last_error ? c->last_error : (int) RWKV_ERROR_GRAPH; return false; };
     if (hipSetDevice(m.device) != hipSuccess || !ensure_scratch(c, 1)) return fail();
     if (m.has_embed) {
-        if (t > 0 && p.tok_in && !p.tok_in->recv(j, c->d_tokens, sizeof(uint32_t), c->stream)) return fail();
+        if (t > 0 && p.tok_in && !p.tok_in->recv(j, 0, c->d_tokens, sizeof(uint32_t), c->stream)) return fail();
     } else {
-        if (!p.in || !p.in->recv(j, c->b.x, D * sizeof(float), c->stream)) return fail();
-        if (m.arch_major == 7 && !p.in->recv(j, c->b.v_first, D * sizeof(float), c->stream)) return fail();
+        if (!p.in || !p.in->recv(j, 0, c->b.x, D * sizeof(float), c->stream)) return fail();
+        if (m.arch_major == 7 && !p.in->recv(j, 1, c->b.v_first, D * sizeof(float), c->stream)) return fail();
     }
     if (!forward_decode(c, m.has_head)) return fail();
     if (m.has_head) {
@@ -178,10 +184,10 @@ bool stage_iteration(StagePart & p, rwkv_context * err, size_t t, int j) {
         uint32_t * dst = m.has_embed ? c->d_tokens : c->d_next_token;
         launch_argmax(c->d_logits, m.n_vocab(), dst, c->stream);
         if (hipMemcpyAsync(p.d_hist + (size_t) j * p.n_tokens + t, dst, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail();
-        if (p.tok_out && t + 1 < p.n_tokens && !p.tok_out->send(j, dst, sizeof(uint32_t), c->stream)) return fail();
+        if (p.tok_out && t + 1 < p.n_tokens && !p.tok_out->send(j, 0, dst, sizeof(uint32_t), c->stream)) return fail();
     } else {
-        if (!p.out || !p.out->send(j, c->b.x, D * sizeof(float), c->stream)) return fail();
-        if (m.arch_major == 7 && !p.out->send(j, c->b.v_first, D * sizeof(float), c->stream)) return fail();
+        if (!p.out || !p.out->send(j, 0, c->b.x, D * sizeof(float), c->stream)) return fail();
+        if (m.arch_major == 7 && !p.out->send(j, 1, c->b.v_first, D * sizeof(float), c->stream)) return fail();
     }
     return true;
 }
@@ -227,6 +233,8 @@ bool pipeline_decode_greedy(rwkv_context * const * fronts, size_t n_streams, con
             RW_CTX_CHECK(f0, RWKV_ERROR_ARGS, false, a.device == b.device && a.layer_begin == b.layer_begin && a.layer_end == b.layer_end, "decode stream %zu is not a clone of stream 0", j);
         }
         RW_CTX_CHECK(f0, RWKV_ERROR_ARGS, false, first_tokens[j] < (uint32_t) f0->model->n_vocab(), "Token of stream %zu is out of range", j);
+        // one recurrent state and one token buffer per context: the same context twice would interleave two streams on them
+        for (size_t i = 0; i < j; i++) RW_CTX_CHECK(f0, RWKV_ERROR_ARGS, false, fronts[i] != f, "decode streams %zu and %zu are the same context", i, j);
     }
     int prev_dev = 0;
     (void) hipGetDevice(&prev_dev);

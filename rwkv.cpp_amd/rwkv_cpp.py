@@ -17,6 +17,8 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # RWKV_LIB_DIR selects an alternative in-tree build directory (A/B variants built with `make LIBDIR=... OBJDIR=... EXTRA=-D...`)
 LIB_PATH = os.path.join(PKG_DIR, os.environ.get("RWKV_LIB_DIR", "lib"), "librwkv.so")
+# tests/ only: the same objects + csrc/testhooks.cpp (include/rwkv_testhooks.h); the product library does not export test entry points
+HOOKS_LIB_PATH = os.path.join(PKG_DIR, os.environ.get("RWKV_LIB_DIR", "lib"), "librwkv_testhooks.so")
 
 QUANTIZED_FORMAT_NAMES = ("Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0")
 P_FLOAT = ctypes.POINTER(ctypes.c_float)
@@ -123,8 +125,11 @@ class RWKVSharedLibrary:
         L.rwkv_mi_sample.restype = ctypes.c_bool
         L.rwkv_mi_decode_sample.argtypes = [c_ctx, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, P_UINT32, P_FLOAT]
         L.rwkv_mi_decode_sample.restype = ctypes.c_bool
-        L.rwkv_mi_test_set_tag.argtypes = [c_ctx, ctypes.c_uint32]
-        L.rwkv_mi_test_set_tag.restype = ctypes.c_bool
+        L.rwkv_mi_decode_generation.argtypes = [c_ctx]
+        L.rwkv_mi_decode_generation.restype = ctypes.c_uint32
+        if hasattr(L, "rwkv_mi_test_set_tag"):   # (librwkv_testhooks.so only)
+            L.rwkv_mi_test_set_tag.argtypes = [c_ctx, ctypes.c_uint32]
+            L.rwkv_mi_test_set_tag.restype = ctypes.c_bool
         # the C++ decode loop of a pipeline (runner.cpp)
         L.rwkv_mi_decode_greedy_streams.argtypes = [ctypes.POINTER(c_ctx), ctypes.c_size_t, P_UINT32, ctypes.c_size_t, P_UINT32, P_FLOAT]
         L.rwkv_mi_decode_greedy_streams.restype = ctypes.c_bool
@@ -405,8 +410,12 @@ class RWKVModel:
     def healthy(self) -> bool:
         return bool(self._library.library.rwkv_mi_decode_healthy(self._ctx.ptr))
 
+    def decode_generation(self) -> int:
+        """Hand-over generation the persistent kernel's next launch starts from (advances 8 per layer and launch; 0: path 2 is off)."""
+        return int(self._library.library.rwkv_mi_decode_generation(self._ctx.ptr))
+
     def test_set_tag(self, base: int) -> bool:
-        """Test hook: presets the persistent kernel's rolling hand-over tag (see include/rwkv_mi355x.h)."""
+        """Test hook (a model opened through librwkv_testhooks.so only): presets the persistent kernel's rolling hand-over tag."""
         return bool(self._library.library.rwkv_mi_test_set_tag(self._ctx.ptr, base & 0xFFFFFFFF))
 
     def clone(self, thread_count: int = 1) -> "RWKVModel":

@@ -55,6 +55,14 @@ CONFIGS = {
     "mega-v6-2048-v8k": ModelSpec("6", 3, 2048, 8192, 7168, 64, 32, 64, name="mega-v6-2048-v8k"),
     "mega-v6-2048-v32k": ModelSpec("6", 2, 2048, 32768, 7168, 64, 32, 64, name="mega-v6-2048-v32k"),
     "test-v7": ModelSpec("7", 3, 256, 512, 1024, 64, v7_rank_w=64, v7_rank_a=64, v7_rank_v=32, v7_rank_g=96, name="test-v7"),
+    # two-layer slices of the BASELINE configurations C4 / C2 at their REAL row lengths, ranks and vocabulary (tests/test_gpu_real_geometry.py):
+    # RWKV-7-World-2.9B (D 2560: 80 blocks per row, ranks 96 / 96 / 64 / 320) and RWKV-4-Pile-169M (D 768, V 50277: a multiple of nothing)
+    "slice-v7-2560": ModelSpec("7", 2, 2560, 4096, 10240, 64, v7_rank_w=96, v7_rank_a=96, v7_rank_v=64, v7_rank_g=320, name="slice-v7-2560"),
+    "slice-v4-768": ModelSpec("4", 2, 768, 50277, 3072, name="slice-v4-768"),
+    # the World vocabulary on the ring kernel's folded head: 65536 rows = 16 sixteen-row groups per workgroup = three passes of the six consumers
+    "mega-v6-2048-v64k": ModelSpec("6", 1, 2048, 65536, 7168, 64, 32, 64, name="mega-v6-2048-v64k"),
+    # RWKV-6-World-3B geometry (D 2560, F 8960, mix rank 32, decay rank 64)
+    "mega-v6-2560": ModelSpec("6", 2, 2560, 4096, 8960, 64, 32, 64, name="mega-v6-2560"),
 }
 
 

@@ -34,6 +34,28 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
 
 
+def _dynamic_symbols(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_product_library_exports_the_declared_surface_and_nothing_else():
+    """A drop-in exports the reference's rwkv.h symbols + the declared rwkv_mi_* extensions: no kernel host stubs (_ZN6rwkvmi...), no
+    engine internals, no test entry points (csrc/rwkv.map; round-3 review). The test entry points live in librwkv_testhooks.so."""
+    library()
+    declared = set(_declared_symbols())
+    exported = _dynamic_symbols(pkg.LIB_PATH)
+    assert exported, "nm found no dynamic symbols"
+    assert set(exported) == declared, (sorted(set(exported) - declared), sorted(declared - set(exported)))
+    assert not any(n.startswith("rwkv_mi_test_") for n in exported)
+    text = open(os.path.join(ROOT, "include", "rwkv_testhooks.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    hooks = set(re.findall(r"RWKV_API[^;(]*?\b(rwkv_\w+)\s*\(", text))
+    assert len(hooks) == 4
+    assert set(_dynamic_symbols(pkg.HOOKS_LIB_PATH)) == declared | hooks
+
+
 def test_library_contains_gfx950_code_objects():
     blob = open(pkg.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"k_mvq_t1" in blob

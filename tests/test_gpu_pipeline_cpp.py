@@ -177,3 +177,45 @@ def test_native_stage_runner_on_one_rank(tmp_path):
     assert comm
     L.rwkv_mi_comm_free(ctypes.c_void_p(comm))
     one.free()
+
+
+@pytest.mark.parametrize("devices", ["0,0,0", "0,0"])
+def test_rwkv7_greedy_loop_through_a_chain(tmp_path, devices):
+    """An RWKV-7 stage hands over TWO vectors per iteration, x and v_first. Round 3 sent both through one mailbox of the hop: the second
+    send overwrote the first before the receiver had run, and every later stage computed with x == v_first -- silently wrong tokens
+    from rwkv_mi_decode_greedy / rwkv_mi_decode_greedy_streams on a RWKV_MI_DEVICES chain. Every message has its own mailbox now
+    (runner.cpp LocalHop): single stream and two interleaved streams against the one-device context and the oracle."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS["test-v7"]
+    synth.write_model(p, spec, "Q5_1", seed=53)
+    om = O.OracleModel(p)
+    ost, tok, ref = om.init_state(), 7, []
+    for _ in range(20):
+        ol, ost = om.eval(tok, ost)
+        tok = int(np.argmax(ol))
+        ref.append(tok)
+    pm = _pipeline_model(p, devices)
+    pm.state_load(None)
+    got, _ = pm.decode_greedy(7, 20)
+    assert list(got) == ref
+    assert np.array_equal(pm.state_store(), ost)
+    one = model(p)
+    clones = [pm, pm.clone()]
+    firsts = [7, 300]
+    for m in clones:
+        m.state_load(None)
+    toks, _ = type(pm).decode_greedy_streams(clones, firsts, 20)
+    for j, f in enumerate(firsts):
+        one.state_load(None)
+        r, _ = one.decode_greedy(f, 20)
+        assert list(toks[j]) == list(r), j
+        assert np.array_equal(clones[j].state_store(), one.state_store()), j
+    assert list(toks[0]) == ref
+    # the same context twice is an argument error, not two streams interleaved on one state
+    with pytest.raises(ValueError):
+        type(pm).decode_greedy_streams([pm, pm], firsts, 4)
+    clones[1].free()
+    one.free()
+    pm.free()
+    om.free()
