@@ -349,11 +349,60 @@ def bench_prefill(args, pkg, lib, path, spec, torch):
         ol, ost = om.eval_sequence(prompt[:n], om.init_state())
         cpu_s = time.time() - t0
         om.free()
+        # Two arms for F16 matrices in sequence mode (csrc/kernels.hip): the exact one (k_mvf, ggml's addition order: bit for bit) and the
+        # timed default (k_mmf16_seq on the matrix cores: same operand rounding, another addition order -> equal to rounding; only RWKV-7's
+        # F16 low-rank stages and FP16 files reach it). The exact arm must equal the oracle; the timed arm must be within the stated tolerance.
+        prev = os.environ.get("RWKV_MI_SEQ_F16")
+        os.environ["RWKV_MI_SEQ_F16"] = "valu"
         model.state_load(None)
         gl = model.eval_resident(prompt[:n], want_logits=True)
         gst = model.state_store()
-        equal = bool(np.array_equal(gl, ol) and np.array_equal(gst, ost))
-        result["parity"] = {"tokens_checked": n, "equal": equal, "what": "logits and state after the first tokens of the prompt, GPU sequence pass vs CPU oracle, bit for bit"}
+        exact = bool(np.array_equal(gl, ol) and np.array_equal(gst, ost))
+        if prev is None:
+            del os.environ["RWKV_MI_SEQ_F16"]
+        else:
+            os.environ["RWKV_MI_SEQ_F16"] = prev
+        model.state_load(None)
+        tl = model.eval_resident(prompt[:n], want_logits=True)
+        tst = model.state_store()
+        err_l, err_s = float(np.abs(tl - ol).max()), float(np.abs(tst - ost).max())
+        timed = {"bit_identical": bool(err_l == 0.0 and err_s == 0.0), "max_abs_logit_diff_full_model": err_l, "max_abs_state_diff_full_model": err_s}
+        timed_ok = True
+        if not timed["bit_identical"]:
+            # The matrix-core arm ran (F16 low-rank stages / FP16 file). Its products agree with the oracle's to rounding, but a 24 - 32-layer
+            # network of RANDOM weights amplifies any rounding difference (it is chaotic: 1e-7 grows to 1e-2 over 32 layers x 128 tokens), so
+            # the tolerance is checked where it means something: on a TWO-layer slice of the same geometry, same tokens -- exact arm bit for
+            # bit, timed arm within 1e-4 * (1 + max |oracle|) on logits and state (what tests/test_gpu_seq_f16.py asserts).
+            from rwkv_cpp_amd import synth as synth_mod
+            sp = os.path.join(args.model_dir, f"synthetic-{args.config}-{args.dtype}-slice2.bin")
+            synth_mod.write_model(sp, spec, args.dtype, seed=42, limit_layers=2)
+            som = oracle_lib.OracleModel(sp)
+            sol, sost = som.eval_sequence(prompt[:n], som.init_state())
+            som.free()
+            sm = pkg.RWKVModel(lib, sp, thread_count=1, gpu_layer_count=3)
+            sm.state_load(None)
+            sl = sm.eval_resident(prompt[:n], want_logits=True)
+            sst = sm.state_store()
+            os.environ["RWKV_MI_SEQ_F16"] = "valu"
+            sm.state_load(None)
+            xl = sm.eval_resident(prompt[:n], want_logits=True)
+            xst = sm.state_store()
+            if prev is None:
+                del os.environ["RWKV_MI_SEQ_F16"]
+            else:
+                os.environ["RWKV_MI_SEQ_F16"] = prev
+            sm.free()
+            os.remove(sp)
+            tol_l, tol_s = 1e-4 * (1.0 + float(np.abs(sol).max())), 1e-4 * (1.0 + float(np.abs(sost).max()))
+            e_l, e_s = float(np.abs(sl - sol).max()), float(np.abs(sst - sost).max())
+            timed_ok = bool(e_l <= tol_l and e_s <= tol_s and np.array_equal(xl, sol) and np.array_equal(xst, sost))
+            timed.update({"two_layer_slice": {"max_abs_logit_diff": e_l, "max_abs_state_diff": e_s, "tolerance_logits": tol_l, "tolerance_state": tol_s,
+                                              "exact_arm_bit_identical": bool(np.array_equal(xl, sol) and np.array_equal(xst, sost)), "within_tolerance": timed_ok}})
+        equal = exact and timed_ok
+        result["parity"] = {"tokens_checked": n, "equal": equal, "exact_arm_bit_identical": exact, "timed_arm": timed,
+                            "what": "logits and state after the first tokens of the prompt, GPU sequence pass vs CPU oracle: bit for bit on the exact arm "
+                                    "(RWKV_MI_SEQ_F16=valu); the timed default runs F16 matrices (RWKV-7 low-rank stages, FP16 files) on the matrix cores: "
+                                    "equal to rounding per product, checked within 1e-4 * (1 + max |oracle|) on a two-layer slice of the same geometry"}
         result["cpu_baseline"] = {"value": n / cpu_s, "unit": "tokens/s", "cores": usable_cores(), "kind": "port",
                                   "sample": f"{n}-token sequence pass of the same file on the host CPU ({cpu_s:.1f}s)"}
         if not equal:

@@ -263,7 +263,98 @@ static void launch_mvf_t(const DevTensor & W, const float * x, int64_t ldx, int6
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sequence mode, F16 weights: y[T][N] = epi(W[N][K] . fp16(x[T][K])) on the matrix cores (v_mfma_f32_32x32x16_f16).
+//
+// What it keeps of ggml's F16 product (rwkv_graph.inc:416-447 low-rank stages, :744-866 the sequential graph on an FP16 file): the
+// activations are rounded to fp16 first, every product is exact in f32, the sum is accumulated in f32. What it does NOT keep is the
+// ORDER of the additions (ggml: 32 partial sums k mod 32, each a chain of single FMAs; the matrix core adds eight products at a time
+// into one accumulator) -- so this path is not bit-identical to the single-token kernel / the CPU oracle, it agrees with them to
+// rounding: measured <= 3e-6 relative on the logits. The contract allows exactly that: the reference promises serial == sequence
+// bit for bit only for FP32 files (tests/test_eval_sequence_in_chunks.c:54 runs on an FP32 model) and validates FP16 against recorded
+// thresholds (tests/test_tiny_rwkv.c:38-54). FP32 matrices therefore stay on k_mvf (memcmp equality), F16 matrices take this kernel
+// from k_mfma_min_tokens tokens per pass on (RWKV_MI_SEQ_F16=valu keeps them on k_mvf: the bit-exact A/B arm of the tests).
+//
+// A workgroup = one tile of 32 weight rows x 64 tokens (two MFMA tiles sharing the weight operand), its four waves split K; operands go
+// straight from global memory / L2 into the MFMA operand registers (lane l: token or row l & 31, k = 8 (l >> 5) .. + 7 of the
+// 16-wide step: one 16-byte weight load and two 32-byte activation loads per lane and step): these products are short (K = 64 .. 320
+// for the second low-rank stages, N = 64 .. 320 for the first) and were 22 % of an RWKV-7 2.9B pass on the VALU kernel (62 of
+// 281 ms, round-3 review).
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 mf_h8 __attribute__((ext_vector_type(8)));
+typedef float mf_f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ mf_h8 mf_cvt8(const float4 a, const float4 b) {
+    mf_h8 h;
+    h[0] = (_Float16) a.x; h[1] = (_Float16) a.y; h[2] = (_Float16) a.z; h[3] = (_Float16) a.w;
+    h[4] = (_Float16) b.x; h[5] = (_Float16) b.y; h[6] = (_Float16) b.z; h[7] = (_Float16) b.w;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void k_mmf16_seq(const uint16_t * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x, int64_t ldx,
+                                                   int64_t T, float * __restrict__ y, int64_t ldy, Epi epi) {
+    __shared__ __attribute__((aligned(16))) float l_part[3][32][64];   // the partial tiles of waves 1..3: [wave][register][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const int64_t n0 = (int64_t) blockIdx.x * 32, t0 = (int64_t) blockIdx.y * 64;
+    const int64_t nrow = n0 + i < N ? n0 + i : N - 1;
+    const int64_t ta = t0 + i < T ? t0 + i : T - 1, tb = t0 + 32 + i < T ? t0 + 32 + i : T - 1;
+    // the four waves of a workgroup share ONE 32-row x 64-token tile and split K: the first low-rank stages have 64 .. 320 rows (2 .. 10
+    // row tiles) against 2560-long rows -- with one K range per tile 16 - 48 workgroups walked 160 dependent steps each and the product
+    // ran slower than on the VALU kernel; the partial tiles are added in wave order (deterministic)
+    const int64_t steps = K / 16;
+    const int64_t s_lo = steps * wave / 4, s_hi = steps * (wave + 1) / 4;
+    const uint16_t * wp = W + nrow * K + 8 * kh;
+    const float * xa = x + ta * ldx + 8 * kh, * xb = x + tb * ldx + 8 * kh;
+    mf_f16v acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+#pragma unroll 4
+    for (int64_t sidx = s_lo; sidx < s_hi; sidx++) {
+        const int64_t k0 = sidx * 16;
+        const int4 wraw = *reinterpret_cast<const int4 *>(wp + k0);
+        const float4 a0 = *reinterpret_cast<const float4 *>(xa + k0), a1 = *reinterpret_cast<const float4 *>(xa + k0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(xb + k0), b1 = *reinterpret_cast<const float4 *>(xb + k0 + 4);
+        mf_h8 wv;
+        __builtin_memcpy(&wv, &wraw, 16);
+        // D[token][row] += A[token][k] * B[k][row]: A = the activations (fp16-rounded here, round-to-nearest-even like ggml's fp32 -> fp16), B = the weights
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mf_cvt8(a0, a1), wv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mf_cvt8(b0, b1), wv, acc1, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { l_part[wave - 1][r][lane] = acc0[r]; l_part[wave - 1][16 + r][lane] = acc1[r]; }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] += l_part[w][r][lane]; acc1[r] += l_part[w][16 + r][lane]; }
+    // C / D layout: column (= weight row) lane & 31, row (= token) (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int64_t n = n0 + i;
+    if (n >= N) return;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int64_t tr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int64_t t1 = t0 + tr, t2 = t0 + 32 + tr;
+        if (t1 < T) y[t1 * ldy + n] = apply_epi(epi, acc0[r], t1, n, ldy);
+        if (t2 < T) y[t2 * ldy + n] = apply_epi(epi, acc1[r], t2, n, ldy);
+    }
+}
+
+static bool seq_f16_on_mfma() {   // (read per call: the test suite runs both arms in one process)
+    const char * e = getenv("RWKV_MI_SEQ_F16");
+    return !(e && e[0] == 'v');
+}
+
 void launch_matvec_f(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
+    if (W.type == T_F16 && T >= 32 && W.cols() % 16 == 0 && ldx % 4 == 0 && seq_f16_on_mfma()) {
+        const int64_t N = W.rows(), K = W.cols();
+        hipLaunchKernelGGL(k_mmf16_seq, dim3((unsigned) ((N + 31) / 32), (unsigned) ((T + 63) / 64)), dim3(256), 0, st,
+                           (const uint16_t *) W.data, N, K, x, ldx, T, y, ldy, epi);
+        return;
+    }
     if (W.type == T_F16) launch_mvf_t<true>(W, x, ldx, T, y, ldy, epi, st);
     else launch_mvf_t<false>(W, x, ldx, T, y, ldy, epi, st);
 }

@@ -45,6 +45,8 @@ struct R6P {
     int head_wg0;                                      // first of the H workgroups whose comm wave runs a WKV head
     unsigned ring_bytes, mirror_bytes;                 // LDS ring (multiple of 4 KiB) and how much of its head is repeated behind its end
     int inflight, thin;                                // loader: DMA instructions in flight (normal / while the workgroup gathers)
+    int look;                                          // consumers: records taken per look at a hand-over's sentinel (hint_take)
+    int hthin;                                         // ... while a wave of the workgroup watches a hand-over's sentinel (= inflight: no third level)
     int nap;                                           // extra 64-cycle sleeps between two looks at a gather's sentinel unit
     int burst;                                         // loader: fills issued per round (between two looks at the consumers' positions)
     int dbg;                                           // timing experiment: 8 = the loader alone (every other wave leaves at once; results are WRONG)
@@ -57,7 +59,8 @@ struct R6P {
 enum { FL_LANDED = 0, FL_SWB = 1, FL_SWE = 2 /* wide sweeps begun / ended (the loader keeps fewer fills in flight while they differ) */, FL_DONE = 4 /* [8], 16-byte aligned */, FL_GX = 12, FL_GACT = 13, FL_GYQ = 14, FL_GKQ = 15,
        FL_RED1 = 16, FL_RED2 = 17, FL_PRO = 18, FL_KEYS = 19,
        FL_HX = 20, FL_HACT = 21, FL_HYQ = 22, FL_HKQ = 23, FL_HTL = 24 /* "some wave saw its sentinel turn" per gather kind */,
-       FL_PROX = 25 /* consumer waves 4, 5 are done with their share of a prologue's elementwise part */, FL_WORDS = 32 };
+       FL_PROX = 25 /* consumer waves 4, 5 are done with their share of a prologue's elementwise part */,
+       FL_HWB = 26, FL_HWE = 27 /* sentinel watches begun / ended (p.hthin: the loader's depth while a wave of the workgroup watches a hand-over) */, FL_WORDS = 32 };
 
 struct R6Lds { size_t x, q1, q2, u, tl, bc, red, out, dl, misc, fl, ring, fixed; };
 __host__ __device__ inline R6Lds r6_lds(int D, int F) {
@@ -101,33 +104,76 @@ __device__ __forceinline__ void fl_wait(Poll & pl, unsigned * f, unsigned want) 
 // ---------------------------------------------------------------------------------------------------------------
 // ring records -> row sums
 // ---------------------------------------------------------------------------------------------------------------
-template <int FMT, int R, int U> struct RawRec { RawBlk<FMT> raw[U][R]; };
+// A record in registers. The buffers are read-modify-write operands of the inline-asm reads below ("+v"): a buffer is ONE virtual
+// register from rec_reserve() to its last use, whichever of its (conditional) loads ran. Through plain loads the compiler sees
+// phi(undef, record) chains over the hand-over wait loops, splits the live ranges around them and copies whole records (v_mov_b64
+// chains, then spills); tied operands leave it nothing to split.
+template <int FMT> struct RBlk { wv4i q[QF<FMT>::QS / 16]; unsigned qh, sc; };
+template <int FMT, int R, int U> struct RawRec { RBlk<FMT> raw[U][R]; };
+template <int FMT>
+__device__ __forceinline__ void to_raw(RawBlk<FMT> & o, const RBlk<FMT> & r) {
+    o.q[0] = make_int4(r.q[0].x, r.q[0].y, r.q[0].z, r.q[0].w);
+    if constexpr (QF<FMT>::QS == 32) o.q[1] = make_int4(r.q[1].x, r.q[1].y, r.q[1].z, r.q[1].w);
+    o.qh = r.qh; o.sc = r.sc;
+}
+template <int FMT>
+__device__ __forceinline__ void from_raw(RBlk<FMT> & o, const RawBlk<FMT> & r) {
+    o.q[0] = wv4i{r.q[0].x, r.q[0].y, r.q[0].z, r.q[0].w};
+    if constexpr (QF<FMT>::QS == 32) o.q[1] = wv4i{r.q[1].x, r.q[1].y, r.q[1].z, r.q[1].w};
+    o.qh = r.qh; o.sc = r.sc;
+}
+// start of a buffer's life (no instruction)
+template <int FMT, int R, int U>
+__device__ __forceinline__ void rec_reserve(RawRec<FMT, R, U> & w) {
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            RBlk<FMT> & o = w.raw[u][r];
+            asm volatile("" : "=v"(o.q[0]));
+            if constexpr (QF<FMT>::QS == 32) asm volatile("" : "=v"(o.q[1]));
+            asm volatile("" : "=v"(o.sc));
+            if constexpr (QF<FMT>::QH) asm volatile("" : "=v"(o.qh)); else o.qh = 0u;
+        }
+}
 
 // A record is read linearly from its ring offset: the first `mirror` bytes of the ring exist a second time right behind its end (the
 // loader fills both), so a record that starts near the end continues there -- no wrap arithmetic, every read an immediate offset from
-// one base register per access width.
+// one base register per access width. ring_lds = LDS address of the ring; the reads are in flight on return (rec_wait).
 template <int FMT, int R, int U>
-__device__ __forceinline__ void rec_load(RawRec<FMT, R, U> & w, const unsigned char * ring, unsigned off, int lane) {
+__device__ __forceinline__ void rec_load(RawRec<FMT, R, U> & w, unsigned ring_lds, unsigned off, int lane) {
     constexpr unsigned QS = QF<FMT>::QS, SCB = QF<FMT>::HM ? 4 : 2;
     constexpr unsigned SC0 = U * R * 64 * QS, QH0 = SC0 + U * R * 64 * SCB;
-    const int4 * b16 = reinterpret_cast<const int4 *>(ring + off) + lane;
-    const unsigned char * bsc = ring + off + SC0 + (unsigned) lane * SCB;
-    const uint32_t * bqh = reinterpret_cast<const uint32_t *>(ring + off + QH0) + lane;
+    const unsigned a16 = ring_lds + off + (unsigned) lane * 16u, asc = ring_lds + off + (unsigned) lane * SCB, aqh = ring_lds + off + (unsigned) lane * 4u;
 #pragma unroll
     for (int u = 0; u < U; u++) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            RawBlk<FMT> & o = w.raw[u][r];
-            constexpr int dummy = 0; (void) dummy;
-            const int c16 = (u * R + r) * (int) (QS / 16) * 64;
-            o.q[0] = b16[c16];
-            if constexpr (QS == 32) o.q[1] = b16[c16 + 64];
-            if constexpr (QF<FMT>::HM) o.sc = *reinterpret_cast<const uint32_t *>(bsc + (unsigned) (u * R + r) * 256u);
-            else o.sc = (unsigned) *reinterpret_cast<const uint16_t *>(bsc + (unsigned) (u * R + r) * 128u);
-            if constexpr (QF<FMT>::QH) o.qh = bqh[(u * R + r) * 64];
+            RBlk<FMT> & o = w.raw[u][r];
+            const unsigned k = (unsigned) (u * R + r);
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(o.q[0]) : "v"(a16), "n"(k * (QS / 16) * 1024u));
+            if constexpr (QS == 32) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(o.q[1]) : "v"(a16), "n"(k * 2048u + 1024u));
+            if constexpr (QF<FMT>::HM) asm volatile("ds_read_b32 %0, %1 offset:%2" : "+v"(o.sc) : "v"(asc), "n"(SC0 + k * 256u));
+            else asm volatile("ds_read_u16 %0, %1 offset:%2" : "+v"(o.sc) : "v"(asc), "n"(SC0 + k * 128u));
+            if constexpr (QF<FMT>::QH) asm volatile("ds_read_b32 %0, %1 offset:%2" : "+v"(o.qh) : "v"(aqh), "n"(QH0 + k * 256u));
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
+}
+// the reads of rec_load have returned (the compiler does not count inline-asm LDS operations: waited for by hand; every register of the
+// record passes through the statement, so no use can move above it)
+template <int FMT, int R, int U>
+__device__ __forceinline__ void rec_wait(RawRec<FMT, R, U> & w) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            RBlk<FMT> & o = w.raw[u][r];
+            asm volatile("" : "+v"(o.q[0]));
+            if constexpr (QF<FMT>::QS == 32) asm volatile("" : "+v"(o.q[1]));
+            asm volatile("" : "+v"(o.sc));
+            if constexpr (QF<FMT>::QH) asm volatile("" : "+v"(o.qh));
+        }
 }
 
 // The activation blocks a lane needs are the same for every record of a phase (block 64 u + lane of the image): read once per phase.
@@ -161,7 +207,7 @@ __device__ __forceinline__ void rec_acc(const RawRec<FMT, R, U> & w, const ActRe
 #pragma unroll
         for (int g = 0; g < GU; g++)
 #pragma unroll
-            for (int r = 0; r < R; r++) { if (u0 + g < U) unpack_raw<FMT>(wb[g][r], w.raw[u0 + g][r]); s0[g][r] = 0; s1[g][r] = 0; }
+            for (int r = 0; r < R; r++) { if (u0 + g < U) { RawBlk<FMT> rb; to_raw<FMT>(rb, w.raw[u0 + g][r]); unpack_raw<FMT>(wb[g][r], rb); } s0[g][r] = 0; s1[g][r] = 0; }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
 #pragma unroll
@@ -342,6 +388,10 @@ struct R6 {
     // A wave's wide sweep of a hand-over (after its sentinel turned) until the workgroup's gather is complete: the loader is thinned
     // for exactly that span -- its fills sit in the same memory pipe as the polls (row gather-pass). NOT while a wave merely watches a
     // sentinel: the comm wave reaches most gathers a whole row phase early, and a loader thinned through the row phases streams at half rate.
+    // ... and, as a third level (p.hthin, by default the normal depth), while a wave watches a sentinel: with the records of a phase taken
+    // into registers during these waits the loader streams through them, and a poll queues behind whatever the loader has in flight
+    static __device__ __forceinline__ void watch_begin(const Lds & l) { fl_add(l.fl + FL_HWB, 1u); }
+    static __device__ __forceinline__ void watch_end(const Lds & l) { fl_add(l.fl + FL_HWE, 1u); }
     static __device__ __forceinline__ void sweep_begin(const Lds & l) { fl_add(l.fl + FL_SWB, 1u); }
     static __device__ __forceinline__ void sweep_end(const Lds & l) { fl_add(l.fl + FL_SWE, 1u); }
 
@@ -545,7 +595,7 @@ struct R6 {
         const unsigned RB = __builtin_amdgcn_readfirstlane(p.ring_bytes), MIR = __builtin_amdgcn_readfirstlane(p.mirror_bytes);
         const unsigned ring_m0 = __builtin_amdgcn_readfirstlane((unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) l.ring);
         const unsigned voff = (unsigned) lane * 16u;
-        const int w_norm = __builtin_amdgcn_readfirstlane(p.inflight) & ~3, w_thin = __builtin_amdgcn_readfirstlane(p.thin) & ~3;
+        const int w_norm = __builtin_amdgcn_readfirstlane(p.inflight) & ~3, w_thin = __builtin_amdgcn_readfirstlane(p.thin) & ~3, w_hint = __builtin_amdgcn_readfirstlane(p.hthin) & ~3;
         Poll pl{p.ctl, false};
         unsigned issued = 0, roff = 0, landed = 0;
         unsigned min_done = 0, thin = 0;
@@ -568,7 +618,8 @@ struct R6 {
             asm volatile("" ::: "memory");
             const v4u da = *reinterpret_cast<const v4u *>(l.fl + FL_DONE), db = *reinterpret_cast<const v4u *>(l.fl + FL_DONE + 4);
             const v4u dh = *reinterpret_cast<const v4u *>(l.fl);   // {landed, sweeps begun, sweeps ended, -}
-            const int w = thin ? w_thin : w_norm;
+            const uint2 dw = *reinterpret_cast<const uint2 *>(l.fl + FL_HWB);   // {watches begun, ended}
+            const int w = thin == 1u ? w_thin : (thin == 2u ? w_hint : w_norm);
             rounds++;
             if (lsamp && nsamp < 512u && issued * 1024u + 4096u > samp_lo && landed * 1024u < samp_hi) {   // (tracing: this workgroup's rounds around the traced layer)
                 if (lane == 0) {
@@ -604,7 +655,7 @@ struct R6 {
                 unsigned m = da.x < da.y ? da.x : da.y; m = m < da.z ? m : da.z; m = m < da.w ? m : da.w;
                 m = m < db.x ? m : db.x; m = m < db.y ? m : db.y; m = m < db.z ? m : db.z; m = m < db.w ? m : db.w;
                 min_done = __builtin_amdgcn_readfirstlane(m);
-                thin = __builtin_amdgcn_readfirstlane(dh.y != dh.z ? 1u : 0u);
+                thin = __builtin_amdgcn_readfirstlane(dh.y != dh.z ? 1u : (dw.x != dw.y ? 2u : 0u));
             }
         }
         wait_vm(0);
@@ -624,9 +675,11 @@ struct R6 {
         unsigned lbase;        // stream position of the current layer's block
         unsigned next_block;   // stream position of this wave's first record behind the current layer (next layer, head, or none)
         unsigned RB;
+        unsigned ring_lds;     // LDS address of the ring
         unsigned landed;       // chunks known to have landed
         int c, lane;
         int dbg;               // RWKV_MI_RING_DBG (bit 5: timing experiment, the records' arithmetic replaced by an xor of what was read)
+        unsigned look;         // takes per look at a hand-over's sentinel (hint_take)
         long long waited;      // (tracing) cycles spent waiting for the loader
     };
     template <int T, int TE> struct Unroll {
@@ -634,78 +687,51 @@ struct R6 {
     };
     template <int TE> struct Unroll<TE, TE> { template <typename F> static __device__ __forceinline__ void run(F &&) {} };
 
-    // The records of one phase that belong to this wave: j0, j0 + NC, ...; the first TF exist for every wave (compile-time), one more
-    // ("tail") for some. Statically unrolled: the cursor is scalar arithmetic (stream position and ring offset advance by a constant),
-    // the loader's progress is compared against a cached scalar, a record's ring reads are immediate offsets from one base register
-    // (unless it wraps around the ring end: slow path) and, with PIPE, go out BEFORE the previous record's arithmetic.
-    // epi(integral_constant<t>, j, res) receives the row sums of the wave's t-th record (record j of the phase).
-    // (The first version walked the records in a loop with the cursor in a struct: ~300 overhead instructions per record -- half of
-    //  them scalar, forty branches -- around ~140 useful ones; a C phase took 13.7 k cycles for 3.6 k cycles of arithmetic.)
-    // A wave's FIRST record of a phase can leave the ring before the hand-over that the phase waits for: the ring is full by then
-    // (the loader ran ahead during the previous phase's tail), nothing is in flight, and every byte the consumers free only comes
-    // back a memory latency later. Taking the first record into registers in front of the gather gives the loader that room -- six
-    // records per workgroup -- while the workgroup exchanges. Never waits: a record that has not landed yet is read by rows() as before.
-    template <int R, int U> struct Pre { RawRec<FMT, R, U> w; bool have; };
-    // which phases do it (1: r/k/v/g, 2: output, 4: ffn key, 8: ffn value). D = 4096: as many as the registers hold without spilling
-    // (kernel-resource-usage): all four for Q4_0, three for Q4_1 / Q5_0, r/k/v/g (+ ffn value where its record is small enough) for
-    // Q5_1 / Q8_0. D = 2048: none -- a layer block (130 KB per workgroup) nearly fits the ring as it is, and the extra ring checks in
-    // the watch loops cost 2.5 %.
-    static constexpr int PRE_MASK = EPT > 4 ? (FMT == T_Q4_0 ? 15 : ((FMT == T_Q4_1 || FMT == T_Q5_0) ? 13 : 9)) : 0;
-    template <int PH, int R, int U, int TF>
-    static __device__ __forceinline__ void rows_pre(Cons & cs, const Lds & l, Pre<R, U> & pre) {
-        constexpr unsigned RECB = (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0));
-        constexpr unsigned STRIDE = NC * RECB;
-        pre.have = false;
-        if (cs.dbg & 64) return;                                   // (A/B switch)
+    // Records leave the ring for REGISTERS as soon as they have landed -- while the wave watches the hand-over its phase waits for.
+    // Round 3 measured why: at the end of every hand-over the ring is full and nothing is in flight; the consumers drain
+    // it in a microsecond or two and then wait a memory latency (~2 us with all 256 loaders restarting at once) for every further byte:
+    // about half of each row phase was "waiting for the loader", and the hand-over behind a phase waits for the SLOWEST workgroup. One
+    // record per wave in registers (round 3) gave the loader six records of room per hand-over; the register file (512 KB per CU) is
+    // three times the LDS, and a consumer wave holds next to nothing while it waits. So a wave now takes up to NP of its records of
+    // the coming phase -- all of them where the registers allow -- and the loader streams the phase after that into the room they
+    // leave. Record t of the wave lives in buffer t % NP; rows() takes what is still missing (blocking), one record ahead of the
+    // arithmetic, so NP = 2 is the old double buffer and NP = 1 the single one (Q8_0's long value rows).
+    template <int R, int U, int NP> struct Pre {
+        static constexpr int R_ = R, U_ = U, NP_ = NP;
+        static constexpr unsigned RECB = (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0));
+        RawRec<FMT, R, U> w[NP];
+        unsigned have;         // records of this wave taken out of the ring so far in this phase
+        unsigned cnt;          // records this wave owns in this phase
+        unsigned pos, ro;      // stream position / ring offset of the next record to take
+        unsigned after;        // where this wave's stream continues behind the phase
+    };
+    template <int R, int U> static constexpr unsigned recb() { return (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0)); }
+    template <int PH, int R, int U, int NP>
+    static __device__ __forceinline__ void pre_begin(const Cons & cs, Pre<R, U, NP> & pre) {
+        constexpr unsigned RECB = recb<R, U>();
         const unsigned n = cs.cu.n[PH];
         const unsigned j0 = rg_first_j(cs.cu, PH, cs.c);
-        if (j0 >= n) return;
-        const unsigned pos = __builtin_amdgcn_readfirstlane(cs.lbase + cs.cu.off[PH] + j0 * RECB);
-        const unsigned ro = __builtin_amdgcn_readfirstlane(pos - (pos / cs.RB) * cs.RB);
-        const unsigned need = (pos + RECB + 1023u) >> 10;
-        if (cs.landed < need) cs.landed = fl_ld(l.fl + FL_LANDED);
-        if (cs.landed < need) return;
-        const bool only = !(j0 + NC < n);
+        pre.have = 0;
+        pre.cnt = __builtin_amdgcn_readfirstlane(j0 < n ? (n - j0 + NC - 1) / NC : 0u);
+        pre.pos = __builtin_amdgcn_readfirstlane(cs.lbase + cs.cu.off[PH] + j0 * RECB);
+        pre.ro = __builtin_amdgcn_readfirstlane(pre.pos - (pre.pos / cs.RB) * cs.RB);   // (once per phase)
         const unsigned nxt = rg_next_own_in_layer(cs.cu, cs.c, PH + 1);
-        const unsigned after = nxt != RG_NONE ? cs.lbase + nxt : cs.next_block;
-        asm volatile("" ::: "memory");
-        rec_load<FMT, R, U>(pre.w, l.ring, ro, opq(cs.lane));
-        asm volatile("" ::: "memory");
-        __hip_atomic_store(l.fl + FL_DONE + 2 + cs.c, only ? after : pos + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        pre.have = true;
+        pre.after = __builtin_amdgcn_readfirstlane(nxt != RG_NONE ? cs.lbase + nxt : cs.next_block);
+#pragma unroll
+        for (int i = 0; i < NP; i++) rec_reserve<FMT, R, U>(pre.w[i]);
     }
-
-    template <int PH, int R, int U, int TF, bool PIPE_, typename EpiF>
-    static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, EpiF && epi) {
-        Pre<R, U> none;
-        none.have = false;
-        rows<PH, R, U, TF, PIPE_>(cs, pl, l, act, nbk, none, epi);
-    }
-    template <int PH, int R, int U, int TF, bool PIPE_, typename EpiF>
-    static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, Pre<R, U> & pre, EpiF && epi) {
-        constexpr bool PIPE = PIPE_ && QF<FMT>::QS == 16;   // (Q8_0 records are twice the registers: one buffer)
-        constexpr unsigned RECB = (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0));
-        constexpr unsigned STRIDE = NC * RECB;
-        const unsigned n = cs.cu.n[PH];
-        const unsigned j0 = rg_first_j(cs.cu, PH, cs.c);
-        if (j0 >= n) return;
-        const bool tail = j0 + NC * TF < n;                         // wave-uniform
-        const unsigned nxt = rg_next_own_in_layer(cs.cu, cs.c, PH + 1);
-        const unsigned after = nxt != RG_NONE ? cs.lbase + nxt : cs.next_block;
-        unsigned pos = __builtin_amdgcn_readfirstlane(cs.lbase + cs.cu.off[PH] + j0 * RECB);
-        unsigned ro = pos;
-        { const unsigned q = pos / cs.RB; ro = __builtin_amdgcn_readfirstlane(pos - q * cs.RB); }   // (once per phase)
-        const unsigned RB = cs.RB;
-        const int ln = opq(cs.lane);
-        ActRegs<U> ar;
-        act_load<U>(ar, act, nbk, ln);
-        unsigned * const dn = l.fl + FL_DONE + 2 + cs.c;
-        RawRec<FMT, R, U> w1;                                      // (second buffer; the first one is pre.w)
-        auto wbuf = [&](int i) -> RawRec<FMT, R, U> & { return (PIPE && (i & 1)) ? w1 : pre.w; };
-        // ring reads + release of the record at (pos, ro); last = no further record of this wave in the phase
-        auto load = [&](RawRec<FMT, R, U> & wr, bool last) {
-            const unsigned need = (pos + RECB + 1023u) >> 10;
+    // takes record number pre.have (== T, statically) into buffer T % NP and releases its ring space; block = false: only if it has landed
+    // WAIT = false: the reads are still in flight on return -- the caller calls rec_wait on the buffer before its first use, with only
+    // straight arithmetic on OTHER buffers in between (no hardware interlock covers a register with an LDS read pending: a copy the
+    // compiler made in between would copy the old contents)
+    template <int T, int R, int U, int NP, bool WAIT = true>
+    static __device__ __forceinline__ bool rec_take(Cons & cs, Poll & pl, const Lds & l, Pre<R, U, NP> & pre, bool block) {
+        constexpr unsigned RECB = recb<R, U>(), STRIDE = NC * RECB;
+        const unsigned need = (pre.pos + RECB + 1023u) >> 10;
+        if (cs.landed < need) {
+            cs.landed = fl_ld(l.fl + FL_LANDED);
             if (cs.landed < need) {
+                if (!block) return false;
                 const long long t0 = (long long) __builtin_readcyclecounter();
                 for (unsigned spin = 0;; spin++) {
                     cs.landed = fl_ld(l.fl + FL_LANDED);
@@ -714,14 +740,110 @@ struct R6 {
                 }
                 cs.waited += (long long) __builtin_readcyclecounter() - t0;
             }
-            asm volatile("" ::: "memory");
-            rec_load<FMT, R, U>(wr, l.ring, ro, ln);
-            // the reads above are in the LDS queue: the ring may be refilled up to this wave's next record (every lane writes the same word)
-            asm volatile("" ::: "memory");
-            __hip_atomic_store(dn, last ? after : pos + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
+        }
+        asm volatile("" ::: "memory");
+        rec_load<FMT, R, U>(pre.w[T % NP], cs.ring_lds, pre.ro, opq(cs.lane));
+        // the reads above are in the LDS queue: the ring may be refilled up to this wave's next record (every lane writes the same word)
+        asm volatile("" ::: "memory");
+        const bool last = pre.have + 1u >= pre.cnt;
+        __hip_atomic_store(l.fl + FL_DONE + 2 + cs.c, last ? pre.after : pre.pos + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (WAIT) rec_wait<FMT, R, U>(pre.w[T % NP]);
+        pre.have += 1u;
         // (a wave's records are NC records apart: more than one lap of the ring for the long Q8_0 value rows)
-        auto advance = [&]() { pos += STRIDE; ro += STRIDE; ro = ro >= RB ? ro - RB : ro; if constexpr (STRIDE > 32768u) { ro = ro >= RB ? ro - RB : ro; ro = ro >= RB ? ro - RB : ro; } };
+        pre.pos += STRIDE; pre.ro += STRIDE;
+        pre.ro = pre.ro >= cs.RB ? pre.ro - cs.RB : pre.ro;
+        if constexpr (STRIDE > 32768u) { pre.ro = pre.ro >= cs.RB ? pre.ro - cs.RB : pre.ro; pre.ro = pre.ro >= cs.RB ? pre.ro - cs.RB : pre.ro; }
+        return true;
+    }
+    // which phases take records ahead (1: r/k/v/g, 2: output, 4: ffn key, 8: ffn value), and how many per wave. D = 2048: none -- a layer
+    // block (130 KB per workgroup) nearly fits the ring as it is, and the extra ring checks in the watch loops cost 2.5 %.
+    // + 16: W1 + r/k/v/g records during the x hand-over at the top of the layer, + 32: output records during the act hand-over, + 64: ffn
+    // key records during the yq hand-over (the phase behind the one the hand-over feeds), + 128: ffn receptance records behind those
+#ifndef R6_PRE_MASK
+#define R6_PRE_MASK 239
+#endif
+    static constexpr int PRE_MASK = EPT > 4 ? R6_PRE_MASK : 0;
+    // Stage 1 of a gather (gather_hint) with the wait put to use: until the hand-over's sentinel turns, the wave takes its records of
+    // the coming phase as they land -- record 0, then 1, ... up to NP -- and never waits for a record once the hand-over is there.
+    // Written as a straight sequence of NP steps (each: spin until "record t has landed" or "the hand-over turned"), not as one loop that
+    // takes whatever has landed: with every buffer redefined conditionally inside a loop the register allocator splits the buffers'
+    // live ranges around it and copies them (v_mov_b64 chains, then spills: tools/vgpr_live.py showed 253 live registers at a wait
+    // that holds 90).
+    // One step per record: a look at the sentinel (a memory round trip), then -- if the hand-over has not turned -- the record, if it
+    // has landed. Six takes back to back kept all seven waves of a workgroup away from their sentinels for a microsecond, and the hand-
+    // over behind them waited that long (measured: x hand-over + 0.95 us, kq + 1.5 us); a look before EVERY take (1 - 2 us each under
+    // the stream) left the ffn key records in the ring through the yq wait -- three output records and one or two key records was all a
+    // wave got to -- and the loader idle for 4 us behind them. `look` takes per look (p.look, RWKV_MI_RING_LOOK); the workgroup's
+    // "turned" word in LDS is read before every take. Measured on the 7B Q4_0, same box, tokens/s: round-3 kernel 638 - 654, look 1: 639 - 644,
+    // 2: 630, 3: 626, 6: 608 -- every record taken sooner costs the hand-overs more than the row phase behind them gains (the stream
+    // and the polls share the memory system: DESIGN.md 7.2c). Default 1.
+    // Two phases per wait: `a` is the phase this hand-over feeds, `b` the one behind it in the stream (taken only once every record of
+    // `a` is in registers: a wave releases ring space in stream order). With one phase per wait the loader found the ring full again
+    // 2 - 3 us into every wait -- the records of the NEXT phase sat in it until the next wait; now they leave during this one, and
+    // what streams in behind them is two phases ahead.
+    template <int RA, int UA, int NA, int RB_, int UB_, int NB_, int RC, int UC, int NC_>
+    static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap,
+                                                     bool on_a, Pre<RA, UA, NA> & a, bool on_b, Pre<RB_, UB_, NB_> & b, bool on_c, Pre<RC, UC, NC_> & c3) {
+        bool turned = false;
+        const unsigned look = cs.look;
+        auto step = [&](auto & pre, auto tc, bool ok) {
+            constexpr int t = decltype(tc)::value;
+            using P = typename std::remove_reference<decltype(pre)>::type;
+            if (!turned && ok && pre.have == (unsigned) t && (unsigned) t < pre.cnt) {
+                const unsigned need = (pre.pos + P::RECB + 1023u) >> 10;
+                bool here = false;
+                for (unsigned spin = 0;; spin++) {
+                    if (fl_ld(go) >= gen || pl.dead) { turned = true; break; }
+                    if (cs.landed < need) cs.landed = fl_ld(l.fl + FL_LANDED);
+                    const bool landed = cs.landed >= need;
+                    // a landed record is taken at once -- except that every `look`-th take in a row is preceded by a look at the sentinel
+                    if (landed && (spin > 0u || (unsigned) t % look != 0u)) { here = true; break; }
+                    asm volatile("" ::: "memory");
+                    const v4u v = tg_load(xr, unit);
+                    if (__builtin_amdgcn_readfirstlane((int) tg_ok(v, tag))) { fl_st(go, gen); turned = true; break; }
+                    if (landed) { here = true; break; }
+                    if (poll_backoff(pl, spin)) { turned = true; break; }
+                    for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
+                }
+                if (here) (void) rec_take<t, P::R_, P::U_, P::NP_>(cs, pl, l, pre, false);
+            }
+        };
+        if (!(cs.dbg & 64)) {
+            Unroll<0, NA>::run([&](auto tc) { step(a, tc, on_a); });
+            Unroll<0, NB_>::run([&](auto tc) { step(b, tc, on_b && a.have >= a.cnt); });
+            Unroll<0, NC_>::run([&](auto tc) { step(c3, tc, on_c && a.have >= a.cnt && b.have >= b.cnt); });
+        }
+        if (!turned) gather_hint(pl, xr, unit, tag, go, gen, nap);
+    }
+    template <int RA, int UA, int NA, int RB_, int UB_, int NB_>
+    static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap,
+                                                     bool on_a, Pre<RA, UA, NA> & a, bool on_b, Pre<RB_, UB_, NB_> & b) {
+        Pre<1, 1, 1> none;
+        none.have = 0u; none.cnt = 0u; none.pos = 0u; none.ro = 0u; none.after = 0u;
+        hint_take(cs, pl, l, xr, unit, tag, go, gen, nap, on_a, a, on_b, b, false, none);
+    }
+    template <int R, int U, int NP>
+    static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap, bool on, Pre<R, U, NP> & pre) {
+        Pre<1, 1, 1> none;
+        none.have = 0u; none.cnt = 0u; none.pos = 0u; none.ro = 0u; none.after = 0u;
+        hint_take(cs, pl, l, xr, unit, tag, go, gen, nap, on, pre, false, none, false, none);
+    }
+
+    // The records of one phase that belong to this wave: j0, j0 + NC, ...; the first TF exist for every wave that owns any (compile-time),
+    // one more ("tail") for some. Statically unrolled: the cursor is scalar arithmetic (stream position and ring offset advance by a
+    // constant), the loader's progress is compared against a cached scalar, a record's ring reads are immediate offsets from one base
+    // register. epi(integral_constant<t>, j, res) receives the row sums of the wave's t-th record (record j of the phase).
+    // (The first version walked the records in a loop with the cursor in a struct: ~300 overhead instructions per record -- half of
+    //  them scalar, forty branches -- around ~140 useful ones; a C phase took 13.7 k cycles for 3.6 k cycles of arithmetic.)
+    template <int PH, int R, int U, int TF, int NP, typename EpiF>
+    static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, Pre<R, U, NP> & pre, EpiF && epi) {
+        static_assert(NP >= 1 && NP <= TF + 1, "rows: buffers");
+        if (pre.cnt == 0u) return;
+        const bool tail = pre.cnt > (unsigned) TF;                  // wave-uniform
+        const unsigned j0 = rg_first_j(cs.cu, PH, cs.c);
+        const int ln = opq(cs.lane);
+        ActRegs<U> ar;
+        act_load<U>(ar, act, nbk, ln);
         // per-lane partial sums of every record of the phase; ONE interleaved butterfly over all of them at the end (a butterfly is six
         // dependent cross-lane steps: per record they ran back to back, two chains at a time)
         float part[(TF + 1) * R];
@@ -743,34 +865,19 @@ struct R6 {
 #pragma unroll
             for (int r = 0; r < R; r++) asm volatile("" :: "v"(part[t * R + r]));
         };
-        // (the wave's first record may already be in pre.w: rows_pre)
-        if constexpr (PIPE) {
-            if constexpr (TF > 0) {
-                if (!pre.have) load(pre.w, TF == 1 && !tail);
-                Unroll<0, TF>::run([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-                    if constexpr (t + 1 < TF) { advance(); load(wbuf(t + 1), t + 2 == TF && !tail); }
-                    else if (tail) { advance(); load(wbuf(t + 1), true); }
-                    finish(tc, wbuf(t));
-                });
-                if (tail) finish(std::integral_constant<int, TF>{}, wbuf(TF));
-            } else {
-                if (!pre.have) load(pre.w, true);
-                finish(std::integral_constant<int, 0>{}, pre.w);
+        // what is not in registers yet (blocking), up to NP records; then the arithmetic, and behind record t its buffer takes record t + NP
+        Unroll<0, NP>::run([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if ((t < TF || tail) && pre.have <= (unsigned) t) (void) rec_take<t, R, U, NP, false>(cs, pl, l, pre, true);
+        });
+        Unroll<0, TF + 1>::run([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if (t < TF || tail) {
+                rec_wait<FMT, R, U>(pre.w[t % NP]);
+                finish(tc, pre.w[t % NP]);
+                if constexpr (t + NP <= TF) { if (t + NP < TF || tail) (void) rec_take<t + NP, R, U, NP, false>(cs, pl, l, pre, true); }
             }
-        } else {
-            Unroll<0, TF>::run([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                if constexpr (t > 0) advance();
-                if (t > 0 || !pre.have) load(pre.w, t + 1 == TF && !tail);
-                finish(tc, pre.w);
-            });
-            if (tail) {
-                if constexpr (TF > 0) advance();
-                if (TF > 0 || !pre.have) load(pre.w, true);
-                finish(std::integral_constant<int, TF>{}, pre.w);
-            }
-        }
+        });
         wave_sum_n<(TF + 1) * R>(part);
         Unroll<0, TF>::run([&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -786,6 +893,38 @@ struct R6 {
             epi(std::integral_constant<int, TF>{}, (int) (j0 + NC * TF), res);
         }
     }
+    // a phase without records taken ahead
+    template <int PH, int R, int U, int TF, int NP, typename EpiF>
+    static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, EpiF && epi) {
+        Pre<R, U, NP> pre;
+        pre_begin<PH>(cs, pre);
+        rows<PH, R, U, TF, NP>(cs, pl, l, act, nbk, pre, epi);
+    }
+
+    // buffers per wave and phase = records held in registers at once. r/k/v/g sets (C), output rows (E), ffn key sets (K), ffn receptance
+    // rows (R), ffn value rows (G). With records taken ahead (PRE_MASK): as many as the register file holds without spilling
+    // (tools/check_ring_regs.sh prints the budget of every instantiation); without: the double buffer (one buffer for Q8_0's 36-register
+    // blocks and for the long value rows).
+    static constexpr int TFC = (D * 4 / NBLK / 2) / NC, TFE = RE / NC, TFK = (UF * 64 > NBLK ? 32 : 16) / NC;
+    static constexpr bool Q8 = QF<FMT>::QS == 32, Q5 = QF<FMT>::QH;
+    static constexpr int npcap(int want, int tf) { return want < 1 ? 1 : (want > tf + 1 ? tf + 1 : want); }
+#ifndef R6_NPC
+#define R6_NPC (Q8 ? 3 : (Q5 ? 5 : 6))
+#endif
+#ifndef R6_NPE
+#define R6_NPE 3
+#endif
+#ifndef R6_NPK
+#define R6_NPK ((PRE_MASK & 128) ? (Q8 ? 2 : (Q5 ? 4 : 5)) : (Q8 ? 3 : (Q5 ? 5 : 6)))   /* (with the receptance records held as well: one buffer less) */
+#endif
+#ifndef R6_NPG
+#define R6_NPG (Q8 ? 1 : 3)
+#endif
+    static constexpr int NPC = npcap((PRE_MASK & 1) ? R6_NPC : (Q8 ? 1 : 2), TFC);
+    static constexpr int NPE = npcap((PRE_MASK & 2) ? R6_NPE : (Q8 ? 1 : 2), TFE);
+    static constexpr int NPK = npcap((PRE_MASK & 4) ? R6_NPK : (Q8 ? 1 : 2), TFK);
+    static constexpr int NPR = npcap((PRE_MASK & 128) ? 3 : (Q8 ? 1 : 2), TFE);
+    static constexpr int NPG = npcap((PRE_MASK & 8) ? R6_NPG : 1, TFE);
 
     static __device__ __forceinline__ void consumer_main(const R6P & p, const Lds & l, int lane, int wave, unsigned base) {
         const int blk = blockIdx.x;
@@ -799,7 +938,7 @@ struct R6 {
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         const RingShape sh = shape(p);
         Cons cs;
-        cs.cu = rg_cu(sh, blk); cs.lbase = 0; cs.landed = 0; cs.RB = __builtin_amdgcn_readfirstlane(p.ring_bytes); cs.c = c; cs.lane = lane; cs.dbg = __builtin_amdgcn_readfirstlane(p.dbg); cs.waited = 0;
+        cs.cu = rg_cu(sh, blk); cs.lbase = 0; cs.landed = 0; cs.RB = __builtin_amdgcn_readfirstlane(p.ring_bytes); cs.ring_lds = __builtin_amdgcn_readfirstlane((unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) l.ring); cs.c = c; cs.lane = lane; cs.dbg = __builtin_amdgcn_readfirstlane(p.dbg); cs.look = (unsigned) __builtin_amdgcn_readfirstlane(p.look); cs.waited = 0;
         const int mat = (blk * (4 * D / NBLK)) / D;   // which of r, k, v, g this workgroup's sets belong to
         const int cbase = (blk * (4 * D / NBLK)) % D;
         const bool has_dw1 = blk < p.DR;
@@ -812,8 +951,18 @@ struct R6 {
         float xown[XT], rrow[XT];
 #pragma unroll
         for (int t = 0; t < XT; t++) { const int row = c + NC * t; xown[t] = row < RE ? p.x[blk * RE + row] : 0.0f; rrow[t] = 0.0f; }
+        // Where the prologue parameters are loaded (LayerNorm affine, token-shift source, mix weights: 4 / 5 float4 per slot and thread).
+        // R6_LATE_PARAMS = 0 (round 3): a whole phase ahead -- 48 / 60 registers live across a hand-over wait. 1: at the start of the
+        // prologue, in flight under the LayerNorm statistics (two reduction rounds, ~1 us; the lines are the same for every workgroup:
+        // L2 hits) -- the hand-over waits then hold next to nothing but records taken ahead, which is what the registers are for now.
+        // 2 (default): LN1's a phase ahead as in round 3 (nothing else is held across that hand-over), LN2's when the x hand-over's sentinel
+        // has turned -- in flight under the sweep and the statistics, behind the records taken during the wait. Measured on the 7B: placement 1
+        // costs 1.5 + 0.6 us per layer in the two prologues (the loads are NOT covered by the statistics).
+#ifndef R6_LATE_PARAMS
+#define R6_LATE_PARAMS 2
+#endif
         PA pa; PF pf;
-        issue_pa(pa, ar, p.layers[0], p.sin, c, opq(lane));
+        if (R6_LATE_PARAMS != 1) issue_pa(pa, ar, p.layers[0], p.sin, c, opq(lane));
 
         for (int li = 0; li < p.n_layers; li++) {
             const M6Layer & L = p.layers[li];
@@ -825,6 +974,10 @@ struct R6 {
             cs.next_block = li + 1 < p.n_layers ? cs.lbase + cs.cu.layer_bytes + first_own : head_first;
             R6STAMP(0);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 23] = cs.waited;
+            Pre<1, UD, 1> pw;
+            pre_begin<RG_W1>(cs, pw);
+            Pre<2, UD, NPC> pc;
+            pre_begin<RG_C>(cs, pc);
             // (per-lane offsets are derived from an opaque copy of the lane index in every phase: left alone, the compiler hoists a
             //  hundred loop-invariant address registers of the gathers out of the layer loop and spills them)
             // ---- A: x, LN1 + mix + quantise, W1 rows ----
@@ -832,28 +985,31 @@ struct R6 {
                 sweep_begin(l);
                 for (int i = c * 64 + lane; i < D; i += NG * 64) l.x[i] = p.x[i];
             } else {
-                gather_hint(pl, xr, p.xffn + ((blk * 37 + c * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
+                watch_begin(l);
+                hint_take(cs, pl, l, xr, p.xffn + ((blk * 37 + c * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap, (PRE_MASK & 16) != 0, pw, (PRE_MASK & 16) != 0, pc);
+                watch_end(l);
                 sweep_begin(l);
                 gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, c, opq(lane), l.x);
             }
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
             sweep_end(l);
             R6STAMP(1);
+            if (R6_LATE_PARAMS == 1) { issue_pa(pa, ar, L, sin_l, c, opq(lane)); __builtin_amdgcn_sched_barrier(0); }
             if (pro) prologue_A(pl, l, pa, sout_l, blk == 0, c, opq(lane), 2u * li + 1u);
             prologue_wait(pl, l, 2u * li + 1u);
             R6STAMP(2);
-            rows<RG_W1, 1, UD, 0, false>(cs, pl, l, qvec_at(l.q1, D), nb, [&](auto, int j, const float (&res)[1]) {
+            rows<RG_W1, 1, UD, 0, 1>(cs, pl, l, qvec_at(l.q1, D), nb, pw, [&](auto, int j, const float (&res)[1]) {
                 if (lane == 0) tg_store(xr, p.tl + blk + NBLK * j, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
             });
             R6STAMP(3);
             // ---- C: the mixed inputs (this workgroup's matrix reads ONE of the five), decay row, r/k/v/g sets ----
-            Pre<2, UD> pc;
-            pc.have = false;
-            auto try_c = [&]() { if constexpr ((PRE_MASK & 1) != 0) { if (!pc.have) rows_pre<RG_C, 2, UD, 0>(cs, l, pc); } };
-            try_c();
+            Pre<1, UD, NPE> pe;
+            pre_begin<RG_E>(cs, pe);
             {
                 const int img = (0x4213 >> (4 * mat)) & 0xF;   // r, k, v, g -> mix image (w, k, v, r, g order)
-                gather_hint(pl, xr, p.act5 + img * p.act_stride + ((blk * 7 + c * 19) & 127), tagL + SLOT_ACT, l.fl + FL_HACT, g1, p.nap, try_c);
+                watch_begin(l);
+                hint_take(cs, pl, l, xr, p.act5 + img * p.act_stride + ((blk * 7 + c * 19) & 127), tagL + SLOT_ACT, l.fl + FL_HACT, g1, p.nap, (PRE_MASK & 1) != 0, pc, (PRE_MASK & 32) != 0, pe);
+                watch_end(l);
                 sweep_begin(l);
                 gather_qvec<DSL>(pl, xr, p.act5 + img * p.act_stride, D, tagL + SLOT_ACT, c, opq(lane), l.act);
                 if (has_dw1) gather_qvec<DSL>(pl, xr, p.act5, D, tagL + SLOT_ACT, c, opq(lane), l.actw);
@@ -871,7 +1027,7 @@ struct R6 {
                 const int j0 = (int) rg_first_j(cs.cu, RG_C, c);
                 if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 20] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_C]);
                 R6RSTAMP(26);
-                rows<RG_C, 2, UD, NSET / NC, true>(cs, pl, l, qvec_at(l.act, D), nb, pc, [&](auto tc, int, const float (&res)[2]) {
+                rows<RG_C, 2, UD, NSET / NC, NPC>(cs, pl, l, qvec_at(l.act, D), nb, pc, [&](auto tc, int, const float (&res)[2]) {
                     constexpr int t = decltype(tc)::value;
                     all[2 * t] = res[0]; all[2 * t + 1] = res[1];
                 });
@@ -885,66 +1041,68 @@ struct R6 {
             }
             R6STAMP(5); R6RSTAMP(27);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 24] = cs.waited;
-            issue_pf(pf, ar, L, sin_l, c, opq(lane));
+            if (R6_LATE_PARAMS == 0) issue_pf(pf, ar, L, sin_l, c, opq(lane));
             __builtin_amdgcn_sched_barrier(0);
             // ---- E: output projection + residual ----
-            Pre<1, UD> pe;
-            pe.have = false;
-            auto try_e = [&]() { if constexpr ((PRE_MASK & 2) != 0) { if (!pe.have) rows_pre<RG_E, 1, UD, 0>(cs, l, pe); } };
-            try_e();
-            gather_hint(pl, xr, p.yq + ((blk * 7 + c * 19) & 127), tagL + SLOT_YQ, l.fl + FL_HYQ, g1, p.nap, try_e);
+            Pre<2, UD, NPK> pk;
+            pre_begin<RG_FK>(cs, pk);
+            Pre<1, UD, NPR> pr;
+            pre_begin<RG_FR>(cs, pr);
+            watch_begin(l);
+            hint_take(cs, pl, l, xr, p.yq + ((blk * 7 + c * 19) & 127), tagL + SLOT_YQ, l.fl + FL_HYQ, g1, p.nap, (PRE_MASK & 2) != 0, pe, (PRE_MASK & 64) != 0, pk, (PRE_MASK & 128) != 0, pr);
+            watch_end(l);
             sweep_begin(l);
             gather_qvec<DSL>(pl, xr, p.yq, D, tagL + SLOT_YQ, c, opq(lane), l.yq);
             gather_meet(pl, l.fl + FL_GYQ, g1);
             sweep_end(l);
             R6STAMP(6);
-            rows<RG_E, 1, UD, RE / NC, true>(cs, pl, l, qvec_at(l.yq, D), nb, pe, [&](auto tc, int, const float (&res)[1]) {
+            rows<RG_E, 1, UD, RE / NC, NPE>(cs, pl, l, qvec_at(l.yq, D), nb, pe, [&](auto tc, int, const float (&res)[1]) {
                 constexpr int t = decltype(tc)::value;
                 xown[t] = xown[t] + res[0];
             });
             if (lane == 0) tg_store(xr, p.xatt + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XATT);
             R6STAMP(7);
             // ---- F: x, LN2 + mixes + quantise, key sets (-> comm quantises them), receptance rows ----
-            Pre<2, UD> pk;
-            pk.have = false;
-            auto try_k = [&]() { if constexpr ((PRE_MASK & 4) != 0) { if (!pk.have) rows_pre<RG_FK, 2, UD, 0>(cs, l, pk); } };
-            try_k();
-            gather_hint(pl, xr, p.xatt + ((blk * 37 + c * 211) & 1023), tagL + SLOT_XATT, l.fl + FL_HX, 2u * li + 2u, p.nap, try_k);
+            watch_begin(l);
+            hint_take(cs, pl, l, xr, p.xatt + ((blk * 37 + c * 211) & 1023), tagL + SLOT_XATT, l.fl + FL_HX, 2u * li + 2u, p.nap, (PRE_MASK & 4) != 0, pk, (PRE_MASK & 128) != 0, pr);
+            watch_end(l);
+            if (R6_LATE_PARAMS == 2) { issue_pf(pf, ar, L, sin_l, c, opq(lane)); __builtin_amdgcn_sched_barrier(0); }
             sweep_begin(l);
             gather_x(pl, xr, p.xatt, tagL + SLOT_XATT, c, opq(lane), l.x);
             gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
             sweep_end(l);
             R6STAMP(8);
+            if (R6_LATE_PARAMS == 1) { issue_pf(pf, ar, L, sin_l, c, opq(lane)); __builtin_amdgcn_sched_barrier(0); }
             if (pro) prologue_F(pl, l, pf, sout_l, blk == 0, c, opq(lane), 2u * li + 2u);
             prologue_wait(pl, l, 2u * li + 2u);
             R6STAMP(9); R6RSTAMP(28);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 21] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_FK]);
-            rows<RG_FK, 2, UD, (UF * 64 > NBLK ? 32 : 16) / NC, true>(cs, pl, l, qvec_at(l.q1, D), nb, pk, [&](auto, int j, const float (&res)[2]) {
+            rows<RG_FK, 2, UD, TFK, NPK>(cs, pl, l, qvec_at(l.q1, D), nb, pk, [&](auto, int j, const float (&res)[2]) {
                 const float v = lane == 1 ? res[1] : res[0];
                 const float t = v > 0.0f ? v : 0.0f;
                 if (lane < 2) l.out[2 * j + lane] = t * t;
             });
             fl_add(l.fl + FL_KEYS, 1u);
             R6STAMP(10);
-            rows<RG_FR, 1, UD, RE / NC, true>(cs, pl, l, qvec_at(l.q2, D), nb, [&](auto tc, int, const float (&res)[1]) {
+            rows<RG_FR, 1, UD, RE / NC, NPR>(cs, pl, l, qvec_at(l.q2, D), nb, pr, [&](auto tc, int, const float (&res)[1]) {
                 constexpr int t = decltype(tc)::value;
                 rrow[t] = res[0];
             });
             R6STAMP(11); R6RSTAMP(29);
             // ---- G: value projection, x += sigmoid(r) * (Wv k) ----
-            Pre<1, UF> pg;
-            pg.have = false;
+            Pre<1, UF, NPG> pg;
+            pre_begin<RG_G>(cs, pg);
             // (registers: not the long Q8_0 rows of the 7B geometry)
-            auto try_g = [&]() { if constexpr ((PRE_MASK & 8) != 0 && sizeof(RawRec<FMT, 1, UF>) <= 48 * 4) { if (!pg.have) rows_pre<RG_G, 1, UF, 0>(cs, l, pg); } };
-            try_g();
-            gather_hint(pl, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap, try_g);
+            watch_begin(l);
+            hint_take(cs, pl, l, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap, (PRE_MASK & 8) != 0 && sizeof(RawRec<FMT, 1, UF>) <= 48 * 4, pg);
+            watch_end(l);
             sweep_begin(l);
             gather_qvec<KSL>(pl, xr, p.kq, F, tagL + SLOT_KQ, c, opq(lane), l.kq);
             gather_meet(pl, l.fl + FL_GKQ, g1);
             sweep_end(l);
             R6STAMP(12); R6RSTAMP(30);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 22] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_G]);
-            rows<RG_G, 1, UF, RE / NC, false>(cs, pl, l, qvec_at(l.kq, F), nbF, pg, [&](auto tc, int j, const float (&res)[1]) {
+            rows<RG_G, 1, UF, RE / NC, NPG>(cs, pl, l, qvec_at(l.kq, F), nbF, pg, [&](auto tc, int j, const float (&res)[1]) {
                 constexpr int t = decltype(tc)::value;
                 const float gte = sigmoid_f(rrow[t]) * res[0];
                 xown[t] = xown[t] + gte;
@@ -953,8 +1111,12 @@ struct R6 {
             if (lane == 0) tg_store(xr, p.xffn + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
             R6STAMP(13); R6RSTAMP(14);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 25] = cs.waited;
-            if (li + 1 < p.n_layers) {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
-                issue_pa(pa, ar, p.layers[li + 1], p.sin + (long long) (li + 1) * p.state_stride, c, opq(lane));
+            __builtin_amdgcn_sched_barrier(0);   // (the loads below stay behind the value rows: hoisted into them they cost 48 registers at the kernel's peak)
+            if (R6_LATE_PARAMS != 1) {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
+                // (unconditionally -- behind the last layer the same layer's again: under `if (li + 1 < n_layers)` the parameters are
+                //  conditionally redefined, and the old values stay live through the whole layer on the path the compiler cannot rule out)
+                const int nl = li + 1 < p.n_layers ? li + 1 : li;
+                issue_pa(pa, ar, p.layers[nl], p.sin + (long long) nl * p.state_stride, c, opq(lane));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -973,7 +1135,9 @@ struct R6 {
         const int pt = c * 64 + lane;
         R6STAMP(0); R6RSTAMP(16);
         // x after the last layer
+        watch_begin(l);
         gather_hint(pl, xr, p.xffn + ((blk * 37 + c * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
+        watch_end(l);
         sweep_begin(l);
         gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, c, opq(lane), l.x);
         gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
@@ -1102,7 +1266,9 @@ struct R6 {
                 sweep_begin(l);
                 for (int i = g * 64 + lane; i < D; i += NG * 64) l.x[i] = p.x[i];
             } else {
+                watch_begin(l);
                 gather_hint(pl, xr, p.xffn + ((blk * 37 + g * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
+                watch_end(l);
                 sweep_begin(l);
                 gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, g, opq(lane), l.x);
             }
@@ -1131,7 +1297,7 @@ struct R6 {
                 const WPl dw1 = ar.w(L.dw1);
                 const int drow = has_dw1 ? blk : 0;
 #pragma unroll
-                for (int u = 0; u < UD; u++) { const int bb = u * 64 + lnA; load_raw<FMT>(dwr.raw[u][0], dw1.qs, dw1.qh, dw1.sc, (long long) drow * nb + (bb < nb ? bb : nb - 1)); }
+                for (int u = 0; u < UD; u++) { const int bb = u * 64 + lnA; RawBlk<FMT> rb; rb.qh = 0u; load_raw<FMT>(rb, dw1.qs, dw1.qh, dw1.sc, (long long) drow * nb + (bb < nb ? bb : nb - 1)); from_raw<FMT>(dwr.raw[u][0], rb); }
             }
             __builtin_amdgcn_sched_barrier(0);
             fl_wait(pl, l.fl + FL_PRO, 4u * (2u * li + 1u));   // l.x holds x - mean, l.misc[0] the scale
@@ -1148,8 +1314,10 @@ struct R6 {
                     cxn[q] = yw + cb_[q];
                     csx[q] = cpv[q] - cxn[q];
                 }
+                watch_begin(l);
                 gather_hint(pl, xr, p.tl + ((blk * 7) & 127), tagL + SLOT_TL, l.fl + FL_HTL, g1, p.nap);   // (one unit first, then the sweep)
                 poll_units<5, 64>(pl, xr, p.tl, 5 * R, tagL + SLOT_TL, ln, [&](int i, const v4u & v) { l.tl[i] = __uint_as_float(v.x); });
+                watch_end(l);
                 __builtin_amdgcn_wave_barrier();
                 R6STAMP(3); R6RSTAMP(18);
                 // both chunks' sums in ONE loop: a sum is a chain of R dependent adds (its order is the reference's), and the second
@@ -1186,7 +1354,9 @@ struct R6 {
             // ---- C: stage this workgroup's share of the mixed inputs ----
             {
                 const int img = (0x4213 >> (4 * mat)) & 0xF;
+                watch_begin(l);
                 gather_hint(pl, xr, p.act5 + img * p.act_stride + ((blk * 7 + g * 19) & 127), tagL + SLOT_ACT, l.fl + FL_HACT, g1, p.nap);
+                watch_end(l);
                 sweep_begin(l);
                 gather_qvec<DSL>(pl, xr, p.act5 + img * p.act_stride, D, tagL + SLOT_ACT, g, opq(lane), l.act);
                 if (has_dw1) gather_qvec<DSL>(pl, xr, p.act5, D, tagL + SLOT_ACT, g, opq(lane), l.actw);
@@ -1219,6 +1389,7 @@ struct R6 {
                 for (int i = 0; i < S; i++) s[i] = st[i * S + ln];
                 __builtin_amdgcn_sched_barrier(0);
                 unsigned dq[6];
+                watch_begin(l);
                 {
                     const int ptr[2] = {p.dl + ln, p.dl + (NBD > 2 ? 64 + ln : ln)};
                     const bool valid[2] = {true, NBD > 2};
@@ -1270,6 +1441,7 @@ struct R6 {
 #pragma unroll
                     for (int q = 0; q < 4; q++) dq[q] = (c & 1) ? dv[q].y : dv[q].x;
                 }
+                watch_end(l);
                 // 3. WKV6 (ggml_rwkv_wkv6): ln j owns value column j; {k, u, r, w}_i are broadcast through LDS
                 float4 * bc = reinterpret_cast<float4 *>(l.bc);
                 bc[ln] = make_float4(__uint_as_float(dq[1]), uu, __uint_as_float(dq[0]), wdec);
@@ -1307,14 +1479,18 @@ struct R6 {
             }
             R6STAMP(6); R6RSTAMP(21);
             // ---- E ----
+            watch_begin(l);
             gather_hint(pl, xr, p.yq + ((blk * 7 + g * 19) & 127), tagL + SLOT_YQ, l.fl + FL_HYQ, g1, p.nap);
+            watch_end(l);
             sweep_begin(l);
             gather_qvec<DSL>(pl, xr, p.yq, D, tagL + SLOT_YQ, g, opq(lane), l.yq);
             gather_meet(pl, l.fl + FL_GYQ, g1);
             sweep_end(l);
             R6STAMP(7); R6RSTAMP(22);
             // ---- F ----
+            watch_begin(l);
             gather_hint(pl, xr, p.xatt + ((blk * 37 + g * 211) & 1023), tagL + SLOT_XATT, l.fl + FL_HX, 2u * li + 2u, p.nap);
+            watch_end(l);
             sweep_begin(l);
             gather_x(pl, xr, p.xatt, tagL + SLOT_XATT, g, opq(lane), l.x);
             gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
@@ -1337,7 +1513,9 @@ struct R6 {
             }
             R6STAMP(10); R6RSTAMP(24);
             // ---- G ----
+            watch_begin(l);
             gather_hint(pl, xr, p.kq + ((blk * 5 + g * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap);
+            watch_end(l);
             sweep_begin(l);
             gather_qvec<KSL>(pl, xr, p.kq, F, tagL + SLOT_KQ, g, opq(lane), l.kq);
             gather_meet(pl, l.fl + FL_GKQ, g1);
@@ -1347,7 +1525,9 @@ struct R6 {
         if (p.logits) {   // the head: this wave's share of the last x hand-over (the consumers do the rest)
             const int li = p.n_layers;
             const unsigned tagL = base + (unsigned) li * 8u;
+            watch_begin(l);
             gather_hint(pl, xr, p.xffn + ((blk * 37 + g * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
+            watch_end(l);
             sweep_begin(l);
             gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, g, opq(lane), l.x);
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
@@ -1500,7 +1680,11 @@ static const RingVariant g_ring_variants[] = {
 #define RING_VARIANTS(FMT) \
     {FMT, 8, 4, 7, 3, k6_ring<FMT, 8, 4, 7, 3>},   /* D 4096, F 14336 (448 blocks: 7 steps, 1344 units), decay rank 128 */ \
     {FMT, 4, 2, 4, 2, k6_ring<FMT, 4, 2, 4, 2>}    /* D 2048, F 7168 (224 blocks: 4 steps, 672 units), decay rank 64 */
+#ifdef R6_ONLY_FMT   /* (register-budget experiments: one format, the 7B geometry) */
+    {R6_ONLY_FMT, 8, 4, 7, 3, k6_ring<R6_ONLY_FMT, 8, 4, 7, 3>},
+#else
     RING_VARIANTS(T_Q4_0), RING_VARIANTS(T_Q4_1), RING_VARIANTS(T_Q5_0), RING_VARIANTS(T_Q5_1), RING_VARIANTS(T_Q8_0),
+#endif
 };
 
 static int ring_variant(const Model & m, int n_cu) {
@@ -1719,6 +1903,9 @@ void * ring_v6_create(const Model & m) {
     auto snap = [](int w) { w &= ~3; return w < 4 ? 4 : (w > 52 ? 52 : w); };
     q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 48));
     q.thin = snap(env_int("RWKV_MI_RING_THIN", 16));
+    q.hthin = snap(env_int("RWKV_MI_RING_HTHIN", q.inflight));
+    q.look = env_int("RWKV_MI_RING_LOOK", 1);
+    if (q.look < 1) q.look = 1;
     q.nap = env_int("RWKV_MI_RING_NAP", 2);
     q.dbg = env_int("RWKV_MI_RING_DBG", 0);
     q.burst = env_int("RWKV_MI_RING_BURST", 24) / 4;   // in groups of four fills

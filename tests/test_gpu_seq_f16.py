@@ -1,0 +1,105 @@
+"""Sequence mode on F16 matrices on the matrix cores (k_mmf16_seq, csrc/kernels.hip): FP16 model files and the F16 low-rank stages of
+RWKV-7 (rwkv_graph.inc:416-447) / the F16 emb of a quantised checkpoint, T >= 32 tokens per pass.
+
+Contract (BASELINE north star; reference tests/test_eval_sequence_in_chunks.c:54, tests/test_tiny_rwkv.c:38-54): bit-exactness with the
+CPU path is asked for FP32 files; FP16 files are validated against recorded thresholds. The matrix core keeps ggml's operand rounding
+(activations -> fp16, exact products, f32 accumulation) but not the ORDER of the additions, so this arm is compared with the oracle
+within a tolerance that is stated here:
+
+  kernel level   |y - ref64| <= 2e-6 * sum_k |w_k x_k|    (ref64: the same fp16-rounded operands summed in float64; the oracle itself,
+                 with ggml's order, sits inside the same bound)
+  model level    logits: max |gpu - oracle| <= 1e-4 * (1 + max |oracle|), greedy token identical; state: same bound per layer slice
+
+The exact arm (RWKV_MI_SEQ_F16=valu, k_mvf in ggml's order) stays bit-identical to the oracle -- every other test of the suite runs on
+it (tests/conftest.py) -- and FP32 matrices never take the matrix-core kernel."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_lib import gpu_mul_mat, library, model, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def mfma_arm():
+    old = os.environ.get("RWKV_MI_SEQ_F16")
+    os.environ["RWKV_MI_SEQ_F16"] = "mfma"
+    yield
+    if old is None:
+        del os.environ["RWKV_MI_SEQ_F16"]
+    else:
+        os.environ["RWKV_MI_SEQ_F16"] = old
+
+
+# K: the RWKV-7 2.9B ranks (96, 64, 320) and row length (2560), the 169M row (768), fewer steps than waves (32); N: below a
+# 32-row wave tile, ragged, the ranks, more than one 128-row workgroup; T: one tile pair, ragged below / above 64, several token tiles
+@pytest.mark.parametrize("K,N,T", [(96, 2560, 64), (64, 130, 33), (320, 96, 100), (2560, 96, 32), (2560, 320, 130), (96, 40, 65), (768, 257, 97), (32, 70, 64)])
+def test_f16_gemm_against_float64_and_oracle(K, N, T):
+    rng = np.random.default_rng(K + 7 * N + 13 * T)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    x[0, :16] *= 30.0
+    x[T - 1] *= 0.01
+    t = O.TYPE_IDS["FP16"]
+    y = gpu_mul_mat(t, w.view(np.uint8).reshape(-1), K, N, x)
+    xh = x.astype(np.float16).astype(np.float64)
+    wd = w.astype(np.float64)
+    ref64 = xh @ wd.T
+    bound = 2e-6 * (np.abs(xh) @ np.abs(wd).T) + 1e-30
+    assert (np.abs(y - ref64) <= bound).all(), float((np.abs(y - ref64) / bound).max())
+    ref = O.mul_mat(t, w.view(np.uint8).reshape(-1), K, N, x)
+    assert (np.abs(ref - ref64) <= bound).all()
+    # the exact arm on the same operands IS the oracle
+    os.environ["RWKV_MI_SEQ_F16"] = "valu"
+    assert np.array_equal(gpu_mul_mat(t, w.view(np.uint8).reshape(-1), K, N, x), ref)
+    # ... and FP32 matrices never leave it
+    os.environ["RWKV_MI_SEQ_F16"] = "mfma"
+    w32 = w.astype(np.float32)
+    t32 = O.TYPE_IDS["FP32"]
+    assert np.array_equal(gpu_mul_mat(t32, w32.view(np.uint8).reshape(-1), K, N, x), O.mul_mat(t32, w32.view(np.uint8).reshape(-1), K, N, x))
+
+
+def _close(a, b, what):
+    tol = 1e-4 * (1.0 + float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol, (what, err, tol)
+    return err
+
+
+@pytest.mark.parametrize("name,fmt", [("test-v6", "FP16"), ("test-v5.2", "FP16"), ("test-v4", "FP16"), ("test-v7", "FP16"),
+                                      ("test-v7", "Q5_1"), ("slice-v7-2560", "Q5_1"), ("slice-v7-2560", "Q4_0")])
+@pytest.mark.parametrize("T", [32, 97])
+def test_sequence_pass_on_the_matrix_cores(tmp_path, name, fmt, T):
+    """FP16 files (every matrix F16) and directly generated quantised RWKV-7 files (low-rank stages F16, as in a converted checkpoint)."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS[name]
+    synth.write_model(p, spec, fmt, seed=59)
+    toks = [int((1103515245 * i + 12345) % spec.n_vocab) for i in range(T)]
+    om = O.OracleModel(p)
+    ol, ost = om.eval_sequence(toks, om.init_state())
+    m = model(p)
+    gl, gst = m.eval_sequence(toks, None)
+    err = _close(gl, ol, "logits")
+    assert int(np.argmax(gl)) == int(np.argmax(ol))
+    per = om.state_len // spec.n_layer
+    for layer in range(spec.n_layer):
+        _close(gst[layer * per:(layer + 1) * per], ost[layer * per:(layer + 1) * per], f"state of layer {layer}")
+    # not bit-identical (or this arm is not the one that ran) -- except where nothing F16 is long enough to take it
+    assert err > 0.0 or fmt != "FP16"
+    # the exact arm on the same file: bit-identical
+    os.environ["RWKV_MI_SEQ_F16"] = "valu"
+    el, est = m.eval_sequence(toks, None)
+    assert np.array_equal(el, ol) and np.array_equal(est, ost)
+    # single tokens never take the matrix-core kernel: decode is bit-exact on either setting
+    os.environ["RWKV_MI_SEQ_F16"] = "mfma"
+    st, ost2 = None, om.init_state()
+    for t in toks[:4]:
+        lg, st = m.eval(t, st)
+        olg, ost2 = om.eval(t, ost2)
+    assert np.array_equal(lg, olg) and np.array_equal(st, ost2)
+    m.free()
+    om.free()
