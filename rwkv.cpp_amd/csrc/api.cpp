@@ -104,9 +104,19 @@ RWKV_API bool rwkv_eval(struct rwkv_context * ctx, const uint32_t token, const f
     RW_CTX_CHECK(ctx, RWKV_ERROR_ARGS, false, token < n_vocab, "Token (%" PRId32 ") is out of range (0 .. %zu)", (int32_t) token, n_vocab - 1);
     if (!ctx->stages.empty()) return pipeline_eval(ctx, &token, 1, 1, state_in, state_out, logits_out);
     HIP_CTX_OK(ctx, hipSetDevice(ctx->model->device));
+    bool aborted = false;
+    if ((state_in || state_out) && forward_streamed_eligible(ctx)) {
+        // the state slices travel under the layers of the other groups (engine.hip, forward_streamed)
+        if (!upload_tokens(ctx, &token, 1)) return false;
+        if (!forward_streamed(ctx, logits_out != nullptr, state_in, state_out, logits_out, &aborted)) return false;
+        if (!aborted) return true;
+        // (poll time-out: the input state is complete on the device in the buffer the step read -- repeat on the per-layer launches)
+        ctx->cur ^= 1;
+        if (!run_tokens(ctx, &token, 1, logits_out != nullptr)) return false;
+        return fetch_outputs(ctx, state_out, logits_out);
+    }
     if (!state_from_host(ctx, state_in)) return false;
     if (!run_tokens(ctx, &token, 1, logits_out != nullptr)) return false;
-    bool aborted = false;
     if (!fetch_outputs(ctx, state_out, logits_out, &aborted)) return false;
     if (aborted) {
         // The persistent kernel gave up (device shared with another process' persistent kernel). It only writes the OTHER state

@@ -3,9 +3,11 @@
 // and T > 1 (sequence mode); state and weights never leave HBM between calls.
 #include "model.h"
 
+#include <condition_variable>
 #include <cstdarg>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 namespace rwkvmi {
 
@@ -200,6 +202,7 @@ static void drop_graphs(rwkv_context * ctx) {
 void destroy_context(rwkv_context * ctx) {
     if (!ctx) return;
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    if (ctx->abi_streamer) { abi_streamer_free(ctx->abi_streamer); ctx->abi_streamer = nullptr; }
     drop_graphs(ctx);
     for (int i = 0; i < 2; i++) if (ctx->state[i]) (void) hipFree(ctx->state[i]);
     if (ctx->scratch) (void) hipFree(ctx->scratch);
@@ -522,18 +525,24 @@ struct Runner {
         mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
     }
 
-    void run(bool want_logits) {
+    void run_embed() {
+        if (m.has_embed) launch_embed_ln0(*m.emb, ctx->d_tokens, T, D, f(m.ln0_w), f(m.ln0_b), b.x, st);
+    }
+    // layers [lb, le) of the stage (absolute layer ids); returns true when the launch also produced the logits (ring kernel, last layers)
+    bool run_layers(uint32_t lb, uint32_t le, bool want_logits) {
         const float * sin = ctx->state[ctx->cur];
         float * sout = ctx->state[ctx->cur ^ 1];
         const int64_t per_layer = m.state_per_layer();
-        if (m.has_embed) launch_embed_ln0(*m.emb, ctx->d_tokens, T, D, f(m.ln0_w), f(m.ln0_b), b.x, st);
-        bool head_done = false;
         if (T == 1 && ctx->mega) {
-            head_done = want_logits && m.has_head && mega_v6_folds_head(ctx->mega);
-            mega_v6_forward(ctx->mega, b.x, sin + (int64_t) m.layer_begin * per_layer, sout + (int64_t) m.layer_begin * per_layer, st, &ctx->prof,
-                            head_done ? ctx->d_logits : nullptr);
-        } else
-        for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
+            const bool whole = lb == m.layer_begin && le == m.layer_end;
+            const bool head_done = want_logits && m.has_head && le == m.layer_end && mega_v6_folds_head(ctx->mega);
+            const float * s0 = sin + (int64_t) m.layer_begin * per_layer;
+            float * o0 = sout + (int64_t) m.layer_begin * per_layer;
+            if (whole) mega_v6_forward(ctx->mega, b.x, s0, o0, st, &ctx->prof, head_done ? ctx->d_logits : nullptr);
+            else ring_v6_forward_range(ctx->mega, b.x, s0, o0, st, nullptr, head_done ? ctx->d_logits : nullptr, (int) (lb - m.layer_begin), (int) (le - m.layer_begin));
+            return head_done;
+        }
+        for (uint32_t i = lb; i < le; i++) {
             const LayerW & L = m.layers[i];
             const float * li = sin + (int64_t) i * per_layer;
             float * lo = sout + (int64_t) i * per_layer;
@@ -549,13 +558,19 @@ struct Runner {
             }
             ffn(L, li, lo);
         }
-        if (want_logits && m.has_head && !head_done) {
-            // ln_out on the last token only, then the head projection (rwkv_graph.inc:704-708, 851-854)
-            launch_layernorm(b.x + (T - 1) * D, 1, D, f(m.ln_out_w), f(m.ln_out_b), b.xlast, st);
-            const int64_t Tsave = T; T = 1;
-            mm(m.head, b.xlast, ctx->d_logits);
-            T = Tsave;
-        }
+        return false;
+    }
+    void run_head() {
+        // ln_out on the last token only, then the head projection (rwkv_graph.inc:704-708, 851-854)
+        launch_layernorm(b.x + (T - 1) * D, 1, D, f(m.ln_out_w), f(m.ln_out_b), b.xlast, st);
+        const int64_t Tsave = T; T = 1;
+        mm(m.head, b.xlast, ctx->d_logits);
+        T = Tsave;
+    }
+    void run(bool want_logits) {
+        run_embed();
+        const bool head_done = run_layers(m.layer_begin, m.layer_end, want_logits);
+        if (want_logits && m.has_head && !head_done) run_head();
     }
 };
 
@@ -574,6 +589,161 @@ bool forward(rwkv_context * ctx, int64_t T, bool want_logits) {
     ctx->cur ^= 1;
     HIP_CTX_OK(ctx, hipGetLastError());
     RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH | RWKV_ERROR_ALLOC, false, !r.failed, "a sequence-mode product could not be launched (out of device memory for the tile-major weight image?)");
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rwkv_eval with the caller's state STREAMED (rwkv_eval.inc:2-22,38-76; rwkv.h:106-108: state_in / state_out are host buffers on
+// every call). The plain form is upload (34.6 MB for the 7B) -> token -> download, serial: 2.97 ms per token against 1.54 ms with the
+// state resident (round 3: 337 vs 649 tokens/s). Here the token is cut into up to eight layer groups:
+//     this thread      for each group: upload its state slice (copy stream), record; the compute stream waits for THAT slice only and
+//                      runs the group's layers (the ring kernel on a layer range: one launch per group; the per-layer paths: their
+//                      launches), records "group done"
+//     download thread  for each group: a second copy stream waits for "group done" and brings the group's new state slice back
+// so the PCIe traffic of both directions runs under the layers of other groups; exposed are the first slice's upload, the last
+// slice's download and the logits. Nothing is assumed about the caller's memory (pageable copies through the runtime's staging path,
+// both directions at once from two threads); state_in == state_out is fine (a slice is read before its group runs, written after).
+// The state on the device is complete afterwards (state[cur]): a poll time-out of the persistent kernel falls back as before.
+// ---------------------------------------------------------------------------------------------------------------
+struct AbiStreamer {
+    hipStream_t up = nullptr, down = nullptr;
+    std::vector<hipEvent_t> ev_up, ev_done;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    // job of the download thread
+    int n_groups = 0, published = 0, finished = 0;     // groups of this call / "group done" recorded so far / downloaded so far
+    bool quit = false, failed = false;
+    int device = 0;
+    float * h_out = nullptr; const float * d_out = nullptr;
+    std::vector<std::pair<int64_t, int64_t>> slices;    // (offset, count) in floats per group
+    uint64_t call = 0, seen = 0;
+
+    void run() {
+        (void) hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || call != seen; });
+            if (quit) return;
+            seen = call;
+            int g = 0;
+            while (g < n_groups) {
+                cv.wait(lk, [&] { return quit || published > g || g >= n_groups; });
+                if (quit) return;
+                if (g >= n_groups) break;       // (the call failed before this group ran)
+                const auto sl = slices[(size_t) g];
+                hipEvent_t ev = ev_done[(size_t) g];
+                lk.unlock();
+                bool ok = hipStreamWaitEvent(down, ev, 0) == hipSuccess &&
+                          hipMemcpyAsync(h_out + sl.first, d_out + sl.first, (size_t) sl.second * sizeof(float), hipMemcpyDeviceToHost, down) == hipSuccess &&
+                          hipStreamSynchronize(down) == hipSuccess;
+                lk.lock();
+                if (!ok) failed = true;
+                g++;
+                finished = g;
+                cv.notify_all();
+            }
+        }
+    }
+};
+
+void abi_streamer_free(void * p) {
+    AbiStreamer * a = (AbiStreamer *) p;
+    if (!a) return;
+    { std::lock_guard<std::mutex> lk(a->mu); a->quit = true; }
+    a->cv.notify_all();
+    if (a->worker.joinable()) a->worker.join();
+    for (hipEvent_t e : a->ev_up) (void) hipEventDestroy(e);
+    for (hipEvent_t e : a->ev_done) (void) hipEventDestroy(e);
+    if (a->up) (void) hipStreamDestroy(a->up);
+    if (a->down) (void) hipStreamDestroy(a->down);
+    delete a;
+}
+
+bool forward_streamed_eligible(const rwkv_context * ctx) {
+    const char * e = getenv("RWKV_MI_ABI_STREAM");       // 0: off, 1: whatever the size of the state (tests), unset: from 4 MB of state
+    if ((e && e[0] == '0') || !ctx->stages.empty() || !ctx->owns_stream) return false;
+    const Model & m = *ctx->model;
+    if (m.layer_end - m.layer_begin < 2 || !m.has_embed || !m.has_head) return false;
+    if (ctx->mega && mega_v6_kind(ctx->mega) != 2) return false;     // (the register-prefetch kernel has no layer-range launch)
+    if (e && e[0] == '1') return true;
+    return (size_t) m.state_len() * sizeof(float) >= ((size_t) 4 << 20);   // small states: the serial copies are already cheap
+}
+
+// One token (already in ctx->d_tokens) from the caller's state_in (nullptr: the fresh state) into the caller's state_out (nullptr: none).
+// On return the streams are drained; *aborted reports a poll time-out of the persistent kernel (the caller repeats the step).
+bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, float * h_out, float * h_logits, bool * aborted) {
+    *aborted = false;
+    Model & m = *ctx->model;
+    if (!ensure_scratch(ctx, 1)) return false;
+    AbiStreamer * a = (AbiStreamer *) ctx->abi_streamer;
+    if (!a) {
+        a = new (std::nothrow) AbiStreamer();
+        RW_CTX_CHECK(ctx, RWKV_ERROR_ALLOC, false, a != nullptr, "out of memory");
+        a->device = m.device;
+        bool ok = hipStreamCreateWithFlags(&a->up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&a->down, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 8 && ok; i++) {
+            hipEvent_t e1 = nullptr, e2 = nullptr;
+            ok = hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
+            if (e1) a->ev_up.push_back(e1);
+            if (e2) a->ev_done.push_back(e2);
+        }
+        if (!ok) { abi_streamer_free(a); RW_CTX_CHECK(ctx, RWKV_ERROR_ALLOC, false, false, "cannot create the copy streams of the streamed rwkv_eval"); }
+        a->worker = std::thread([a] { a->run(); });
+        ctx->abi_streamer = a;
+    }
+    const uint32_t L = m.layer_end - m.layer_begin;
+    const int G = (int) (L < 8 ? L : 8);
+    const int64_t per = m.state_per_layer();
+    float * sin = ctx->state[ctx->cur];
+    float * sout = ctx->state[ctx->cur ^ 1];
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    {
+        std::lock_guard<std::mutex> lk(a->mu);
+        a->slices.clear();
+        for (int g = 0; g < G; g++) {
+            const uint32_t lb = m.layer_begin + (uint32_t) ((uint64_t) L * g / G), le = m.layer_begin + (uint32_t) ((uint64_t) L * (g + 1) / G);
+            ranges.push_back({lb, le});
+            a->slices.push_back({(int64_t) lb * per, (int64_t) (le - lb) * per});
+        }
+        a->n_groups = h_out ? G : 0; a->published = 0; a->finished = 0; a->failed = false;
+        a->h_out = h_out; a->d_out = sout;
+        a->call++;
+    }
+    a->cv.notify_all();
+    Runner r{ctx, m, ctx->stream, 1, m.n_embed(), m.head_count, m.head_size, ctx->b};
+    if (!h_in) { if (!state_from_host(ctx, nullptr)) return false; }
+    r.run_embed();
+    const bool chained = ctx->mega != nullptr;
+    if (chained) mega_chain_begin(ctx);
+    bool ok = true, head_done = false;
+    for (int g = 0; g < G && ok; g++) {
+        const auto sl = a->slices[(size_t) g];
+        if (h_in) {
+            ok = hipMemcpyAsync(sin + sl.first, h_in + sl.first, (size_t) sl.second * sizeof(float), hipMemcpyHostToDevice, a->up) == hipSuccess &&
+                 hipEventRecord(a->ev_up[(size_t) g], a->up) == hipSuccess && hipStreamWaitEvent(ctx->stream, a->ev_up[(size_t) g], 0) == hipSuccess;
+            if (!ok) break;
+        }
+        head_done = r.run_layers(ranges[(size_t) g].first, ranges[(size_t) g].second, want_logits) || head_done;
+        ok = hipEventRecord(a->ev_done[(size_t) g], ctx->stream) == hipSuccess;
+        if (ok && h_out) { { std::lock_guard<std::mutex> lk(a->mu); a->published = g + 1; } a->cv.notify_all(); }
+    }
+    if (chained) mega_chain_end(ctx);
+    if (ok && want_logits && !head_done) r.run_head();
+    if (ok && h_logits) ok = hipMemcpyAsync(h_logits, ctx->d_logits, (size_t) m.n_vocab() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    const bool ctl_ok = !ctx->mega || mega_v6_ctl_fetch(ctx->mega, ctx->stream);
+    const bool sync_ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    {   // the download thread must be done with this call whatever happened above (it holds the caller's pointer)
+        std::unique_lock<std::mutex> lk(a->mu);
+        if (!ok) { a->n_groups = a->published; }     // (groups that never ran are not downloaded)
+        a->cv.notify_all();
+        a->cv.wait(lk, [&] { return a->finished >= a->n_groups; });
+        ok = ok && !a->failed;
+    }
+    ctx->cur ^= 1;
+    RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, ok && sync_ok, "HIP error in the streamed rwkv_eval: %s", hipGetErrorString(hipGetLastError()));
+    RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH | RWKV_ERROR_ALLOC, false, !r.failed, "a product could not be launched");
+    if (ctx->mega && (!ctl_ok || mega_v6_aborted_cached(ctx->mega))) { recover_from_abort(ctx); *aborted = true; }
     return true;
 }
 

@@ -17,6 +17,9 @@
 //    which the tests assert with array_equal.
 #include "kdev.h"
 
+#include <mutex>
+#include <vector>
+
 namespace rwkvmi {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -275,11 +278,8 @@ static void launch_mvf_t(const DevTensor & W, const float * x, int64_t ldx, int6
 // thresholds (tests/test_tiny_rwkv.c:38-54). FP32 matrices therefore stay on k_mvf (memcmp equality), F16 matrices take this kernel
 // from k_mfma_min_tokens tokens per pass on (RWKV_MI_SEQ_F16=valu keeps them on k_mvf: the bit-exact A/B arm of the tests).
 //
-// A workgroup = one tile of 32 weight rows x 64 tokens (two MFMA tiles sharing the weight operand), its four waves split K; operands go
-// straight from global memory / L2 into the MFMA operand registers (lane l: token or row l & 31, k = 8 (l >> 5) .. + 7 of the
-// 16-wide step: one 16-byte weight load and two 32-byte activation loads per lane and step): these products are short (K = 64 .. 320
-// for the second low-rank stages, N = 64 .. 320 for the first) and were 22 % of an RWKV-7 2.9B pass on the VALU kernel (62 of
-// 281 ms, round-3 review).
+// These products are short (K = 64 .. 320 for the second low-rank stages, N = 64 .. 320 for the first) and were 22 % of an RWKV-7 2.9B
+// pass on the VALU kernel (62 of 281 ms, round-3 review).
 // ---------------------------------------------------------------------------------------------------------------
 typedef _Float16 mf_h8 __attribute__((ext_vector_type(8)));
 typedef float mf_f16v __attribute__((ext_vector_type(16)));
@@ -291,55 +291,116 @@ __device__ __forceinline__ mf_h8 mf_cvt8(const float4 a, const float4 b) {
     return h;
 }
 
-__global__ __launch_bounds__(256) void k_mmf16_seq(const uint16_t * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x, int64_t ldx,
-                                                   int64_t T, float * __restrict__ y, int64_t ldy, Epi epi) {
-    __shared__ __attribute__((aligned(16))) float l_part[3][32][64];   // the partial tiles of waves 1..3: [wave][register][lane]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// LDS-tiled: a workgroup (4 waves) owns 64 tokens x 64 weight rows, K walks in chunks of 64 through two LDS buffers. Global loads
+// are row-contiguous (activations: 256 bytes of f32 per token and chunk, rounded to fp16 on the way into LDS; weights: 128 bytes per
+// row); the MFMA operands come out of LDS as 16-byte reads on a 144-byte row pitch (conflict-free for the 32 rows of a lane group).
+// (The first version fed the operands straight from global memory: 64 different cache lines per activation load instruction -- 20.0 k
+// tokens/s on the RWKV-7 2.9B pass against 18.4 k on the VALU kernel.) Few-tile shapes (the first low-rank stages: N = 64 .. 320)
+// additionally split K over blockIdx.z; k_mmf16_combine adds the parts in part order (deterministic) and applies the epilogue.
+constexpr int MF_KC = 64, MF_PITCH = 72;      // chunk of K, LDS row pitch in halfs
+
+struct MfArgs {
+    const uint16_t * W; const float * x; float * y; float * part;
+    int64_t N, K, ldx, T, ldy; int ksplit;
+    Epi epi;
+};
+
+__global__ __launch_bounds__(256) void k_mmf16_seq(MfArgs p) {
+    __shared__ __attribute__((aligned(16))) _Float16 l_x[2][64 * MF_PITCH];
+    __shared__ __attribute__((aligned(16))) _Float16 l_w[2][64 * MF_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
-    const int64_t n0 = (int64_t) blockIdx.x * 32, t0 = (int64_t) blockIdx.y * 64;
-    const int64_t nrow = n0 + i < N ? n0 + i : N - 1;
-    const int64_t ta = t0 + i < T ? t0 + i : T - 1, tb = t0 + 32 + i < T ? t0 + 32 + i : T - 1;
-    // the four waves of a workgroup share ONE 32-row x 64-token tile and split K: the first low-rank stages have 64 .. 320 rows (2 .. 10
-    // row tiles) against 2560-long rows -- with one K range per tile 16 - 48 workgroups walked 160 dependent steps each and the product
-    // ran slower than on the VALU kernel; the partial tiles are added in wave order (deterministic)
-    const int64_t steps = K / 16;
-    const int64_t s_lo = steps * wave / 4, s_hi = steps * (wave + 1) / 4;
-    const uint16_t * wp = W + nrow * K + 8 * kh;
-    const float * xa = x + ta * ldx + 8 * kh, * xb = x + tb * ldx + 8 * kh;
-    mf_f16v acc0, acc1;
+    const int64_t n0 = (int64_t) blockIdx.x * 64, t0 = (int64_t) blockIdx.y * 64;
+    const int tw = wave & 1, nw = wave >> 1;                      // this wave's 32-token x 32-row quadrant
+    // K range of this part
+    const int64_t chunks = (p.K + MF_KC - 1) / MF_KC;
+    const int64_t c_lo = chunks * blockIdx.z / p.ksplit, c_hi = chunks * (blockIdx.z + 1) / p.ksplit;
+    // staging roles: activations 4 x float4 per thread (row tid / 16 + 16 j, columns 4 (tid % 16) ..), weights 2 x 16 bytes (row tid / 8 + 32 j)
+    const int xr = tid >> 4, xc = (tid & 15) * 4, wr = tid >> 3, wc = (tid & 7) * 8;
+    float4 xv[4]; int4 wv[2];
+    auto fetch = [&](int64_t c) {
+        const int64_t k0 = c * MF_KC;
 #pragma unroll
-    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-#pragma unroll 4
-    for (int64_t sidx = s_lo; sidx < s_hi; sidx++) {
-        const int64_t k0 = sidx * 16;
-        const int4 wraw = *reinterpret_cast<const int4 *>(wp + k0);
-        const float4 a0 = *reinterpret_cast<const float4 *>(xa + k0), a1 = *reinterpret_cast<const float4 *>(xa + k0 + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(xb + k0), b1 = *reinterpret_cast<const float4 *>(xb + k0 + 4);
-        mf_h8 wv;
-        __builtin_memcpy(&wv, &wraw, 16);
-        // D[token][row] += A[token][k] * B[k][row]: A = the activations (fp16-rounded here, round-to-nearest-even like ggml's fp32 -> fp16), B = the weights
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mf_cvt8(a0, a1), wv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(mf_cvt8(b0, b1), wv, acc1, 0, 0, 0);
-    }
-    if (wave > 0) {
+        for (int j = 0; j < 4; j++) {
+            const int64_t t = t0 + xr + 16 * j;
+            const bool ok = t < p.T && k0 + xc < p.K;
+            xv[j] = ok ? *reinterpret_cast<const float4 *>(p.x + t * p.ldx + k0 + xc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-        for (int r = 0; r < 16; r++) { l_part[wave - 1][r][lane] = acc0[r]; l_part[wave - 1][16 + r][lane] = acc1[r]; }
-    }
+        for (int j = 0; j < 2; j++) {
+            const int64_t n = n0 + wr + 32 * j;
+            const bool ok = n < p.N && k0 + wc < p.K;
+            wv[j] = ok ? *reinterpret_cast<const int4 *>(p.W + n * p.K + k0 + wc) : make_int4(0, 0, 0, 0);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 h; h[0] = (_Float16) xv[j].x; h[1] = (_Float16) xv[j].y; h[2] = (_Float16) xv[j].z; h[3] = (_Float16) xv[j].w;   // round to nearest even, like ggml's fp32 -> fp16
+            *reinterpret_cast<h4 *>(&l_x[buf][(xr + 16 * j) * MF_PITCH + xc]) = h;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) *reinterpret_cast<int4 *>(&l_w[buf][(wr + 32 * j) * MF_PITCH + wc]) = wv[j];
+    };
+    mf_f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    if (c_lo < c_hi) { fetch(c_lo); stash(0); }
     __syncthreads();
-    if (wave > 0) return;
+    for (int64_t c = c_lo; c < c_hi; c++) {
+        const int buf = (int) ((c - c_lo) & 1);
+        if (c + 1 < c_hi) fetch(c + 1);
+        const _Float16 * ax = &l_x[buf][(32 * tw + i) * MF_PITCH + 8 * kh];
+        const _Float16 * bw = &l_w[buf][(32 * nw + i) * MF_PITCH + 8 * kh];
 #pragma unroll
-    for (int w = 0; w < 3; w++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) { acc0[r] += l_part[w][r][lane]; acc1[r] += l_part[w][16 + r][lane]; }
+        for (int kk = 0; kk < MF_KC / 16; kk++) {
+            const mf_h8 a = *reinterpret_cast<const mf_h8 *>(ax + 16 * kk);
+            const mf_h8 b = *reinterpret_cast<const mf_h8 *>(bw + 16 * kk);
+            // D[token][row] += A[token][k] * B[k][row]: A = the activations, B = the weights (k of lane l: 8 (l >> 5) .. + 7 of the 16-wide step)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        }
+        if (c + 1 < c_hi) stash(buf ^ 1);
+        __syncthreads();
+    }
     // C / D layout: column (= weight row) lane & 31, row (= token) (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    const int64_t n = n0 + i;
-    if (n >= N) return;
+    const int64_t n = n0 + 32 * nw + i;
+    if (p.ksplit == 1) {
+        if (n < p.N) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t t = t0 + 32 * tw + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (t < p.T) p.y[t * p.ldy + n] = apply_epi(p.epi, acc[r], t, n, p.ldy);
+            }
+        }
+        return;
+    }
+    // split K: every part stores its tile ([tile][part][reg][thread]); k_mmf16_combine adds the parts in order (a second launch: partial
+    // tiles written on one XCD are only guaranteed visible to another at a kernel boundary)
+    const int64_t tile = (int64_t) blockIdx.y * gridDim.x + blockIdx.x;
+    float * mine = p.part + ((tile * p.ksplit + blockIdx.z) * 16) * 256;
+#pragma unroll
+    for (int r = 0; r < 16; r++) mine[r * 256 + tid] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void k_mmf16_combine(MfArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5, tw = wave & 1, nw = wave >> 1;
+    const int64_t n0 = (int64_t) blockIdx.x * 64, t0 = (int64_t) blockIdx.y * 64;
+    const int64_t tile = (int64_t) blockIdx.y * gridDim.x + blockIdx.x;
+    const float * base = p.part + (tile * p.ksplit * 16) * 256;
+    float sum[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) sum[r] = base[r * 256 + tid];
+    for (int z = 1; z < p.ksplit; z++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sum[r] += base[((int64_t) z * 16 + r) * 256 + tid];
+    const int64_t n = n0 + 32 * nw + i;
+    if (n >= p.N) return;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const int64_t tr = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int64_t t1 = t0 + tr, t2 = t0 + 32 + tr;
-        if (t1 < T) y[t1 * ldy + n] = apply_epi(epi, acc0[r], t1, n, ldy);
-        if (t2 < T) y[t2 * ldy + n] = apply_epi(epi, acc1[r], t2, n, ldy);
+        const int64_t t = t0 + 32 * tw + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (t < p.T) p.y[t * p.ldy + n] = apply_epi(p.epi, sum[r], t, n, p.ldy);
     }
 }
 
@@ -348,11 +409,39 @@ static bool seq_f16_on_mfma() {   // (read per call: the test suite runs both ar
     return !(e && e[0] == 'v');
 }
 
+// workspace of the split-K form (partial tiles), one per device and STREAM SLOT: launches of one stream are ordered, so a stream can
+// reuse its workspace launch after launch; contexts (= streams) of one device get different slots
+static std::mutex g_mf_mu;
+constexpr int64_t MF_MAX_TILES = 128, MF_MAX_SPLIT = 8;
+struct MfWs { int dev; hipStream_t st; float * part; };
+static std::vector<MfWs> g_mf_ws;
+static float * mf_workspace(int dev, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mf_mu);
+    for (const MfWs & w : g_mf_ws) if (w.dev == dev && w.st == st) return w.part;
+    float * part = nullptr;
+    if (hipMalloc((void **) &part, (size_t) MF_MAX_TILES * MF_MAX_SPLIT * 16 * 256 * sizeof(float)) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    g_mf_ws.push_back({dev, st, part});
+    return part;
+}
+
 void launch_matvec_f(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
-    if (W.type == T_F16 && T >= 32 && W.cols() % 16 == 0 && ldx % 4 == 0 && seq_f16_on_mfma()) {
+    if (W.type == T_F16 && T >= 32 && W.cols() % 8 == 0 && ldx % 4 == 0 && seq_f16_on_mfma()) {
         const int64_t N = W.rows(), K = W.cols();
-        hipLaunchKernelGGL(k_mmf16_seq, dim3((unsigned) ((N + 31) / 32), (unsigned) ((T + 63) / 64)), dim3(256), 0, st,
-                           (const uint16_t *) W.data, N, K, x, ldx, T, y, ldy, epi);
+        MfArgs a{};
+        a.W = (const uint16_t *) W.data; a.x = x; a.y = y; a.N = N; a.K = K; a.ldx = ldx; a.T = T; a.ldy = ldy; a.epi = epi; a.ksplit = 1;
+        const int64_t tiles = ((N + 63) / 64) * ((T + 63) / 64), chunks = (K + MF_KC - 1) / MF_KC;
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        if (tiles < 128 && chunks >= 8 && tiles <= MF_MAX_TILES) {
+            int ks = (int) (256 / tiles);
+            ks = ks > (int) MF_MAX_SPLIT ? (int) MF_MAX_SPLIT : ks;
+            ks = ks > (int) (chunks / 2) ? (int) (chunks / 2) : ks;
+            float * part = ks >= 2 ? mf_workspace(dev, st) : nullptr;
+            if (part) { a.ksplit = ks; a.part = part; }
+        }
+        const dim3 grid((unsigned) ((N + 63) / 64), (unsigned) ((T + 63) / 64), (unsigned) a.ksplit);
+        hipLaunchKernelGGL(k_mmf16_seq, grid, dim3(256), 0, st, a);
+        if (a.ksplit > 1) hipLaunchKernelGGL(k_mmf16_combine, dim3(grid.x, grid.y), dim3(256), 0, st, a);
         return;
     }
     if (W.type == T_F16) launch_mvf_t<true>(W, x, ldx, T, y, ldy, epi, st);

@@ -161,6 +161,8 @@ struct rwkv_context {
     hipEvent_t handoff_ev = nullptr;   // (stage contexts) residual stream handed to the next stage
     hipEvent_t consumed_ev = nullptr;  // (stage contexts) this stage is done with the pass whose input it was handed
 
+    void * abi_streamer = nullptr;   // copy streams + download thread of the streamed rwkv_eval (engine.hip), created on first use
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t mega_done = nullptr;   // completion of this context's latest persistent-kernel launch (engine.hip: launches are chained per device)
 
@@ -229,6 +231,7 @@ int      mega_v6_kind(void * h);            // 1: register prefetch (mega_v6.hip
 void *   ring_v6_create(const Model & m);
 void     ring_v6_destroy(void * h);
 void     ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits);
+void     ring_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1);
 bool     ring_v6_folds_head(void * h);
 bool     ring_v6_ctl_fetch(void * h, hipStream_t st);
 bool     ring_v6_aborted_cached(void * h);
@@ -249,6 +252,10 @@ bool pipeline_state_store(rwkv_context * front, float * state_out);
 bool pipeline_decode_greedy(rwkv_context * const * fronts, size_t n_streams, const uint32_t * first_tokens, size_t n_tokens, uint32_t * tokens_out, float * elapsed_ms);
 // after a poll time-out of the persistent kernel: drain, clear, drop the persistent path (see engine.hip)
 void recover_from_abort(rwkv_context * ctx);
+// rwkv_eval with the caller's state streamed group by group under the layers (engine.hip)
+bool forward_streamed_eligible(const rwkv_context * ctx);
+bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, float * h_out, float * h_logits, bool * aborted);
+void abi_streamer_free(void * p);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
 bool forward_decode(rwkv_context * ctx, bool want_logits);
 // grows the per-context activation scratch to hold T tokens

@@ -41,6 +41,7 @@ struct R6P {
     int act_stride;                                    // units between the five mix images
     unsigned * ctl;                                    // [0] tag generation, [1] abort
     const unsigned char * stream; const R6Cu * cus;     // the per-workgroup weight streams
+    int layer0, layers_total;                          // this launch covers layers [layer0, layer0 + n_layers) of the stage's layers_total (the streamed rwkv_eval cuts a token into groups)
     int F, DR, R, H;
     int head_wg0;                                      // first of the H workgroups whose comm wave runs a WKV head
     unsigned ring_bytes, mirror_bytes;                 // LDS ring (multiple of 4 KiB) and how much of its head is repeated behind its end
@@ -590,8 +591,14 @@ struct R6 {
     static __device__ __forceinline__ void loader_main(const R6P & p, const Lds & l, int lane) {
         const int wave = 0;
         const R6Cu cu = p.cus[blockIdx.x];
-        const unsigned total = __builtin_amdgcn_readfirstlane(p.logits ? cu.chunks_head : cu.chunks);          // fills (multiple of four)
-        const unsigned long long src0 = (unsigned long long) p.stream + cu.base;
+        // fills of this launch (multiple of four): the whole stage's as precomputed, or a layer range's (+ the head's rows behind the last layer)
+        unsigned total_ = p.logits ? cu.chunks_head : cu.chunks;
+        if (p.n_layers != p.layers_total) {
+            const unsigned long long bytes = (unsigned long long) p.n_layers * cu.layer_bytes + (p.logits ? (unsigned long long) rg_head(p.n_vocab, D).bytes : 0ull);
+            total_ = (unsigned) ((bytes + 4 * RG_CHUNK - 1) / (4 * RG_CHUNK)) * 4u;
+        }
+        const unsigned total = __builtin_amdgcn_readfirstlane(total_);
+        const unsigned long long src0 = (unsigned long long) p.stream + cu.base + (unsigned long long) p.layer0 * cu.layer_bytes;
         const unsigned RB = __builtin_amdgcn_readfirstlane(p.ring_bytes), MIR = __builtin_amdgcn_readfirstlane(p.mirror_bytes);
         const unsigned ring_m0 = __builtin_amdgcn_readfirstlane((unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) l.ring);
         const unsigned voff = (unsigned) lane * 16u;
@@ -1882,7 +1889,7 @@ void * ring_v6_create(const Model & m) {
     ok = ok && hipMemcpy(rg->ctl, init, sizeof(init), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok || hipDeviceSynchronize() != hipSuccess) { ring_v6_destroy(rg); return nullptr; }
     R6P & q = rg->proto;
-    q.layers = rs->d_layers; q.n_layers = rs->n_layers;
+    q.layers = rs->d_layers; q.n_layers = rs->n_layers; q.layer0 = 0; q.layers_total = rs->n_layers;
     q.arena = (const unsigned char *) m.arena; q.w2b = rs->w2b;
     q.state_stride = m.state_per_layer();
     q.xch = rg->xch; q.xch_bytes = (unsigned) (units * 16);
@@ -1937,10 +1944,18 @@ bool ring_v6_folds_head(void * h) { return ((RingV6 *) h)->sh->head; }
 
 // logits != nullptr (only when ring_v6_folds_head): ln_out + head run inside the launch and the logits land there
 void ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits) {
+    ring_v6_forward_range(h, x, sin, sout, st, pf, logits, 0, ((RingV6 *) h)->sh->n_layers);
+}
+
+// Layers [l0, l1) of the stage in one launch (sin / sout: state of the stage's FIRST layer; x: the residual stream in plain memory, read
+// by the first and written by the last layer of the launch). logits (only with l1 == the stage's last layer): ln_out + head inside.
+void ring_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1) {
     RingV6 * rg = (RingV6 *) h;
     R6P q = rg->proto;
-    q.x = x; q.sin = sin; q.sout = sout;
-    q.logits = rg->sh->head ? logits : nullptr;
+    q.x = x;
+    q.layers = rg->sh->d_layers + l0; q.n_layers = l1 - l0; q.layer0 = l0; q.layers_total = rg->sh->n_layers;
+    q.sin = sin + (long long) l0 * q.state_stride; q.sout = sout + (long long) l0 * q.state_stride;
+    q.logits = (rg->sh->head && l1 == rg->sh->n_layers) ? logits : nullptr;
     const RingKernel fn = g_ring_variants[rg->sh->variant].fn;
     if (pf && pf->on) {
         if (pf->used * 2 + 2 > pf->events.size()) {
@@ -1948,7 +1963,7 @@ void ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipSt
             (void) hipEventCreate(&a); (void) hipEventCreate(&c);
             pf->events.push_back(a); pf->events.push_back(c); pf->bytes.push_back(0);
         }
-        pf->bytes[pf->used] = rg->sh->bytes + (q.logits ? rg->sh->bytes_head : 0);
+        pf->bytes[pf->used] = rg->sh->bytes * (uint64_t) (l1 - l0) / (uint64_t) rg->sh->n_layers + (q.logits ? rg->sh->bytes_head : 0);
         hipExtLaunchKernelGGL(fn, dim3((unsigned) rg->sh->n_blocks), dim3(512), (uint32_t) rg->sh->lds, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, q);
         pf->used++;
     } else {
