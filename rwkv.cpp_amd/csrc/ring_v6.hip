@@ -271,13 +271,12 @@ struct R6 {
     static constexpr int S = 64, NBLK = RG_NBLK, NC = RG_NC, NG = RG_NC + 1;   // NG: waves that gather (consumers + comm)
     static constexpr int D = EPT * 512;
     static constexpr int nb = D / 32;
-    static constexpr int UD = nb / 64;                       // steps of a D-long row
+    static constexpr int UD = (nb + 63) / 64;                // steps of a D-long row (the last one may be short: zero blocks in the stream)
     static constexpr int RE = D / NBLK;                      // output / receptance / value rows per workgroup
     static constexpr int XT = (RE + NC - 1) / NC;            // rows per x unit (<= 3)
-    static constexpr int V4 = D / 1024;                      // float4 groups per prologue thread (256 threads)
     static constexpr int XSL = (NBLK * NC + NG * 64 - 1) / (NG * 64);   // gather slots per lane for an x-like vector
     static constexpr int DSL = (3 * nb + NG * 64 - 1) / (NG * 64);      // ... for a quantised D-vector
-    static_assert(UD >= 1 && XT <= 3 && D % 1024 == 0 && RE >= NC, "geometry");
+    static_assert(UD >= 1 && XT <= 3 && D % 512 == 0 && nb % RG_HSTEPS == 0 && RE >= NC, "geometry");
 
     struct Lds {
         float *x, *tl, *bc, *out, *misc;
@@ -403,8 +402,11 @@ struct R6 {
     // part behind them -- LayerNorm affine, token-shift mixes, quantisation: most of a prologue -- is spread over all six consumer waves
     // where the row divides that way (D = 4096: 1024 groups of four elements = three per thread of waves 0..3 + two per thread of
     // waves 4, 5, which used to idle through the prologue); every 32-block stays inside eight consecutive lanes.
-    static constexpr int SLO = V4 == 4 ? 3 : V4;        // groups of four elements per thread of consumer waves 0..3
-    static constexpr int SHI = V4 == 4 ? 2 : 0;         // ... of consumer waves 4, 5
+    // D / 4 groups of four elements = 256 SLO + 128 SHI: D = 4096 -> 3 + 2, 2560 -> 2 + 1, 2048 -> 2 + 0
+    static constexpr int Q128 = D / 512;                // groups of four per 128 threads
+    static constexpr int SLO = (Q128 + 2) / 3;          // groups of four elements per thread of consumer waves 0..3
+    static constexpr int SHI = Q128 - 2 * SLO;          // ... of consumer waves 4, 5
+    static_assert(SHI >= 0 && SHI <= SLO, "prologue slots");
     static constexpr int SMAX = SLO > SHI ? SLO : SHI;
     static __device__ __forceinline__ int pslots(int c) { return c < 4 ? SLO : SHI; }
     // element index of slot k of consumer wave c (a missing slot repeats slot 0: loads stay unconditional)
@@ -1154,8 +1156,9 @@ struct R6 {
             const float scale = ln_stats(pl, l, pt, lane, 2u * li + 1u);
             const float * lw = ar.f(p.lnout_w), * lb = ar.f(p.lnout_b);
 #pragma unroll
-            for (int u = 0; u < V4; u++) {
+            for (int u = 0; u < (D + 1023) / 1024; u++) {
                 const int i = pt * 4 + u * 1024;
+                if (i >= D) break;
                 const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
                 const float4 w4 = *reinterpret_cast<const float4 *>(lw + i), b4 = *reinterpret_cast<const float4 *>(lb + i);
                 const float xs[4] = {xc.x, xc.y, xc.z, xc.w}, ws[4] = {w4.x, w4.y, w4.z, w4.w}, bs[4] = {b4.x, b4.y, b4.z, b4.w};
@@ -1685,8 +1688,9 @@ typedef void (*RingKernel)(R6P);
 struct RingVariant { int fmt, ept, nbd, uf, ksl; RingKernel fn; };
 static const RingVariant g_ring_variants[] = {
 #define RING_VARIANTS(FMT) \
-    {FMT, 8, 4, 7, 3, k6_ring<FMT, 8, 4, 7, 3>},   /* D 4096, F 14336 (448 blocks: 7 steps, 1344 units), decay rank 128 */ \
-    {FMT, 4, 2, 4, 2, k6_ring<FMT, 4, 2, 4, 2>}    /* D 2048, F 7168 (224 blocks: 4 steps, 672 units), decay rank 64 */
+    {FMT, 8, 4, 7, 3, k6_ring<FMT, 8, 4, 7, 3>},   /* D 4096, F 14336 (448 blocks: 7 steps, 1344 units), decay rank 128: RWKV-6 7B */ \
+    {FMT, 5, 2, 5, 2, k6_ring<FMT, 5, 2, 5, 2>},   /* D 2560, F 8960 (280 blocks: 5 steps, 840 units), decay rank 64: RWKV-6 3B */ \
+    {FMT, 4, 2, 4, 2, k6_ring<FMT, 4, 2, 4, 2>}    /* D 2048, F 7168 (224 blocks: 4 steps, 672 units), decay rank 64: RWKV-6 1.6B */
 #ifdef R6_ONLY_FMT   /* (register-budget experiments: one format, the 7B geometry) */
     {R6_ONLY_FMT, 8, 4, 7, 3, k6_ring<R6_ONLY_FMT, 8, 4, 7, 3>},
 #else

@@ -106,3 +106,39 @@ def test_rwkv6_world_vocabulary_head(tmp_path, kind):
     finally:
         del os.environ["RWKV_MI_PERSIST"]
         del os.environ["RWKV_MI_NO_AUTOTUNE"]
+
+
+@pytest.mark.parametrize("fmt", ["Q4_0", "Q5_1", "Q8_0"])
+def test_rwkv6_3b_geometry_on_the_ring_kernel(tmp_path, fmt):
+    """RWKV-6-World-3B: D = 2560 (80 blocks per row: a short second 64-block step in every D-long record), F = 8960 (280 blocks: key groups
+    on 140 of the 256 workgroups), 40 heads, ten output rows per workgroup (two records on four of the six consumer waves, one on two).
+    Round 3's ring kernel was instantiated for D = 4096 and 2048 only and this geometry fell to the seven launches (ring_v6.hip,
+    variant table). Decode, greedy loop and the folded head against the oracle; the register-prefetch kernel has no such variant."""
+    os.environ["RWKV_MI_NO_AUTOTUNE"] = "1"
+    os.environ["RWKV_MI_PERSIST"] = "ring"
+    try:
+        library()
+        p = str(tmp_path / "m.bin")
+        spec = synth.CONFIGS["mega-v6-2560"]
+        synth.write_model(p, spec, fmt, seed=73)
+        om = O.OracleModel(p)
+        m = model(p)
+        assert m.decode_path() == 2 and m.persist_kind() == 2
+        ost, st = om.init_state(), None
+        for i, t in enumerate(TOKENS):
+            ol, ost = om.eval(t, ost)
+            lg, st = m.eval(t, st)
+            assert np.array_equal(lg, ol) and np.array_equal(st, ost), (fmt, i, float(np.abs(lg - ol).max()))
+        m.state_load(None)
+        toks, _ = m.decode_greedy(5, 8)
+        os2, tok, ref = om.init_state(), 5, []
+        for _ in range(8):
+            ol, os2 = om.eval(tok, os2)
+            tok = int(np.argmax(ol))
+            ref.append(tok)
+        assert list(toks) == ref and np.array_equal(m.state_store(), os2)
+        assert m.healthy()
+        m.free(); om.free()
+    finally:
+        del os.environ["RWKV_MI_PERSIST"]
+        del os.environ["RWKV_MI_NO_AUTOTUNE"]
