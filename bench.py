@@ -64,14 +64,31 @@ def pmc_traffic(path_id, args, kind=0):
     return e.get("hbm_bytes_per_launch"), e.get("source")
 
 
+def prefill_source_stamp():
+    """sha256 over the sources of the sequence-mode GEMM: a matrix-pipe PMC quote is only valid for the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rwkv.cpp_amd/csrc/prefill.hip", "rwkv.cpp_amd/csrc/kdev.h"):
+        try:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        except OSError:
+            h.update(b"missing:" + f.encode())
+    return h.hexdigest()[:16]
+
+
 def mfma_busy(args):
     """Matrix-pipe utilisation of k_mmq_mfma from the committed rocprofv3 PMC pass (profiles/pmc_mfma.json): counters need their own profiler
-    run, so the bench can only quote them, for the workload they were taken on."""
+    run, so the bench can only quote them, for the workload AND the build of prefill.hip they were taken on (source stamp, like pmc_traffic)."""
     f = os.path.join(ROOT, "profiles", "pmc_mfma.json")
     try:
-        return json.load(open(f)).get(f"{args.config}:{args.dtype}:prefill")
+        e = json.load(open(f)).get(f"{args.config}:{args.dtype}:prefill")
     except Exception:
         return None
+    if not e:
+        return None
+    if e.get("prefill_source_stamp") != prefill_source_stamp():
+        return {"stale": "profiles/pmc_mfma.json was taken on another build of prefill.hip (source stamp differs or missing); re-run tools/gpu_pmc_mfma.sh"}
+    return e
 
 
 def parse_args():
