@@ -115,6 +115,10 @@ RWKV_API bool rwkv_mi_comm_available(void);
 RWKV_API bool rwkv_mi_comm_unique_id(void * id_out, size_t capacity);
 RWKV_API void * rwkv_mi_comm_init(const void * id128, int rank, int world);
 RWKV_API void rwkv_mi_comm_free(void * comm);
+/* The same kind of handle WITHOUT RCCL, for ranks that share one GPU (RCCL refuses that; tests of the multi-process loop): mailboxes in
+ * device memory shared through HIP IPC, hand-shakes through a POSIX shared-memory segment `name` ("/...", the same on every rank, unique
+ * per communicator and run). A hop synchronises the stream on both sides: correct and slow, not a production transport. */
+RWKV_API void * rwkv_mi_comm_init_ipc(const char * name, int rank, int world);
 RWKV_API bool rwkv_mi_stage_run(struct rwkv_context * const * handles, size_t n_streams, const uint32_t * first_tokens, size_t n_tokens,
                                 int rank, int world, void * comm_fwd, void * comm_fb, uint32_t * tokens_out, float * elapsed_ms);
 /* Copies the context's logits (n_vocab floats, from the last step that produced any) to host memory. */

@@ -15,11 +15,19 @@
 #include "model.h"
 #include "rwkv_mi355x.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <functional>
 #include <memory>
 #include <mutex>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 
 using namespace rwkvmi;
 
@@ -151,6 +159,81 @@ struct RcclHop : Hop {
         return hipEventRecord(ev_b, own) == hipSuccess && hipStreamWaitEvent(st, ev_b, 0) == hipSuccess;
     }
 };
+
+// ---- a communicator WITHOUT RCCL: mailboxes in device memory shared through HIP IPC, hand-shakes through POSIX shared memory ----
+// For tests of the multi-process loop on ONE GPU (RCCL refuses two ranks on one device): the protocol of rwkv_mi_stage_run -- forward
+// hops, the token feedback on its own communicator, several decode streams in flight -- is the same, only the transport differs. Every
+// rank owns one mailbox per communicator (in a communicator a rank receives from exactly one peer: rank - 1 on the forward one, the last
+// rank on the feedback one): k_ipc_slots slots of k_ipc_slot_bytes. A message is complete on the host before it is announced (the sender
+// synchronises its stream, then bumps `sent`; the receiver waits for `sent`, copies out, synchronises, bumps `taken`): no inter-process
+// events, which makes the hop slow and the ordering plain. Not a production transport.
+constexpr int k_ipc_slots = 32;
+constexpr size_t k_ipc_slot_bytes = 64 * 1024;
+struct IpcBox {
+    std::atomic<int> state;                  // 0: nothing, 1: handle published
+    hipIpcMemHandle_t mem;
+    std::atomic<uint64_t> sent[k_ipc_slots], taken[k_ipc_slots];
+};
+struct IpcShm { std::atomic<int> ready; int world; IpcBox box[16]; };
+struct IpcWorld {
+    std::string name; int rank = 0, world = 0, device = 0;
+    IpcShm * shm = nullptr;
+    void * mine = nullptr;                   // this rank's mailbox (device memory)
+    void * peer[16] = {};                    // opened mailboxes of the ranks this one sends to
+    uint64_t got[k_ipc_slots] = {};          // messages received per slot of this rank's mailbox
+    uint64_t put[16][k_ipc_slots] = {};      // messages sent per (destination, slot)
+    ~IpcWorld() {
+        for (void * p : peer) if (p) (void) hipIpcCloseMemHandle(p);
+        if (mine) (void) hipFree(mine);
+        if (shm) (void) munmap(shm, sizeof(IpcShm));
+        if (rank == 0 && !name.empty()) (void) shm_unlink(name.c_str());
+    }
+};
+static bool spin_until(const std::function<bool()> & pred, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned i = 0;; i++) {
+        if (pred()) return true;
+        if ((i & 255u) == 255u) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+            std::this_thread::yield();
+        }
+    }
+}
+struct IpcHop : Hop {
+    IpcWorld * w; int peer;                  // peer: the rank this hop sends to / receives from
+    IpcHop(IpcWorld * world, int p) : w(world), peer(p) {}
+    bool send(int j, int msg, const void * src, size_t bytes, hipStream_t st) override {
+        const int s = j * k_hop_msgs + msg;
+        if (s >= k_ipc_slots || bytes > k_ipc_slot_bytes || peer < 0 || peer >= w->world) return false;
+        IpcBox & b = w->shm->box[peer];
+        if (!w->peer[peer]) {
+            if (!spin_until([&] { return b.state.load(std::memory_order_acquire) == 1; }, 60.0)) return false;
+            if (hipIpcOpenMemHandle(&w->peer[peer], b.mem, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return false;
+        }
+        const uint64_t n = w->put[peer][s];
+        if (!spin_until([&] { return b.taken[s].load(std::memory_order_acquire) >= n; }, 60.0)) return false;   // the previous message has left the slot
+        if (hipMemcpyAsync((char *) w->peer[peer] + (size_t) s * k_ipc_slot_bytes, src, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        w->put[peer][s] = n + 1;
+        b.sent[s].store(n + 1, std::memory_order_release);
+        return true;
+    }
+    bool recv(int j, int msg, void * dst, size_t bytes, hipStream_t st) override {
+        const int s = j * k_hop_msgs + msg;
+        if (s >= k_ipc_slots || bytes > k_ipc_slot_bytes) return false;
+        IpcBox & b = w->shm->box[w->rank];
+        const uint64_t n = w->got[s];
+        if (!spin_until([&] { return b.sent[s].load(std::memory_order_acquire) > n; }, 60.0)) return false;
+        if (hipMemcpyAsync(dst, (const char *) w->mine + (size_t) s * k_ipc_slot_bytes, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        w->got[s] = n + 1;
+        b.taken[s].store(n + 1, std::memory_order_release);
+        return true;
+    }
+};
+
+// what rwkv_mi_comm_init / rwkv_mi_comm_init_ipc hand out
+struct MiComm { void * nccl = nullptr; IpcWorld * ipc = nullptr; };
 
 // ---------------------------------------------------------------------------------------------------------------
 // one stage's share of the loop
@@ -339,11 +422,49 @@ RWKV_API void * rwkv_mi_comm_init(const void * id128, int rank, int world) {
     void * comm = nullptr;
     const int e = r.CommInitRank(&comm, world, id, rank);
     if (e != 0) { fprintf(stderr, "rwkv_mi_comm_init: ncclCommInitRank failed: %s\n", r.GetErrorString ? r.GetErrorString(e) : "?"); return nullptr; }
-    return comm;
+    MiComm * c = new MiComm();
+    c->nccl = comm;
+    return c;
+}
+// The same kind of handle over HIP-IPC mailboxes (see IpcWorld): `name` = a POSIX shared-memory name ("/something") unique to this
+// communicator of this run, the same on every rank; rank 0 creates the segment. Current device = the rank's device.
+RWKV_API void * rwkv_mi_comm_init_ipc(const char * name, int rank, int world) {
+    if (!name || name[0] != '/' || rank < 0 || world < 1 || world > 16 || rank >= world) return nullptr;
+    std::unique_ptr<IpcWorld> w(new IpcWorld());
+    w->rank = rank; w->world = world;
+    (void) hipGetDevice(&w->device);
+    int fd = -1;
+    if (rank == 0) {
+        (void) shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, sizeof(IpcShm)) != 0) { if (fd >= 0) close(fd); fprintf(stderr, "rwkv_mi_comm_init_ipc: cannot create %s\n", name); return nullptr; }
+    } else {
+        if (!spin_until([&] { fd = shm_open(name, O_RDWR, 0600); if (fd < 0) return false; struct stat sb; if (fstat(fd, &sb) != 0 || (size_t) sb.st_size < sizeof(IpcShm)) { close(fd); fd = -1; return false; } return true; }, 60.0)) {
+            fprintf(stderr, "rwkv_mi_comm_init_ipc: %s never appeared\n", name); return nullptr;
+        }
+    }
+    void * m = mmap(nullptr, sizeof(IpcShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return nullptr;
+    w->shm = (IpcShm *) m;
+    w->name = name;
+    if (rank == 0) { w->shm->world = world; w->shm->ready.store(1, std::memory_order_release); }      // (a fresh segment is zero-filled)
+    else if (!spin_until([&] { return w->shm->ready.load(std::memory_order_acquire) == 1; }, 60.0)) return nullptr;
+    if (hipMalloc(&w->mine, (size_t) k_ipc_slots * k_ipc_slot_bytes) != hipSuccess) return nullptr;
+    IpcBox & b = w->shm->box[rank];
+    if (hipIpcGetMemHandle(&b.mem, w->mine) != hipSuccess) { fprintf(stderr, "rwkv_mi_comm_init_ipc: hipIpcGetMemHandle failed: %s\n", hipGetErrorString(hipGetLastError())); return nullptr; }
+    b.state.store(1, std::memory_order_release);
+    MiComm * c = new MiComm();
+    c->ipc = w.release();
+    return c;
 }
 RWKV_API void rwkv_mi_comm_free(void * comm) {
+    MiComm * c = (MiComm *) comm;
+    if (!c) return;
     Rccl & r = rccl();
-    if (comm && r.ok()) (void) r.CommDestroy(comm);
+    if (c->nccl && r.ok()) (void) r.CommDestroy(c->nccl);
+    delete c->ipc;
+    delete c;
 }
 RWKV_API bool rwkv_mi_comm_available(void) { return rccl().ok(); }
 
@@ -360,7 +481,9 @@ RWKV_API bool rwkv_mi_stage_run(struct rwkv_context * const * handles, size_t n_
     RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, n_tokens > 0 && rank >= 0 && rank < world, "bad n_tokens / rank / world");
     const Model & m = *c0->model;
     RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, m.has_embed == (rank == 0) && m.has_head == (rank == world - 1), "the stage's layer range does not fit rank %d of %d", rank, world);
-    RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, world == 1 || (comm_fwd && comm_fb && rccl().ok()), "a pipeline of %d ranks needs two communicators (rwkv_mi_comm_init)", world);
+    const MiComm * cf = (const MiComm *) comm_fwd, * cb = (const MiComm *) comm_fb;
+    RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, world == 1 || (cf && cb && ((cf->nccl && cb->nccl && rccl().ok()) || (cf->ipc && cb->ipc))),
+                 "a pipeline of %d ranks needs two communicators of one kind (rwkv_mi_comm_init / rwkv_mi_comm_init_ipc)", world);
     RW_CTX_CHECK(c0, RWKV_ERROR_ARGS, false, !m.has_embed || first_tokens != nullptr, "the first stage needs the seed tokens");
     StagePart part;
     for (size_t j = 0; j < n_streams; j++) {
@@ -372,10 +495,16 @@ RWKV_API bool rwkv_mi_stage_run(struct rwkv_context * const * handles, size_t n_
     RUN_OK(c0, hipSetDevice(m.device));
     std::unique_ptr<Hop> in, out, tin, tout;
     bool ok = true, o = true;
-    if (rank > 0) { in.reset(new RcclHop(comm_fwd, rank - 1, false, o)); ok = ok && o; part.in = in.get(); }
-    if (rank + 1 < world) { out.reset(new RcclHop(comm_fwd, rank + 1, false, o)); ok = ok && o; part.out = out.get(); }
-    if (world > 1 && rank == 0) { tin.reset(new RcclHop(comm_fb, world - 1, true, o)); ok = ok && o; part.tok_in = tin.get(); }
-    if (world > 1 && rank == world - 1) { tout.reset(new RcclHop(comm_fb, 0, true, o)); ok = ok && o; part.tok_out = tout.get(); }
+    auto hop = [&](const MiComm * c, int peer, bool side) -> Hop * {
+        if (c->ipc) return new IpcHop(c->ipc, peer);
+        Hop * h = new RcclHop(c->nccl, peer, side, o);
+        ok = ok && o;
+        return h;
+    };
+    if (rank > 0) { in.reset(hop(cf, rank - 1, false)); part.in = in.get(); }
+    if (rank + 1 < world) { out.reset(hop(cf, rank + 1, false)); part.out = out.get(); }
+    if (world > 1 && rank == 0) { tin.reset(hop(cb, world - 1, true)); part.tok_in = tin.get(); }
+    if (world > 1 && rank == world - 1) { tout.reset(hop(cb, 0, true)); part.tok_out = tout.get(); }
     RW_CTX_CHECK(c0, RWKV_ERROR_ALLOC, false, ok, "cannot create the streams of the token feedback");
     DevMem hist; hist.dev = m.device;
     if (m.has_head) {
