@@ -56,6 +56,15 @@ RG_HD uint32_t rg_qh_off(const RingShape & s, int R, int U, int u, int r) { retu
 RG_HD int rg_rows_c(const RingShape & s) { return 4 * s.D / RG_NBLK; }                 // r/k/v/g rows per workgroup (all of one matrix)
 RG_HD int rg_rows_e(const RingShape & s) { return s.D / RG_NBLK; }                     // output / receptance / value rows per workgroup
 RG_HD int rg_gpb(const RingShape & s) { return (s.F / 32 + RG_NBLK - 1) / RG_NBLK; }   // 32-row groups of ffn.key per workgroup
+// Two-row sets of ffn.key of workgroup b, and how many of them (the LAST ones) do not travel through the ring: 32 sets over six consumer
+// waves are 6 + 6 + 5 + 5 + 5 + 5, and a wave that holds five records in registers (ring_v6.hip, NPK) never completes a phase of six
+// during a hand-over wait -- so it never gets to the records behind it. The comm wave, idle through the key rows, takes the two odd sets
+// (read from the planes like the decay row); 16 sets (2 + 2 + 3 + 3 + 3 + 3, a remainder of four) stay as they are.
+RG_HD int rg_key_sets(const RingShape & s, int b) {
+    const int gpb = rg_gpb(s), key0 = b * gpb * 32;
+    return key0 < s.F ? ((s.F - key0 < gpb * 32 ? s.F - key0 : gpb * 32) / 2) : 0;
+}
+RG_HD int rg_key_comm(const RingShape & s, int b) { const int n = rg_key_sets(s, b); return (n >= RG_NC && n % RG_NC <= 2) ? n % RG_NC : 0; }
 
 // rows of a record: phase-specific matrix (RG_C: the matrix index 0..3 = r, k, v, g), first row, rows per record, row length
 struct RingRec { int mat, row0, R, K; };
@@ -76,7 +85,8 @@ RG_HD RingCu rg_cu(const RingShape & s, int b) {
     c.n[RG_DW1] = 0;   // (the decay row of workgroup b < DR is read from the planes by its comm wave, beside the consumers' r/k/v/g sets: ring_v6.hip)
     c.n[RG_C] = (uint32_t) (rg_rows_c(s) / 2);
     c.n[RG_E] = (uint32_t) rg_rows_e(s);
-    c.n[RG_FK] = (uint32_t) (key0 < s.F ? ((s.F - key0 < gpb * 32 ? s.F - key0 : gpb * 32) / 2) : 0);
+    (void) key0;
+    c.n[RG_FK] = (uint32_t) (rg_key_sets(s, b) - rg_key_comm(s, b));
     c.n[RG_FR] = (uint32_t) rg_rows_e(s);
     c.n[RG_G] = (uint32_t) rg_rows_e(s);
     const uint32_t d1 = rg_rec_bytes(s, 1, s.D), d2 = rg_rec_bytes(s, 2, s.D), f1 = rg_rec_bytes(s, 1, s.F);
@@ -84,7 +94,7 @@ RG_HD RingCu rg_cu(const RingShape & s, int b) {
     // E, FR and G share one mapping (a wave keeps the residual and the receptance of its rows in registers across the three phases).
     // The two-row sets of C and FK do not divide by six: the extra sets go to consumers 2 and 3 (waves 4 and 5, which share their SIMDs
     // with the loader and the comm wave, not with another consumer); the decay row goes to a wave with the fewest r/k/v/g sets
-    c.rot[RG_W1] = 0; c.rot[RG_DW1] = RG_NC - 1; c.rot[RG_C] = 2; c.rot[RG_E] = 0; c.rot[RG_FK] = 2; c.rot[RG_FR] = 0; c.rot[RG_G] = 0;
+    c.rot[RG_W1] = 0; c.rot[RG_DW1] = RG_NC - 1; c.rot[RG_C] = 2; c.rot[RG_E] = 0; c.rot[RG_FK] = (rg_key_sets(s, b) - rg_key_comm(s, b)) % RG_NC ? 2 : 0; c.rot[RG_FR] = 0; c.rot[RG_G] = 0;
     uint32_t p = 0;
     for (int ph = 0; ph < RG_NPHASE; ph++) { c.off[ph] = p; p += c.n[ph] * c.rec[ph]; }
     c.layer_bytes = p;

@@ -162,9 +162,31 @@ __device__ __forceinline__ void rec_load(RawRec<FMT, R, U> & w, unsigned ring_ld
 }
 // the reads of rec_load have returned (the compiler does not count inline-asm LDS operations: waited for by hand; every register of the
 // record passes through the statement, so no use can move above it)
-template <int FMT, int R, int U>
+// YOUNGER = LDS operations issued behind this record's reads that may stay in flight (the reads of the record taken right after it + the
+// release word: LDS operations of a wave complete in order, so "at most YOUNGER outstanding" means this record's have returned; 0: everything)
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+    if constexpr (N <= 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+    else if constexpr (N == 13) asm volatile("s_waitcnt lgkmcnt(13)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+}
+// LDS instructions of one record's reads (rec_load) + the release word
+template <int FMT, int R, int U> constexpr int rec_lds_ops() { return U * R * ((QF<FMT>::QS / 16) + 1 + (QF<FMT>::QH ? 1 : 0)) + 1; }
+template <int FMT, int R, int U, int YOUNGER = 0>
 __device__ __forceinline__ void rec_wait(RawRec<FMT, R, U> & w) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lgkm<(YOUNGER > 15 ? 0 : YOUNGER)>();      // (more than the counter holds: wait for everything)
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
@@ -294,10 +316,26 @@ struct R6 {
     // cooperative gathers: the NG gathering waves each poll a share of the units and stage it into LDS, then meet on a counter
     // -----------------------------------------------------------------------------------------------------------
     // x-like vector: unit (workgroup b, consumer c) at b * NC + c carries rows b * RE + c + NC * t, t < XT
-    static __device__ __forceinline__ void gather_x(Poll & pl, xrsrc xr, int buf, unsigned tag, int g, int lane, float * lx) {
+    // plain != nullptr (the first layer of a launch): the vector lies in plain memory (written before the launch) and is read in the same
+    // unit-shaped pieces -- one code path, so that the layer loop has no separate "first layer" branch (around which the register allocator
+    // spilled the record buffers that are reserved across it)
+    static __device__ __forceinline__ void gather_x(Poll & pl, xrsrc xr, int buf, unsigned tag, int g, int lane, float * lx, const float * plain = nullptr) {
         constexpr int N = NBLK * NC;
         const int i0 = g * 64 + lane;
         v4u v[XSL];
+        if (plain) {
+#pragma unroll
+            for (int k = 0; k < XSL; k++) {
+                const unsigned i = (unsigned) (i0 + k * NG * 64);
+                const unsigned ic = i < (unsigned) N ? i : 0u;
+                const unsigned b = (ic * 43691u) >> 18, c = ic - 6u * b;
+                const float * src = plain + b * RE + c;
+                v[k].x = __float_as_uint(src[0]);
+                v[k].y = __float_as_uint(src[(XT > 1 && c + NC < (unsigned) RE) ? NC : 0]);
+                v[k].z = __float_as_uint(src[(XT > 2 && c + 2 * NC < (unsigned) RE) ? 2 * NC : 0]);
+                v[k].w = 0u;
+            }
+        } else
         for (unsigned spin = 0;; spin++) {
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -767,9 +805,10 @@ struct R6 {
     // which phases take records ahead (1: r/k/v/g, 2: output, 4: ffn key, 8: ffn value), and how many per wave. D = 2048: none -- a layer
     // block (130 KB per workgroup) nearly fits the ring as it is, and the extra ring checks in the watch loops cost 2.5 %.
     // + 16: W1 + r/k/v/g records during the x hand-over at the top of the layer, + 32: output records during the act hand-over, + 64: ffn
-    // key records during the yq hand-over (the phase behind the one the hand-over feeds), + 128: ffn receptance records behind those
+    // key records during the yq hand-over (the phase behind the one the hand-over feeds), + 128: ffn receptance records behind those.
+    // (+ 16 only compiles without scratch since the layer loop has no separate first-layer branch: see gather_x)
 #ifndef R6_PRE_MASK
-#define R6_PRE_MASK 239
+#define R6_PRE_MASK 255
 #endif
     static constexpr int PRE_MASK = EPT > 4 ? R6_PRE_MASK : 0;
     // Stage 1 of a gather (gather_hint) with the wait put to use: until the hand-over's sentinel turns, the wave takes its records of
@@ -792,8 +831,8 @@ struct R6 {
     // what streams in behind them is two phases ahead.
     template <int RA, int UA, int NA, int RB_, int UB_, int NB_, int RC, int UC, int NC_>
     static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap,
-                                                     bool on_a, Pre<RA, UA, NA> & a, bool on_b, Pre<RB_, UB_, NB_> & b, bool on_c, Pre<RC, UC, NC_> & c3) {
-        bool turned = false;
+                                                     bool on_a, Pre<RA, UA, NA> & a, bool on_b, Pre<RB_, UB_, NB_> & b, bool on_c, Pre<RC, UC, NC_> & c3, bool no_handover = false) {
+        bool turned = no_handover;            // (the first layer of a launch: nothing to wait for, nothing taken ahead)
         const unsigned look = cs.look;
         auto step = [&](auto & pre, auto tc, bool ok) {
             constexpr int t = decltype(tc)::value;
@@ -826,10 +865,10 @@ struct R6 {
     }
     template <int RA, int UA, int NA, int RB_, int UB_, int NB_>
     static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap,
-                                                     bool on_a, Pre<RA, UA, NA> & a, bool on_b, Pre<RB_, UB_, NB_> & b) {
+                                                     bool on_a, Pre<RA, UA, NA> & a, bool on_b, Pre<RB_, UB_, NB_> & b, bool no_handover = false) {
         Pre<1, 1, 1> none;
         none.have = 0u; none.cnt = 0u; none.pos = 0u; none.ro = 0u; none.after = 0u;
-        hint_take(cs, pl, l, xr, unit, tag, go, gen, nap, on_a, a, on_b, b, false, none);
+        hint_take(cs, pl, l, xr, unit, tag, go, gen, nap, on_a, a, on_b, b, false, none, no_handover);
     }
     template <int R, int U, int NP>
     static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap, bool on, Pre<R, U, NP> & pre) {
@@ -879,12 +918,17 @@ struct R6 {
             constexpr int t = decltype(tc)::value;
             if ((t < TF || tail) && pre.have <= (unsigned) t) (void) rec_take<t, R, U, NP, false>(cs, pl, l, pre, true);
         });
+        // (record t's reads were issued NP - 1 takes ago; the take issued right before this wait -- of record t - 1 + NP, behind the
+        //  arithmetic of record t - 1 -- may stay in flight: its LDS latency overlaps the arithmetic instead of preceding it)
+        bool took = false;                                         // the previous iteration issued a take (wave-uniform)
         Unroll<0, TF + 1>::run([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             if (t < TF || tail) {
-                rec_wait<FMT, R, U>(pre.w[t % NP]);
+                if (NP >= 2 && took) rec_wait<FMT, R, U, rec_lds_ops<FMT, R, U>()>(pre.w[t % NP]);
+                else rec_wait<FMT, R, U>(pre.w[t % NP]);
                 finish(tc, pre.w[t % NP]);
-                if constexpr (t + NP <= TF) { if (t + NP < TF || tail) (void) rec_take<t + NP, R, U, NP, false>(cs, pl, l, pre, true); }
+                took = false;
+                if constexpr (t + NP <= TF) { if (t + NP < TF || tail) { (void) rec_take<t + NP, R, U, NP, false>(cs, pl, l, pre, true); took = true; } }
             }
         });
         wave_sum_n<(TF + 1) * R>(part);
@@ -914,7 +958,8 @@ struct R6 {
     // rows (R), ffn value rows (G). With records taken ahead (PRE_MASK): as many as the register file holds without spilling
     // (tools/check_ring_regs.sh prints the budget of every instantiation); without: the double buffer (one buffer for Q8_0's 36-register
     // blocks and for the long value rows).
-    static constexpr int TFC = (D * 4 / NBLK / 2) / NC, TFE = RE / NC, TFK = (UF * 64 > NBLK ? 32 : 16) / NC;
+    static constexpr int TFC = (D * 4 / NBLK / 2) / NC, TFE = RE / NC, KSETS = UF * 64 > NBLK ? 32 : 16 /* two-row key sets of a workgroup that owns any */,
+                         KCOMM = (KSETS % NC <= 2) ? KSETS % NC : 0 /* ... of which the comm wave takes the last ones (ring_geom.h, rg_key_comm) */, TFK = (KSETS - KCOMM) / NC;
     static constexpr bool Q8 = QF<FMT>::QS == 32, Q5 = QF<FMT>::QH;
     static constexpr int npcap(int want, int tf) { return want < 1 ? 1 : (want > tf + 1 ? tf + 1 : want); }
 #ifndef R6_NPC
@@ -964,14 +1009,19 @@ struct R6 {
         // R6_LATE_PARAMS = 0 (round 3): a whole phase ahead -- 48 / 60 registers live across a hand-over wait. 1: at the start of the
         // prologue, in flight under the LayerNorm statistics (two reduction rounds, ~1 us; the lines are the same for every workgroup:
         // L2 hits) -- the hand-over waits then hold next to nothing but records taken ahead, which is what the registers are for now.
-        // 2 (default): LN1's a phase ahead as in round 3 (nothing else is held across that hand-over), LN2's when the x hand-over's sentinel
-        // has turned -- in flight under the sweep and the statistics, behind the records taken during the wait. Measured on the 7B: placement 1
-        // costs 1.5 + 0.6 us per layer in the two prologues (the loads are NOT covered by the statistics).
+        // 2 (default): both when the x hand-over's sentinel has turned -- in flight under the sweep and the statistics, behind the records taken
+        // during the wait (LN1's a phase ahead as in round 3 would be 48 registers live across the loop's back edge and the wait in which the
+        // r/k/v/g records are taken). Measured on the 7B: placement 1 costs 1.5 + 0.6 us per layer in the two prologues (the loads are NOT
+        // covered by the statistics).
 #ifndef R6_LATE_PARAMS
 #define R6_LATE_PARAMS 2
 #endif
+        // (D = 2048 takes no records ahead and holds nothing across the x hand-over: there LN1's parameters go out a phase ahead as in round 3 --
+        //  issued behind the sentinel they cost the 1.6B 1.8 %)
+        constexpr bool PA_EARLY = R6_LATE_PARAMS == 0 || (R6_LATE_PARAMS == 2 && (PRE_MASK & 16) == 0);
+        constexpr bool PF_EARLY = R6_LATE_PARAMS == 0 || (R6_LATE_PARAMS == 2 && (PRE_MASK & 4) == 0);
         PA pa; PF pf;
-        if (R6_LATE_PARAMS != 1) issue_pa(pa, ar, p.layers[0], p.sin, c, opq(lane));
+        if (PA_EARLY) issue_pa(pa, ar, p.layers[0], p.sin, c, opq(lane));
 
         for (int li = 0; li < p.n_layers; li++) {
             const M6Layer & L = p.layers[li];
@@ -990,15 +1040,16 @@ struct R6 {
             // (per-lane offsets are derived from an opaque copy of the lane index in every phase: left alone, the compiler hoists a
             //  hundred loop-invariant address registers of the gathers out of the layer loop and spills them)
             // ---- A: x, LN1 + mix + quantise, W1 rows ----
-            if (li == 0) {
-                sweep_begin(l);
-                for (int i = c * 64 + lane; i < D; i += NG * 64) l.x[i] = p.x[i];
-            } else {
+            {
+                // (the first layer of a launch has no hand-over in front of it: its x lies in plain memory; same statements, see gather_x)
+                const bool first = li == 0;
                 watch_begin(l);
-                hint_take(cs, pl, l, xr, p.xffn + ((blk * 37 + c * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap, (PRE_MASK & 16) != 0, pw, (PRE_MASK & 16) != 0, pc);
+                hint_take(cs, pl, l, xr, p.xffn + ((blk * 37 + c * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap, (PRE_MASK & 16) != 0 && !first, pw,
+                          (PRE_MASK & 16) != 0 && !first, pc, first);
                 watch_end(l);
+                if (R6_LATE_PARAMS == 2 && !PA_EARLY) { issue_pa(pa, ar, L, sin_l, c, opq(lane)); __builtin_amdgcn_sched_barrier(0); }
                 sweep_begin(l);
-                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, c, opq(lane), l.x);
+                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, c, opq(lane), l.x, first ? p.x : nullptr);
             }
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
             sweep_end(l);
@@ -1050,7 +1101,7 @@ struct R6 {
             }
             R6STAMP(5); R6RSTAMP(27);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 24] = cs.waited;
-            if (R6_LATE_PARAMS == 0) issue_pf(pf, ar, L, sin_l, c, opq(lane));
+            if (PF_EARLY) issue_pf(pf, ar, L, sin_l, c, opq(lane));
             __builtin_amdgcn_sched_barrier(0);
             // ---- E: output projection + residual ----
             Pre<2, UD, NPK> pk;
@@ -1075,7 +1126,7 @@ struct R6 {
             watch_begin(l);
             hint_take(cs, pl, l, xr, p.xatt + ((blk * 37 + c * 211) & 1023), tagL + SLOT_XATT, l.fl + FL_HX, 2u * li + 2u, p.nap, (PRE_MASK & 4) != 0, pk, (PRE_MASK & 128) != 0, pr);
             watch_end(l);
-            if (R6_LATE_PARAMS == 2) { issue_pf(pf, ar, L, sin_l, c, opq(lane)); __builtin_amdgcn_sched_barrier(0); }
+            if (R6_LATE_PARAMS == 2 && !PF_EARLY) { issue_pf(pf, ar, L, sin_l, c, opq(lane)); __builtin_amdgcn_sched_barrier(0); }
             sweep_begin(l);
             gather_x(pl, xr, p.xatt, tagL + SLOT_XATT, c, opq(lane), l.x);
             gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
@@ -1121,7 +1172,7 @@ struct R6 {
             R6STAMP(13); R6RSTAMP(14);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 25] = cs.waited;
             __builtin_amdgcn_sched_barrier(0);   // (the loads below stay behind the value rows: hoisted into them they cost 48 registers at the kernel's peak)
-            if (R6_LATE_PARAMS != 1) {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
+            if (PA_EARLY) {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
                 // (unconditionally -- behind the last layer the same layer's again: under `if (li + 1 < n_layers)` the parameters are
                 //  conditionally redefined, and the old values stay live through the whole layer on the path the compiler cannot rule out)
                 const int nl = li + 1 < p.n_layers ? li + 1 : li;
@@ -1272,15 +1323,13 @@ struct R6 {
             const unsigned g1 = (unsigned) li + 1u;
             R6STAMP(0);
             // ---- A ----
-            if (li == 0) {
-                sweep_begin(l);
-                for (int i = g * 64 + lane; i < D; i += NG * 64) l.x[i] = p.x[i];
-            } else {
+            {
+                const bool first = li == 0;
                 watch_begin(l);
-                gather_hint(pl, xr, p.xffn + ((blk * 37 + g * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
+                if (!first) gather_hint(pl, xr, p.xffn + ((blk * 37 + g * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
                 watch_end(l);
                 sweep_begin(l);
-                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, g, opq(lane), l.x);
+                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, g, opq(lane), l.x, first ? p.x : nullptr);
             }
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
             sweep_end(l);
@@ -1498,6 +1547,27 @@ struct R6 {
             sweep_end(l);
             R6STAMP(7); R6RSTAMP(22);
             // ---- F ----
+            // the key sets of this workgroup that do not travel through the ring (the last KCOMM of its KSETS: ring_geom.h): this wave is idle
+            // through the key rows; their blocks go in flight now, from the planes, like the decay row's
+            RawRec<FMT, 2, UD> kxr[KCOMM > 0 ? KCOMM : 1];
+            const bool k_has = KCOMM > 0 && blk * gpb * 32 < nbF * 32;
+            if constexpr (KCOMM > 0) {
+                const WPl fk = ar.w(L.fk);
+                const int lnK = opq(lane);
+#pragma unroll
+                for (int q = 0; q < KCOMM; q++)
+#pragma unroll
+                    for (int u = 0; u < UD; u++)
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const long long row = k_has ? (long long) blk * gpb * 32 + 2 * (KSETS - KCOMM + q) + r : 0;
+                            const int bb = u * 64 + lnK;
+                            RawBlk<FMT> rb; rb.qh = 0u;
+                            load_raw<FMT>(rb, fk.qs, fk.qh, fk.sc, row * nb + (bb < nb ? bb : nb - 1));
+                            from_raw<FMT>(kxr[q].raw[u][r], rb);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             watch_begin(l);
             gather_hint(pl, xr, p.xatt + ((blk * 37 + g * 211) & 1023), tagL + SLOT_XATT, l.fl + FL_HX, 2u * li + 2u, p.nap);
             watch_end(l);
@@ -1506,6 +1576,22 @@ struct R6 {
             gather_meet(pl, l.fl + FL_GX, 2u * li + 2u);
             sweep_end(l);
             R6STAMP(8); R6RSTAMP(23);
+            if constexpr (KCOMM > 0) {
+                if (k_has) {
+                    prologue_wait(pl, l, 2u * li + 2u);              // l.q1 holds the quantised key input
+                    const int lnK = opq(lane);
+                    ActRegs<UD> ark;
+                    act_load<UD>(ark, qvec_at(l.q1, D), nb, lnK);
+                    float part[2 * KCOMM];
+#pragma unroll
+                    for (int q = 0; q < KCOMM; q++) rec_acc<FMT, 2, UD>(kxr[q], ark, nb, lnK, part + 2 * q);
+                    wave_sum_n<2 * KCOMM>(part);
+                    const float v = pick_lane<2 * KCOMM>(part, lnK);
+                    const float t = v > 0.0f ? v : 0.0f;
+                    if (lnK < 2 * KCOMM) l.out[2 * (KSETS - KCOMM) + lnK] = t * t;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
             fl_wait(pl, l.fl + FL_KEYS, (unsigned) NC * g1);     // every consumer's key sets are in l.out
             R6STAMP(9);
             {

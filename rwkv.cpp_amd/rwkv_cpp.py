@@ -139,8 +139,9 @@ class RWKVSharedLibrary:
         L.rwkv_mi_comm_unique_id.restype = ctypes.c_bool
         L.rwkv_mi_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.rwkv_mi_comm_init.restype = ctypes.c_void_p
-        L.rwkv_mi_comm_init_ipc.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
-        L.rwkv_mi_comm_init_ipc.restype = ctypes.c_void_p
+        if hasattr(L, "rwkv_mi_comm_init_ipc"):   # (absent from older A/B builds loaded through RWKV_LIB_DIR)
+            L.rwkv_mi_comm_init_ipc.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+            L.rwkv_mi_comm_init_ipc.restype = ctypes.c_void_p
         L.rwkv_mi_comm_free.argtypes = [ctypes.c_void_p]
         L.rwkv_mi_comm_free.restype = None
         L.rwkv_mi_stage_run.argtypes = [ctypes.POINTER(c_ctx), ctypes.c_size_t, P_UINT32, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

@@ -48,6 +48,10 @@ static void check_shape(const RingShape & s, const char * name) {
             }
             off += c.n[ph] * c.rec[ph];
         }
+        // the key sets the comm wave reads from the planes: the last ones of the workgroup, not in the stream
+        for (int j = (int) c.n[RG_FK]; j < rg_key_sets(s, b); j++)
+            for (int q = 0; q < 2; q++) { const int row = b * rg_gpb(s) * 32 + 2 * j + q; auto & v = seen[{RG_FK, 0}]; CHECK(row < (int) v.size(), "comm key row"); if (row < (int) v.size()) v[(size_t) row]++; }
+        CHECK((int) c.n[RG_FK] + rg_key_comm(s, b) == rg_key_sets(s, b) && rg_key_comm(s, b) <= 2, "%s wg %d: key sets", name, b);
         CHECK(c.layer_bytes == off, "%s wg %d: layer bytes", name, b);
         if (b == 0) layer_bytes0 = c.layer_bytes;
         // the cursor of a consumer wave: first own record of phase >= from, in stream order
@@ -97,14 +101,14 @@ static void check_head(int n_vocab, int K) {
 
 int main() {
     struct Fmt { const char * name; int qs, scb, qhb; } fmts[] = {{"Q4_0", 16, 2, 0}, {"Q4_1", 16, 4, 0}, {"Q5_0", 16, 2, 4}, {"Q5_1", 16, 4, 4}, {"Q8_0", 32, 2, 0}};
-    struct Geo { int D, F, R5, DR; } geos[] = {{2048, 7168, 160, 64}, {4096, 14336, 320, 128}, {4096, 14336, 160, 64}};
+    struct Geo { int D, F, R5, DR; } geos[] = {{2048, 7168, 160, 64}, {4096, 14336, 320, 128}, {4096, 14336, 160, 64}, {2560, 8960, 160, 64}};
     for (const Fmt & f : fmts)
         for (const Geo & g : geos) {
             RingShape s; s.D = g.D; s.F = g.F; s.R5 = g.R5; s.DR = g.DR; s.qs = f.qs; s.scb = f.scb; s.qhb = f.qhb;
             char name[64]; snprintf(name, sizeof name, "%s D=%d", f.name, g.D);
             check_shape(s, name);
         }
-    for (int v : {4096, 8192, 32768, 65536}) for (int K : {2048, 4096}) check_head(v, K);
+    for (int v : {4096, 8192, 32768, 65536}) for (int K : {2048, 2560, 4096}) check_head(v, K);
     if (fails) { fprintf(stderr, "%d checks failed\n", fails); return 1; }
     printf("ring geometry OK\n");
     return 0;
