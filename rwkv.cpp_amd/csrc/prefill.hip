@@ -865,17 +865,49 @@ bool launch_wkv6_seq(const float * r, const float * k, const float * v, const fl
 // runs the 64-element update and the second chain serially in every lane: ~580 instructions per token on H waves (40 of the chip's
 // 1024 SIMDs at 2.9B). Here a wave owns FOUR rows, lane = 16 * row + q with q = elements 4 q .. 4 q + 3 of the row:
 //   * the update is 4 elements per lane (28 instructions instead of 448);
-//   * the sa chain runs down the 16 lanes of a DPP row: step q adds lane q's four products, in order, onto what lane q - 1 produced
-//     in the step before (row_shr:1, lane 0 receives 0.0f like the reference's `sa = 0`); lanes other than q compute values nobody
-//     reads. 64 dependent adds per token -- the floor -- then one ds_bpermute hands lane 15's sum to the row;
+//   * the sa chain: every lane of the row adds the row's 64 products itself, in order, reading each one through a DPP row_newbcast of
+//     its owner (w7_row_sum above): 64 dependent full-rate adds per token -- the floor -- and the sum is in all 16 lanes when it ends;
 //   * the out chain IS skewed: it only reads. Lane q parks its four products s_ij r_j of token t in an LDS ring (own column, used as an
 //     indexed register file: no barrier) and at step sigma adds those of token sigma - q onto the sum it receives from lane q - 1;
 //     lane 15 emits out[sigma - 15]. Four adds per token instead of 64.
-// ~130 instructions per token and wave, 16 H workgroups of 4 waves. Per-token operands are staged through LDS in chunks of 32 tokens
+// ~100 instructions per token and wave, 16 H workgroups of 4 waves. Per-token operands are staged through LDS in chunks of 32 tokens
 // (global loads of chunk c + 1 in flight during chunk c), read as one 16-byte vector per array and token, one token ahead.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int W7_CH = 32;                                                     // tokens per staged chunk (the staging loops assume 32)
 constexpr int W7_LDS = (2 * W7_CH * (5 * 64 + 16) + 4 * 16 * 64 * 4) * 4;     // two chunk buffers (r w k a b: 64 each, v: 16 rows) + the out-chain rings
+
+// sa of a row = ((((0 + p_0) + p_1) + ...) + p_63): the row's 16 lanes hold p_{4q .. 4q+3}; every lane of the row adds all 64 products
+// itself, in order, each read through a DPP row_newbcast of the lane that owns it (v_add_f32_dpp: one full-rate instruction per
+// term). All 16 lanes end with the same, complete sum: no hand-over of partial sums from lane to lane, no LDS permute at the end.
+// The instructions are written out by hand: the compiler's hazard recogniser puts two wait states in front of every DPP instruction
+// whose ANY source was written by the previous VALU instruction; the hardware needs them for the DPP-permuted source only
+// (the products, written long before), not for the accumulator, which is read like any other source 1.
+template <int Q> __device__ __forceinline__ float w7_bc(float p) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0x150 + Q /* row_newbcast:Q */, 0xF, 0xF, true));
+}
+template <int Q> __device__ __forceinline__ void w7_chain(float & x, float p0, float p1, float p2, float p3) {
+    if constexpr (Q < 16) {
+        x = w7_bc<Q>(p0) + x; x = w7_bc<Q>(p1) + x; x = w7_bc<Q>(p2) + x; x = w7_bc<Q>(p3) + x;
+        w7_chain<Q + 1>(x, p0, p1, p2, p3);
+    }
+}
+__device__ __forceinline__ float w7_row_sum(float p0, float p1, float p2, float p3) {
+    float x = 0.0f;
+#ifdef W7_CHAIN_BUILTIN
+    w7_chain<0>(x, p0, p1, p2, p3);
+#else
+#define W7_A(Q) "v_add_f32_dpp %0, %1, %0 row_newbcast:" #Q " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                "v_add_f32_dpp %0, %2, %0 row_newbcast:" #Q " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                "v_add_f32_dpp %0, %3, %0 row_newbcast:" #Q " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                "v_add_f32_dpp %0, %4, %0 row_newbcast:" #Q " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm("s_nop 1\n\t"                          // (the products may have been written by the instruction just before)
+                 W7_A(0) W7_A(1) W7_A(2) W7_A(3) W7_A(4) W7_A(5) W7_A(6) W7_A(7)
+                 W7_A(8) W7_A(9) W7_A(10) W7_A(11) W7_A(12) W7_A(13) W7_A(14) W7_A(15)
+                 : "+v"(x) : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+#undef W7_A
+#endif
+    return x;
+}
 
 __global__ __launch_bounds__(256) void k_wkv7_seq(const float * __restrict__ r, const float * __restrict__ w, const float * __restrict__ k,
                                                   const float * __restrict__ v, const float * __restrict__ a, const float * __restrict__ b,
@@ -894,10 +926,10 @@ __global__ __launch_bounds__(256) void k_wkv7_seq(const float * __restrict__ r, 
     const int64_t D = (int64_t) H * S;
     float4 * const ring = l_ring + wave * 16 * 64 + lane;
 
-    float s0, s1, s2, s3;
+    v2f s01, s23;                                               // elements 4 q .. 4 q + 3 of row i
     {
         const float4 q4 = *reinterpret_cast<const float4 *>(state_in + h * S * S + (int64_t) i * S + 4 * q);
-        s0 = q4.x; s1 = q4.y; s2 = q4.z; s3 = q4.w;
+        s01 = (v2f){q4.x, q4.y}; s23 = (v2f){q4.z, q4.w};
     }
     // staging: chunk c = tokens [CH c, CH c + CH): five arrays of CH x 16 float4 = ten per thread; v: CH x 16 floats = two per thread
     static_assert(CH == 32, "the staging below is written for chunks of 32 tokens");
@@ -945,23 +977,17 @@ __global__ __launch_bounds__(256) void k_wkv7_seq(const float * __restrict__ r, 
     // one step: `upd` = a token is consumed (state update + its products into the ring); the out chain always advances
     auto step = [&](int sigma, bool upd, const Tok & tk) __attribute__((always_inline)) {
         if (upd) {
-            const float p0 = tk.a.x * s0, p1 = tk.a.y * s1, p2 = tk.a.z * s2, p3 = tk.a.w * s3;
+            const v2f p01 = (v2f){tk.a.x, tk.a.y} * s01, p23 = (v2f){tk.a.z, tk.a.w} * s23;
             // independent of sa: v k, s w and their sum
-            const float kv0 = tk.v * tk.k.x, kv1 = tk.v * tk.k.y, kv2 = tk.v * tk.k.z, kv3 = tk.v * tk.k.w;
-            const float t0 = s0 * tk.w.x + kv0, t1 = s1 * tk.w.y + kv1, t2 = s2 * tk.w.z + kv2, t3 = s3 * tk.w.w + kv3;
-            float x = 0.0f, y = 0.0f;
-#pragma unroll
-            for (int st = 0; st < 16; st += 2) {
-                x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x111 /* row_shr:1 */, 0xF, 0xF, false)) + p0;
-                x += p1; x += p2; x += p3;
-                y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xF, 0xF, false)) + p0;
-                y += p1; y += p2; y += p3;
-            }
-            // lane q's sum is final after step q: even q in x, odd q in y; lane 15 (odd) holds the row's sa in y
-            const float sa = __int_as_float(__builtin_amdgcn_ds_bpermute((lane | 15) << 2, __float_as_int(y)));
-            const float n0 = t0 + sa * tk.b.x, n1 = t1 + sa * tk.b.y, n2 = t2 + sa * tk.b.z, n3 = t3 + sa * tk.b.w;
-            s0 = n0; s1 = n1; s2 = n2; s3 = n3;
-            ring[(sigma & 15) * 64] = make_float4(n0 * tk.r.x, n1 * tk.r.y, n2 * tk.r.z, n3 * tk.r.w);
+            const v2f vv = {tk.v, tk.v};
+            const v2f t01 = s01 * (v2f){tk.w.x, tk.w.y} + vv * (v2f){tk.k.x, tk.k.y};
+            const v2f t23 = s23 * (v2f){tk.w.z, tk.w.w} + vv * (v2f){tk.k.z, tk.k.w};
+            const float sa = w7_row_sum(p01.x, p01.y, p23.x, p23.y);
+            const v2f sv = {sa, sa};
+            s01 = t01 + sv * (v2f){tk.b.x, tk.b.y};
+            s23 = t23 + sv * (v2f){tk.b.z, tk.b.w};
+            const v2f o01 = s01 * (v2f){tk.r.x, tk.r.y}, o23 = s23 * (v2f){tk.r.z, tk.r.w};
+            ring[(sigma & 15) * 64] = make_float4(o01.x, o01.y, o23.x, o23.y);
         }
         const float4 pq = ring[((sigma - q) & 15) * 64];
         float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o_run), 0x111, 0xF, 0xF, false)) + pq.x;
@@ -996,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_wkv7_seq(const float * __restrict__ r, 
         Tok none{};
         for (int sigma = T; sigma < T + 15; sigma++) step(sigma, false, none);   // drain the out chain
     }
-    *reinterpret_cast<float4 *>(state_out + h * S * S + (int64_t) i * S + 4 * q) = make_float4(s0, s1, s2, s3);
+    *reinterpret_cast<float4 *>(state_out + h * S * S + (int64_t) i * S + 4 * q) = make_float4(s01.x, s01.y, s23.x, s23.y);
 }
 
 bool launch_wkv7_seq(const float * r, const float * w, const float * k, const float * v, const float * a, const float * b,
