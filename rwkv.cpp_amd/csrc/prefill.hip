@@ -182,6 +182,11 @@ __global__ __launch_bounds__(256) void k_quant_act_tiles(QuantBatch qb, int64_t 
 // the GEMM
 // ---------------------------------------------------------------------------------------------------------------
 
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
 template <int FMT> struct MF {
     static constexpr bool Q8 = FMT == T_Q8_0;
     static constexpr bool QH = QF<FMT>::QH, HM = QF<FMT>::HM;
@@ -201,8 +206,37 @@ template <int FMT> struct MF {
     static constexpr int  P_TAIL = P_WSC + P_WQH + P_XD + P_XS + P_XO, NTR = (P_TAIL + 63) / 64, NR = NW + 2 + NTR;   // rows per step
     // steps per chunk; stack levels kept in LDS (64 B per thread each) so that two chunks of 8 steps + the levels fit in 160 KiB
     static constexpr bool OVERLAP = !(QH && HM);                // the MFMA of step sigma + 1 runs under the fold of step sigma (Q5_1: no registers for it)
-    static constexpr int CH = 8, STK_LDS = Q8 ? 1 : 2;
-    static constexpr int LDS_BYTES = 2 * CH * SLOT + STK_LDS * 64 * NT;
+#ifndef PF_CH
+#define PF_CH 8
+#endif
+#ifndef PF_NBUF
+#define PF_NBUF 2
+#endif
+    // NBUF chunk buffers of CH steps: chunk k + NBUF - 1 is issued when chunk k starts, (NBUF - 1) CH steps before its first read; the
+    // boundary waits with a counted vmcnt for chunk k only. Measured in round 4 (1.6B Q4_0, average launch of the 1024-token pass,
+    // profiles/r04q_mmq_variants.txt): CH 8 x 2 buffers 40.7 us; CH 4 x 2 / 3 / 4 buffers 42.9 / 43.6 / 43.2 us -- the depth of the
+    // prefetch does not matter, the extra barriers cost 6 %. The timing-only builds behind -DPF_EXP_* (results invalid: parts of the
+    // step are skipped) say where the time is NOT: without the fold 38.6 us, without the LDS operand reads 41.4, without the scale
+    // reads 41.3, without the merges 39.7, without the DMAs after the first chunks 39.2, without the boundary wait + barrier 38.3,
+    // without all of these together 31.8 us. What is left in that last build -- the nibble unpack, the MFMA, the magic subtraction,
+    // the walk's control flow and the launch's fixed part -- is 78 % of the kernel: no single resource the profiler names is the bound.
+    static constexpr int CH = PF_CH, NBUF = PF_NBUF, STK_LDS = Q8 ? 1 : 2;
+    static constexpr int LDS_BYTES = NBUF * CH * SLOT + STK_LDS * 64 * NT;
+    // DMA instructions one wave issues per chunk (its vmcnt share): rows r = sub, sub + NSUB, ... of its step; a tail row is one DMA per
+    // small array that has pieces in it (see `seg` in the kernel)
+    static constexpr int n_dma(int sub) {
+        constexpr int NSUB_ = 8 / CH;
+        const int first[5] = {0, P_WSC, P_WSC + P_WQH, P_WSC + P_WQH + P_XD, P_WSC + P_WQH + P_XD + P_XS};
+        const int count[5] = {P_WSC, P_WQH, P_XD, P_XS, P_XO};
+        int n = 0;
+        for (int r = 0; r < NR; r++) {
+            if (r % NSUB_ != sub) continue;
+            if (r < NW + 2) { n++; continue; }
+            const int lo = 64 * (r - NW - 2), hi = lo + 64;
+            for (int a = 0; a < 5; a++) if (count[a] != 0 && first[a] < hi && first[a] + count[a] > lo) n++;
+        }
+        return n;
+    }
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -228,6 +262,12 @@ template <int FMT>
 __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
     typedef MF<FMT> M;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef PF_EXP_STAMP
+    // timing-only build: workgroup 0's thread 0 overwrites y[0][0 .. 5] with its own timeline in microseconds (100 MHz wall clock):
+    // prologue issued, first chunk landed, walk done, epilogue done; y[0][5] = the wall clock at entry (low bits), for launch gaps
+    const unsigned long long st_t0 = wall_clock64();
+    unsigned long long st_t1 = 0, st_t2 = 0, st_t3 = 0;
+#endif
     const int64_t N = A.N, T = A.T, ldy = A.ldy;
     const int nb = A.nb, RT = A.RT, C = A.C;
     // XCD-aware tile map: block id -> XCD id % 8; the token tiles of one 128-row panel run on the same XCD and share its L2
@@ -282,7 +322,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
         const int64_t b = b_nx;
-        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned) ((M::CH * (k & 1) + st_w) * M::SLOT));
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned) ((M::CH * (k % M::NBUF) + st_w) * M::SLOT));
 #pragma unroll
         for (int r = 0; r < M::NR; r++) {
             if (r % NSUB != sub_w) continue;                         // (wave-uniform)
@@ -323,9 +363,9 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
         b_nx = blk_of(k + 1);
     };
 
-    // two chunk buffers (a third one in flight was measured: no gain)
     const int n_chunks = (n_steps + M::CH - 1) / M::CH;
-    issue(0);
+#pragma unroll
+    for (int k0 = 0; k0 < M::NBUF - 1; k0++) if (k0 < n_chunks) issue(k0);
 
     // ---- software pipeline. Step sigma = one quantisation block of the walk. While the f32 fold of step sigma runs on the VALU,
     //      the MFMA of step sigma + 1 runs on the matrix pipe and the LDS reads of step sigma + 2 are in flight:
@@ -352,18 +392,38 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
             // chunk boundary: this wave's part of chunk k has landed (issued one chunk ago); after the barrier everybody's has, and
             // every wave has finished reading the buffer the next chunk goes into (its last reads are two stages back)
             const int k = sg_l / M::CH;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // chunk k has landed when only the DMAs of the younger chunks k + 1 .. k + NBUF - 2 are outstanding (vmcnt counts this wave's)
+#ifdef PF_EXP_NOSYNC
+            if (false) { } else if (true) { } else
+#endif
+            if (M::NBUF > 2 && k + M::NBUF - 2 < n_chunks) {
+                if (NSUB == 1 || sub_w == 0) wait_vm<M::n_dma(0) * (M::NBUF - 2)>(); else wait_vm<M::n_dma(NSUB - 1) * (M::NBUF - 2)>();
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#ifndef PF_EXP_NOSYNC
             __syncthreads();
-            if (k + 1 < n_chunks) issue(k + 1);
+#endif
+#ifdef PF_EXP_NODMA
+            if (k + M::NBUF - 1 < n_chunks && k < 1) issue(k + M::NBUF - 1);
+#else
+            if (k + M::NBUF - 1 < n_chunks) issue(k + M::NBUF - 1);
+#endif
             to_bnd = k + 1 < n_chunks ? M::CH : 0x40000000;      // (no boundary behind the last chunk)
         }
         to_bnd--;
+#ifdef PF_EXP_NOOPS
+        if (sg_l <= 2)
+#endif
         n_braw = *reinterpret_cast<const int4 *>(lds + (off_l + a_braw));
         n_scw = *reinterpret_cast<const unsigned *>(lds + (off_l + a_scw));
+#ifdef PF_EXP_NOOPS
+        if (sg_l <= 2)
+#endif
         n_aop = *reinterpret_cast<const v4i *>(lds + (off_l + a_aop));
         if constexpr (M::QH) n_qhw = *reinterpret_cast<const unsigned *>(lds + (off_l + a_scw + (M::OFF_WQH - M::OFF_WSC)));
         off_s = off_l;
-        off_l = off_l == (2 * M::CH - 1) * M::SLOT ? 0u : off_l + M::SLOT;
+        off_l = off_l == (M::NBUF * M::CH - 1) * M::SLOT ? 0u : off_l + M::SLOT;
         sg_l++;
     };
     // The MFMA accumulates onto the bit pattern of 1.5 * 2^23: for |sum| < 2^22 the result, read as a float, IS 12582912 + sum exactly,
@@ -404,6 +464,9 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
     // Tokens of register r: (r & 3) + 8 (r >> 2) + 4 h.
     auto read_scales = [&]() {                   // of the step whose codes load_ops read last
         const unsigned char * S = lds + (off_s + a_xd);
+#ifdef PF_EXP_NODX
+        if (sg_l > 2) return;
+#endif
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const float4 dx4 = *reinterpret_cast<const float4 *>(S + 32 * g);
@@ -415,7 +478,7 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
             }
         }
     };
-    int sigma = 0;
+    [[maybe_unused]] int sigma = 0;          // (read by the timing-only builds)
     // One step: fold block sigma into cur (FIRST: the leaf's first block, cur = fma(.., .., +0)), start block sigma + 1, read block
     // sigma + 2. Every LDS read is issued a stage before its use: the eight waves of the workgroup run in lock-step between the chunk
     // barriers, so a read that is waited for right away queues behind everybody else's (measured: 46 % of the wave cycles in waits).
@@ -435,6 +498,9 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
         PIN8(sf);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (M::OVERLAP) launch();
+#ifdef PF_EXP_NOFOLD
+        if (sigma == 0)
+#endif
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const v2f zero = {0.0f, 0.0f};
@@ -452,14 +518,20 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
 #undef PIN8
         sigma++;
     };
+#ifdef PF_EXP_STAMP
+    st_t1 = wall_clock64();
+#endif
     load_ops();          // operands of step 0
+#ifdef PF_EXP_STAMP
+    st_t2 = wall_clock64();
+#endif
     launch();            // block sums of step 0 under way
     read_scales();
     load_ops();          // operands of step 1
 
     // ---- the walk: leaves in bit-reversed order, 8 per iteration of the outer loop (the merges are compile-time code) ----
     v2f s0[8], s1[8], s2[8], S3[8], S4[8], S5[8], V[8];
-    v2f * stk = reinterpret_cast<v2f *>(lds + 2 * M::CH * M::SLOT);   // [level][j][thread]
+    v2f * stk = reinterpret_cast<v2f *>(lds + M::NBUF * M::CH * M::SLOT);   // [level][j][thread]
     constexpr int REV3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
     const int rng = a1 - a0;                     // 8, or 4 / 2 / 1 for a part of a split walk: the merges stop at the part's own root
 #pragma unroll 1
@@ -479,7 +551,11 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
                 for (int j = 0; j < 8; j++) cur[j] = (v2f){0.0f, 0.0f};
             }
             // merges after leaf c = 8 a + u: one per trailing one bit of c
+#ifdef PF_EXP_NOMERGE
+            if (u == 7) { for (int j = 0; j < 8; j++) V[j] = s0[j] + cur[j]; } else if (false) {
+#else
             if (u == 1 || u == 5) {
+#endif
 #pragma unroll
                 for (int j = 0; j < 8; j++) s1[j] = s0[j] + cur[j];
             } else if (u == 3) {
@@ -518,6 +594,9 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
 #undef STK_GET
 #undef STK_PUT
     }
+#ifdef PF_EXP_STAMP
+    st_t3 = wall_clock64();
+#endif
     // ---- split walk: V is this part's subtree sum; k_mmq_combine adds the parts in tree order and applies the epilogue ----
     if (A.split > 1) {
         const int64_t n_tiles = (int64_t) gridDim.y * ((RT + M::RGN - 1) / M::RGN) * C;
@@ -536,6 +615,14 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
             if (t < T) y[t * ldy + n] = apply_epi(epi, V[r >> 1][r & 1], t, n, ldy);
         }
     }
+#ifdef PF_EXP_STAMP
+    __syncthreads();
+    if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && tid == 0) {
+        const unsigned long long st_t4 = wall_clock64();
+        y[0] = (float) (st_t1 - st_t0) * 0.01f; y[1] = (float) (st_t2 - st_t0) * 0.01f; y[2] = (float) (st_t3 - st_t0) * 0.01f;
+        y[3] = (float) (st_t4 - st_t0) * 0.01f; y[4] = (float) n_steps; y[5] = (float) (st_t0 & 0xFFFFFF) * 0.01f;
+    }
+#endif
 }
 
 

@@ -1,0 +1,12 @@
+#!/bin/bash
+# k_mmq_mfma chunk pipeline depth: correctness of the default + timing of the variants given as arguments
+set -u
+cd "$(dirname "$0")/.."
+O=gpurun_out/r04r; mkdir -p $O
+export TMPDIR=/tmp RWKV_BENCH_DIR=/tmp RWKV_BENCH_NO_COLD=1
+( timeout 250 python -m pytest tests/test_gpu_prefill.py -m gpu -q -x -p no:cacheprovider -k "mfma_gemm or sequence_pass" 2>&1 | tail -4 ) > $O/pytest_gemm.txt; cat $O/pytest_gemm.txt
+one() {
+  env RWKV_LIB_DIR=$2 timeout 100 python bench.py --config ${3:-rwkv6-1b6} --dtype ${4:-Q4_0} --mode prefill --steps 3 --warmup 1 --cpu-seconds 0 --parity-tokens 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$1 ${3:-rwkv6-1b6} ${4:-Q4_0}', round(d['value'],1), 'tok/s', round(d['ms_per_step'],2), 'ms; gemm', round(r['avg_launch_us'],2), 'us x', r['launches'], flush=True)"
+}
+for L in "$@"; do one $L $L; done 2>&1 | tee $O/variants.txt
+for L in lib_prev lib; do one $L $L rwkv7-2b9 Q5_1; one $L $L rwkv6-1b6 Q8_0; done 2>&1 | tee -a $O/variants.txt
