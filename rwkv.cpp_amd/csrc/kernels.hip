@@ -383,25 +383,24 @@ __global__ __launch_bounds__(256) void k_mmf16_seq(MfArgs p) {
     for (int r = 0; r < 16; r++) mine[r * 256 + tid] = acc[r];
 }
 
+// (blockIdx.z = register r of the thread's 16 outputs: sixteen times the workgroups, each thread one output -- its parts are loaded
+//  together, not in `ksplit` dependent rounds of sixteen, and added in part order as before)
 __global__ __launch_bounds__(256) void k_mmf16_combine(MfArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5, tw = wave & 1, nw = wave >> 1;
     const int64_t n0 = (int64_t) blockIdx.x * 64, t0 = (int64_t) blockIdx.y * 64;
     const int64_t tile = (int64_t) blockIdx.y * gridDim.x + blockIdx.x;
-    const float * base = p.part + (tile * p.ksplit * 16) * 256;
-    float sum[16];
+    const int r = blockIdx.z;
+    const float * base = p.part + (tile * p.ksplit * 16 + r) * 256 + tid;
+    float part[8];                                               // (MF_MAX_SPLIT)
 #pragma unroll
-    for (int r = 0; r < 16; r++) sum[r] = base[r * 256 + tid];
-    for (int z = 1; z < p.ksplit; z++)
+    for (int z = 0; z < 8; z++) part[z] = z < p.ksplit ? base[(int64_t) z * 16 * 256] : 0.0f;
+    float sum = part[0];
 #pragma unroll
-        for (int r = 0; r < 16; r++) sum[r] += base[((int64_t) z * 16 + r) * 256 + tid];
+    for (int z = 1; z < 8; z++) if (z < p.ksplit) sum += part[z];
     const int64_t n = n0 + 32 * nw + i;
-    if (n >= p.N) return;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int64_t t = t0 + 32 * tw + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (t < p.T) p.y[t * p.ldy + n] = apply_epi(p.epi, sum[r], t, n, p.ldy);
-    }
+    const int64_t t = t0 + 32 * tw + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    if (n < p.N && t < p.T) p.y[t * p.ldy + n] = apply_epi(p.epi, sum, t, n, p.ldy);
 }
 
 static bool seq_f16_on_mfma() {   // (read per call: the test suite runs both arms in one process)
@@ -412,7 +411,7 @@ static bool seq_f16_on_mfma() {   // (read per call: the test suite runs both ar
 // workspace of the split-K form (partial tiles), one per device and STREAM SLOT: launches of one stream are ordered, so a stream can
 // reuse its workspace launch after launch; contexts (= streams) of one device get different slots
 static std::mutex g_mf_mu;
-constexpr int64_t MF_MAX_TILES = 128, MF_MAX_SPLIT = 8;
+constexpr int64_t MF_MAX_TILES = 128, MF_MAX_SPLIT = 8;     // (k_mmf16_combine holds MF_MAX_SPLIT parts in registers)
 struct MfWs { int dev; hipStream_t st; float * part; };
 static std::vector<MfWs> g_mf_ws;
 static float * mf_workspace(int dev, hipStream_t st) {
@@ -441,7 +440,7 @@ void launch_matvec_f(const DevTensor & W, const float * x, int64_t ldx, int64_t 
         }
         const dim3 grid((unsigned) ((N + 63) / 64), (unsigned) ((T + 63) / 64), (unsigned) a.ksplit);
         hipLaunchKernelGGL(k_mmf16_seq, grid, dim3(256), 0, st, a);
-        if (a.ksplit > 1) hipLaunchKernelGGL(k_mmf16_combine, dim3(grid.x, grid.y), dim3(256), 0, st, a);
+        if (a.ksplit > 1) hipLaunchKernelGGL(k_mmf16_combine, dim3(grid.x, grid.y, 16), dim3(256), 0, st, a);
         return;
     }
     if (W.type == T_F16) launch_mvf_t<true>(W, x, ldx, T, y, ldy, epi, st);
