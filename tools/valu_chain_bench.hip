@@ -35,6 +35,11 @@ template <int MODE> __global__ __launch_bounds__(64) void k(float * out, const f
             v2f y = {x, a0}, pp = {p, p};
             asm volatile(REP64("v_pk_add_f32 %0, %1, %0\n\t") : "+v"(y) : "v"(pp));
             x = y.x; a0 = y.y;
+        } else if constexpr (MODE == 9) {    // the same add in the 8-byte VOP3 encoding
+            asm volatile(REP64("v_add_f32_e64 %0, %1, %0\n\t") : "+v"(x) : "v"(p));
+        } else if constexpr (MODE == 10) {   // 64 independent adds, 8-byte encoding
+            asm volatile(REP16("v_add_f32_e64 %0, %4, %0\n\tv_add_f32_e64 %1, %4, %1\n\tv_add_f32_e64 %2, %4, %2\n\tv_add_f32_e64 %3, %4, %3\n\t")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(p));
         } else if constexpr (MODE == 8) {    // DPP adds with three independent instructions after each
             asm volatile(REP64("v_add_f32_dpp %0, %1, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mul_f32 %2, %2, %1\n\tv_mul_f32 %3, %3, %1\n\tv_mul_f32 %4, %4, %1\n\t")
                          : "+v"(x), "+v"(a0), "+v"(a1), "+v"(a2) : "v"(p));
@@ -51,14 +56,14 @@ template <int MODE> static void run(const char * what, int wgs, float * out, con
     hipLaunchKernelGGL(k<MODE>, dim3(wgs), dim3(64), 0, 0, out, in, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    printf("%-70s wgs %5d: %7.1f ns per 64-add block\n", what, wgs, ms * 1e6 / iters);
+    printf("%-70s wgs %5d: %7.1f ns per 64-add block\n", what, wgs, ms * 1e6 / iters); fflush(stdout);
 }
 
 int main() {
     float * in, * out;
     hipMalloc(&in, 192 * 4); hipMalloc(&out, 8192 * 64 * 4);
     std::vector<float> h(192, 0.0f); hipMemcpy(in, h.data(), 192 * 4, hipMemcpyHostToDevice);
-    for (int wgs : {256, 1024, 2048}) {      // 1 wave per CU, ~1 per SIMD, ~2 per SIMD
+    for (int wgs : {256, 2048, 4096}) {      // 1 wave per CU, 2 per SIMD, 4 per SIMD
         run<0>("64 dependent v_add_f32", wgs, out, in);
         run<1>("64 dependent v_add_f32_dpp (row_newbcast source 0)", wgs, out, in);
         run<5>("same, s_nop 1 in front of each", wgs, out, in);
@@ -68,6 +73,8 @@ int main() {
         run<8>("64 dependent v_add_f32_dpp + 3 independent v_mul each", wgs, out, in);
         run<6>("64 independent v_add_f32", wgs, out, in);
         run<7>("64 dependent v_pk_add_f32", wgs, out, in);
+        run<9>("64 dependent v_add_f32_e64 (8-byte encoding of the same add)", wgs, out, in);
+        run<10>("64 independent v_add_f32_e64", wgs, out, in);
     }
     return 0;
 }
