@@ -955,8 +955,9 @@ bool launch_wkv6_seq(const float * r, const float * k, const float * v, const fl
 //   * the sa chain: every lane of the row adds the row's 64 products itself, in order, reading each one through a DPP row_newbcast of
 //     its owner (w7_row_sum above): 64 dependent full-rate adds per token -- the floor -- and the sum is in all 16 lanes when it ends;
 //   * the out chain IS skewed: it only reads. Lane q parks its four products s_ij r_j of token t in an LDS ring (own column, used as an
-//     indexed register file: no barrier) and at step sigma adds those of token sigma - q onto the sum it receives from lane q - 1;
-//     lane 15 emits out[sigma - 15]. Four adds per token instead of 64.
+//     indexed register file: no barrier) and at step sigma adds those of token sigma - 1 - q onto the sum it receives from lane q - 1;
+//     lane 15 emits out[sigma - 16] (one step of lag: every lane's entry is from an earlier step and is read a step ahead). Four adds per
+//     token instead of 64.
 // ~100 instructions per token and wave, 16 H workgroups of 4 waves. Per-token operands are staged through LDS in chunks of 32 tokens
 // (global loads of chunk c + 1 in flight during chunk c), read as one 16-byte vector per array and token, one token ahead.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1061,8 +1062,14 @@ __global__ __launch_bounds__(256) void k_wkv7_seq(const float * __restrict__ r, 
         o.v = l_tok[((c & 1) * CH + tt) * TOKF + 320 + row_wg];
     };
     float o_run = 0.0f;                                          // the out chain's running sum as this lane last produced it
-    // one step: `upd` = a token is consumed (state update + its products into the ring); the out chain always advances
+    float4 pq_n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);           // the ring entry this lane adds at the next step (read a step ahead)
+    int64_t t_off = -16 * D;                                     // out row of the token the chain emits at this step (sigma - 16)
+    const int64_t lane_off = h * S + i;
+    // one step: `upd` = a token is consumed (state update + its products into the ring); the out chain always advances. At step sigma
+    // lane q adds the products of token sigma - 1 - q: every lane's entry was written in an earlier step (lane 0's in the one before),
+    // so it is read a whole step ahead, right behind the ring write, and its LDS round trip is off the token's path.
     auto step = [&](int sigma, bool upd, const Tok & tk) __attribute__((always_inline)) {
+        v2f o01 = {0.0f, 0.0f}, o23 = {0.0f, 0.0f};
         if (upd) {
             const v2f p01 = (v2f){tk.a.x, tk.a.y} * s01, p23 = (v2f){tk.a.z, tk.a.w} * s23;
             // independent of sa: v k, s w and their sum
@@ -1070,18 +1077,22 @@ __global__ __launch_bounds__(256) void k_wkv7_seq(const float * __restrict__ r, 
             const v2f t01 = s01 * (v2f){tk.w.x, tk.w.y} + vv * (v2f){tk.k.x, tk.k.y};
             const v2f t23 = s23 * (v2f){tk.w.z, tk.w.w} + vv * (v2f){tk.k.z, tk.k.w};
             const float sa = w7_row_sum(p01.x, p01.y, p23.x, p23.y);
+            __builtin_amdgcn_sched_barrier(0);                   // (the out chain below stays below: its ring entry needs no wait there)
             const v2f sv = {sa, sa};
             s01 = t01 + sv * (v2f){tk.b.x, tk.b.y};
             s23 = t23 + sv * (v2f){tk.b.z, tk.b.w};
-            const v2f o01 = s01 * (v2f){tk.r.x, tk.r.y}, o23 = s23 * (v2f){tk.r.z, tk.r.w};
-            ring[(sigma & 15) * 64] = make_float4(o01.x, o01.y, o23.x, o23.y);
+            o01 = s01 * (v2f){tk.r.x, tk.r.y}; o23 = s23 * (v2f){tk.r.z, tk.r.w};
         }
-        const float4 pq = ring[((sigma - q) & 15) * 64];
-        float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o_run), 0x111, 0xF, 0xF, false)) + pq.x;
-        o += pq.y; o += pq.z; o += pq.w;
-        o_run = o;
-        const int te = sigma - 15;
-        if (q == 15 && te >= 0 && te < T) out[(int64_t) te * D + h * S + i] = o;
+        {   // (behind the sa chain: the entry read at the end of the previous step has long arrived)
+            const float4 pq = pq_n;
+            float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o_run), 0x111, 0xF, 0xF, false)) + pq.x;
+            o += pq.y; o += pq.z; o += pq.w;
+            o_run = o;
+            if (q == 15 && sigma >= 16) (out + t_off)[lane_off] = o;      // token sigma - 16 (< T: sigma < T + 16)
+            t_off += D;
+        }
+        if (upd) ring[(sigma & 15) * 64] = make_float4(o01.x, o01.y, o23.x, o23.y);
+        pq_n = ring[((sigma - q) & 15) * 64];                    // token sigma - q for step sigma + 1 (lane 15: before step sigma + 1 overwrites the slot)
     };
 
     const int n_chunks = (T + CH - 1) / CH;
@@ -1094,12 +1105,29 @@ __global__ __launch_bounds__(256) void k_wkv7_seq(const float * __restrict__ r, 
         const int n = T - CH * c < CH ? T - CH * c : CH;
         Tok ta, tb;
         read_tok(c, 0, ta);
-        for (int tt = 0; tt < n; tt += 2) {
-            if (tt + 1 < CH) read_tok(c, tt + 1, tb);
-            step(CH * c + tt, true, ta);
-            if (tt + 1 < n) {
-                if (tt + 2 < CH) read_tok(c, tt + 2, ta);
+        if (n == CH) {
+            // whole chunk: no conditions inside, and the LDS queue has the same shape on entry as on the back edge (the ring entry is
+            // read again -- the same one -- behind the first token's operands), so the operand waits are counted and wait for nothing
+            // that was issued after what they need
+            pq_n = ring[((CH * c - 1 - q) & 15) * 64];
+#pragma unroll 1
+            for (int tt = 0; tt < CH - 2; tt += 2) {
+                read_tok(c, tt + 1, tb);
+                step(CH * c + tt, true, ta);
+                read_tok(c, tt + 2, ta);
                 step(CH * c + tt + 1, true, tb);
+            }
+            read_tok(c, CH - 1, tb);
+            step(CH * c + CH - 2, true, ta);
+            step(CH * c + CH - 1, true, tb);
+        } else {
+            for (int tt = 0; tt < n; tt += 2) {
+                if (tt + 1 < CH) read_tok(c, tt + 1, tb);
+                step(CH * c + tt, true, ta);
+                if (tt + 1 < n) {
+                    if (tt + 2 < CH) read_tok(c, tt + 2, ta);
+                    step(CH * c + tt + 1, true, tb);
+                }
             }
         }
         if (more) commit(c + 1);
@@ -1107,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_wkv7_seq(const float * __restrict__ r, 
     }
     {
         Tok none{};
-        for (int sigma = T; sigma < T + 15; sigma++) step(sigma, false, none);   // drain the out chain
+        for (int sigma = T; sigma < T + 16; sigma++) step(sigma, false, none);   // drain the out chain
     }
     *reinterpret_cast<float4 *>(state_out + h * S * S + (int64_t) i * S + 4 * q) = make_float4(s01.x, s01.y, s23.x, s23.y);
 }
