@@ -55,12 +55,21 @@ def test_prefill_stamp_covers_the_gemm_and_not_the_wkv7_section(tmp_path):
     assert b.prefill_source_stamp() != base
 
 
-def test_committed_quotes_belong_to_the_committed_sources():
-    """The quotes in profiles/ were taken on the sources in the tree: a commit that edits a kernel re-takes its PMC pass (or bench.py prints
-    the quote as stale, which the docs then have to say)."""
+def test_a_quote_is_either_of_this_build_or_reported_stale():
+    """bench.py never repeats a quote from another build: for the sources in the tree each committed quote either carries their hash
+    (then it is quoted) or is reported as stale (then the line says so). Both are honest; quoting with a foreign hash is not."""
+    import types
     b = _bench()
-    mf = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma.json")))
-    assert mf["rwkv6-1b6:Q4_0:prefill"]["prefill_source_stamp"] == b.prefill_source_stamp()
+    mf = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma.json")))["rwkv6-1b6:Q4_0:prefill"]
+    got = b.mfma_busy(types.SimpleNamespace(config="rwkv6-1b6", dtype="Q4_0"))
+    if mf["prefill_source_stamp"] == b.prefill_source_stamp():
+        assert got == mf
+    else:
+        assert set(got) == {"stale"}
+    traffic, source = b.pmc_traffic(2, types.SimpleNamespace(config="rwkv6-7b", dtype="Q4_0"), kind=2)
     tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    stamps = {e.get("kernel_source_stamp") for e in tr.values() if isinstance(e, dict)}
-    assert b.kernel_source_stamp(2) in stamps, (stamps, b.kernel_source_stamp(2))
+    fresh = any(isinstance(e, dict) and e.get("kernel_source_stamp") == b.kernel_source_stamp(2) for e in tr.values())
+    if fresh:
+        assert traffic is not None and traffic > 1e9
+    else:
+        assert traffic is None and source and source.startswith("stale")
