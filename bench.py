@@ -483,6 +483,11 @@ def bench_chain(args, pkg, lib, path, spec, torch):
         # the chain against a one-device context of the same file (itself checked against the CPU oracle by the N = 1 line and tests/)
         k = min(args.parity_tokens, args.steps)
         ref = pkg.RWKVModel(lib, path)
+        bpt = ref.bytes_per_token()            # the whole model's algorithmic bytes per token (the chain's stages together stream the same)
+        result["roofline"] = {"bound": "hbm", "kernel": "the stages' single-token kernels, one stage active at a time", "achieved": bpt * single_tok_s / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt * single_tok_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                              "note": "algorithmic bytes per token x tokens/s of the whole chain (hops and launch gaps included); per-kernel launch times "
+                                      "and PMC traffic are quoted by the N = 1 line"}
         ref.state_load(None)
         rt, _ = ref.decode_greedy(first, k)
         rs = ref.state_store()

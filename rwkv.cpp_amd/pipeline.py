@@ -413,6 +413,13 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
                                  "aggregate throughput, weak scaling"},
         "hbm": {"algorithmic_bytes_per_token": int(bpt.item()), "achieved_GBps_single_stream": bpt.item() * single_tok_s / 1e9,
                 "achieved_GBps_aggregate": bpt.item() * total_tok_s / 1e9},
+        # one stream keeps ONE stage busy at a time: its rate is priced against one GPU's HBM, the aggregate against all of them
+        "roofline": {"bound": "hbm", "kernel": "the stages' single-token kernels (%s), one stage active at a time" % path_used.split(" (")[0],
+                     "achieved": bpt.item() * single_tok_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": bpt.item() * single_tok_s / 1e9 / 8000.0,
+                     "traffic": None,
+                     "aggregate": {"achieved": bpt.item() * total_tok_s / 1e9, "peak": 8000.0 * world, "frac": bpt.item() * total_tok_s / 1e9 / (8000.0 * world)},
+                     "note": "algorithmic bytes of all stages per token x tokens/s (whole pipeline, launch gaps and hops included); per-kernel launch "
+                             "times and PMC traffic are quoted by the N = 1 line"},
     }
     if comms:
         comms.close()
