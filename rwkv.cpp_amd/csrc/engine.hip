@@ -125,6 +125,48 @@ static void calibrate_decode_path(rwkv_context * ctx) {
     if (!keep) { mega_chain_forget(ctx); mega_chain_count(ctx, -1); }
 }
 
+// The same question for RWKV-4 / RWKV-7: the persistent launch of persist_v47.hip against the fused per-layer launches (fused_v7.hip).
+static void calibrate_decode_path_v47(rwkv_context * ctx) {
+    if (!ctx->mega) return;
+    const char * e = getenv("RWKV_MI_NO_AUTOTUNE");
+    if (e && e[0] == '1') return;
+    Model & m = *ctx->model;
+    uint32_t * tok = nullptr;
+    if (hipMalloc((void **) &tok, 256) != hipSuccess) return;
+    const size_t sbytes = (size_t) m.state_len() * sizeof(float);
+    bool ok = hipMemsetAsync(tok, 0, 256, ctx->stream) == hipSuccess;
+    uint32_t * saved_tokens = ctx->d_tokens;
+    ctx->d_tokens = tok;
+    void * const h = ctx->mega;
+    auto timed = [&](void * hh) -> float {
+        ctx->mega = hh;
+        ctx->cur = 0;
+        ok = ok && state_from_host(ctx, nullptr);
+        for (int i = 0; i < 2 && ok; i++) ok = forward(ctx, 1, m.has_head);
+        ok = ok && hipEventRecord(ctx->ev0, ctx->stream) == hipSuccess;
+        for (int i = 0; i < 6 && ok; i++) ok = forward(ctx, 1, m.has_head);
+        ok = ok && hipEventRecord(ctx->ev1, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+        float ms = 0.0f;
+        ok = ok && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess;
+        return ms;
+    };
+    (void) sbytes;
+    float t_p = timed(h);
+    bool bad = !ok || mega_v6_aborted(h, ctx->stream);
+    if (bad) { if (mega_v6_aborted_cached(h)) (void) mega_v6_clear_abort(h, ctx->stream); ok = true; t_p = 1e30f; }
+    const float t_fused = timed(nullptr);
+    (void) hipStreamSynchronize(ctx->stream);
+    ctx->d_tokens = saved_tokens;
+    ctx->cur = 0;
+    ctx->last_error = 0;
+    (void) hipFree(tok);
+    const bool keep = ok && !bad && !(t_fused < 0.97f * t_p);
+    if (!keep) mega_v6_destroy(h);
+    ctx->mega = keep ? h : nullptr;
+    if (ok) m.decode_choice.store(keep ? 4 : 3);
+    if (!keep) { mega_chain_forget(ctx); mega_chain_count(ctx, -1); }
+}
+
 // After a poll time-out of the persistent kernel (the device was shared): the stream is drained, the abort word cleared, the
 // persistent path and the captured graphs dropped; the context continues on the per-layer launches. The state buffer the failed
 // step READ is intact (the kernel only writes the other one): the caller may flip `cur` back and repeat the step.
@@ -186,6 +228,14 @@ rwkv_context * create_context(Model * m, uint32_t n_threads) {
     if (!(nf && nf[0] == '1') && fused_v4_supported(*m)) {
         if ((e = hipMalloc(&ctx->fused_scratch, fused_v4_scratch_bytes(*m))) != hipSuccess) return fail(e);
         ctx->fused_v4 = true;
+    }
+    if (ctx->fused_v7 || ctx->fused_v4) {
+        // one persistent launch per token (persist_v47.hip) where the geometry has a variant; the fused launches stay as the fall-back
+        const char * nm = getenv("RWKV_MI_NO_MEGA");
+        const int known = m->decode_choice.load();
+        if (!(nm && nm[0] == '1') && known != 3) ctx->mega = p47_create(*m);
+        if (ctx->mega && mega_chain_count(ctx.get(), +1) > 1) (void) hipDeviceSynchronize();
+        if (!known) calibrate_decode_path_v47(ctx.get());
     }
     // A new context starts from the reference's fresh state (rwkv_eval.inc:224-241), whatever the calibration left behind:
     // rwkv_mi_eval_resident / rwkv_mi_decode_greedy / rwkv_mi_stage_step continue from the resident state without a load.
@@ -538,8 +588,13 @@ struct Runner {
             const bool head_done = want_logits && m.has_head && le == m.layer_end && mega_v6_folds_head(ctx->mega);
             const float * s0 = sin + (int64_t) m.layer_begin * per_layer;
             float * o0 = sout + (int64_t) m.layer_begin * per_layer;
-            if (whole) mega_v6_forward(ctx->mega, b.x, s0, o0, st, &ctx->prof, head_done ? ctx->d_logits : nullptr);
-            else ring_v6_forward_range(ctx->mega, b.x, s0, o0, st, nullptr, head_done ? ctx->d_logits : nullptr, (int) (lb - m.layer_begin), (int) (le - m.layer_begin));
+            if (whole) mega_v6_forward(ctx->mega, b.x, s0, o0, st, &ctx->prof, head_done ? ctx->d_logits : nullptr, b.v_first);
+            else {
+                // (a range's state pointers are those of ITS first layer for persist_v47.hip, of the stage's first layer for the ring kernel)
+                const bool own_base = mega_v6_kind(ctx->mega) == 3;
+                const int64_t so = own_base ? (int64_t) (lb - m.layer_begin) * per_layer : 0;
+                mega_v6_forward_range(ctx->mega, b.x, s0 + so, o0 + so, st, nullptr, head_done ? ctx->d_logits : nullptr, (int) (lb - m.layer_begin), (int) (le - m.layer_begin), b.v_first);
+            }
             return head_done;
         }
         for (uint32_t i = lb; i < le; i++) {
@@ -665,7 +720,7 @@ bool forward_streamed_eligible(const rwkv_context * ctx) {
     if ((e && e[0] == '0') || !ctx->stages.empty() || !ctx->owns_stream) return false;
     const Model & m = *ctx->model;
     if (m.layer_end - m.layer_begin < 2 || !m.has_embed || !m.has_head) return false;
-    if (ctx->mega && mega_v6_kind(ctx->mega) != 2) return false;     // (the register-prefetch kernel has no layer-range launch)
+    if (ctx->mega && !mega_v6_has_range(ctx->mega)) return false;     // (the register-prefetch kernel has no layer-range launch)
     if (e && e[0] == '1') return true;
     return (size_t) m.state_len() * sizeof(float) >= ((size_t) 4 << 20);   // small states: the serial copies are already cheap
 }

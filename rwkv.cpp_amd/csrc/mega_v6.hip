@@ -812,9 +812,11 @@ static int mega_variant(const Model & m, int n_cu) {
 }
 
 static bool is_ring(void * h) { return h && *(const int *) h == 2; }
+static bool is_p47(void * h) { return h && *(const int *) h == 3; }
 
 void mega_v6_destroy(void * h) {
     if (is_ring(h)) { ring_v6_destroy(h); return; }
+    if (is_p47(h)) { p47_destroy(h); return; }
     MegaV6 * mg = (MegaV6 *) h;
     if (!mg) return;
     if (mg->d_layers) (void) hipFree(mg->d_layers);
@@ -922,6 +924,7 @@ void * mega_v6_create_kind(const Model & m, int kind) {
 // debug: cycle stamps of one layer (16 per wave) for the next launches; out must hold n_blocks * 8 * 32 values
 bool mega_v6_trace(void * h, int layer, long long * out, bool fetch) {
     if (is_ring(h)) return ring_v6_trace(h, layer, out, fetch);
+    if (is_p47(h)) return p47_trace(h, layer, out, fetch);
     MegaV6 * mg = (MegaV6 *) h;
     const size_t n = (size_t) mg->n_blocks * 8 * 32;
     if (!mg->trace) { if (hipMalloc((void **) &mg->trace, n * 8) != hipSuccess) return false; (void) hipMemset(mg->trace, 0, n * 8); }
@@ -931,13 +934,20 @@ bool mega_v6_trace(void * h, int layer, long long * out, bool fetch) {
 }
 
 int mega_v6_kind(void * h) { return h ? *(const int *) h : 0; }
-uint64_t mega_v6_bytes(void * h) { if (is_ring(h)) return ring_v6_bytes(h); return ((MegaV6 *) h)->bytes; }
+uint64_t mega_v6_bytes(void * h) { if (is_ring(h)) return ring_v6_bytes(h); if (is_p47(h)) return p47_bytes(h); return ((MegaV6 *) h)->bytes; }
 
 // sin / sout: state of the stage's FIRST layer. One launch covers every layer of the stage.
 bool mega_v6_folds_head(void * h) { return is_ring(h) && ring_v6_folds_head(h); }
 
-void mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits) {
+bool mega_v6_has_range(void * h) { return is_ring(h) || is_p47(h); }
+void mega_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1, float * v_first) {
+    if (is_p47(h)) { p47_forward_range(h, x, v_first, sin, sout, st, pf, l0, l1); return; }
+    ring_v6_forward_range(h, x, sin, sout, st, pf, logits, l0, l1);
+}
+
+void mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, float * v_first) {
     if (is_ring(h)) { ring_v6_forward(h, x, sin, sout, st, pf, logits); return; }
+    if (is_p47(h)) { p47_forward_range(h, x, v_first, sin, sout, st, pf, 0, p47_layers(h)); return; }
     MegaV6 * mg = (MegaV6 *) h;
     M6P q = mg->proto;
     q.x = x; q.sin = sin; q.sout = sout;
@@ -961,10 +971,11 @@ void mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipSt
 // blocking hipMemcpy would go through the legacy null stream and couple every blocking stream of the process.)
 bool mega_v6_ctl_fetch(void * h, hipStream_t st) {
     if (is_ring(h)) return ring_v6_ctl_fetch(h, st);
+    if (is_p47(h)) return p47_ctl_fetch(h, st);
     MegaV6 * mg = (MegaV6 *) h;
     return hipMemcpyAsync(mg->h_ctl, mg->ctl, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess;
 }
-bool mega_v6_aborted_cached(void * h) { if (is_ring(h)) return ring_v6_aborted_cached(h); return ((MegaV6 *) h)->h_ctl[1] != 0; }
+bool mega_v6_aborted_cached(void * h) { if (is_ring(h)) return ring_v6_aborted_cached(h); if (is_p47(h)) return p47_aborted_cached(h); return ((MegaV6 *) h)->h_ctl[1] != 0; }
 bool mega_v6_aborted(void * h, hipStream_t st) {
     if (!mega_v6_ctl_fetch(h, st) || hipStreamSynchronize(st) != hipSuccess) return true;
     return mega_v6_aborted_cached(h);
@@ -972,6 +983,7 @@ bool mega_v6_aborted(void * h, hipStream_t st) {
 // clears the abort word (after the caller has drained the stream), so that the handle -- or the context that drops it -- is usable again
 bool mega_v6_clear_abort(void * h, hipStream_t st) {
     if (is_ring(h)) return ring_v6_clear_abort(h, st);
+    if (is_p47(h)) return p47_clear_abort(h, st);
     MegaV6 * mg = (MegaV6 *) h;
     mg->h_ctl[1] = 0u;
     return hipMemsetAsync(mg->ctl + 1, 0, sizeof(unsigned), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
@@ -979,11 +991,13 @@ bool mega_v6_clear_abort(void * h, hipStream_t st) {
 // the tag generation the next launch starts from (ctl[0]), through the pinned mirror
 unsigned mega_v6_generation(void * h, hipStream_t st) {
     if (!mega_v6_ctl_fetch(h, st) || hipStreamSynchronize(st) != hipSuccess) return 0;
+    if (is_p47(h)) return p47_generation_cached(h);
     return is_ring(h) ? ring_v6_generation_cached(h) : ((MegaV6 *) h)->h_ctl[0];
 }
 // Test hook: presets the rolling tag generation (ctl[0]; the kernel compares its low 16 bits), e.g. just below a 16-bit wrap.
 bool mega_v6_set_tag(void * h, unsigned base, hipStream_t st) {
     if (is_ring(h)) return ring_v6_set_tag(h, base, st);
+    if (is_p47(h)) return p47_set_tag(h, base, st);
     MegaV6 * mg = (MegaV6 *) h;
     if (hipStreamSynchronize(st) != hipSuccess) return false;
     return hipMemcpy(mg->ctl, &base, sizeof(unsigned), hipMemcpyHostToDevice) == hipSuccess;

@@ -37,7 +37,8 @@ struct Model {
     int64_t head_count = 0, head_size = 0, ffn_size = 0;
     int64_t max_lowrank = 0;  // widest intermediate of a low-rank pair (v6 5*r, decay rank; v7 ranks)
     // Single-token path the first context of this model measured as fastest on its device (engine.hip, calibrate_decode_path):
-    // 0 not measured, 1 persistent kernel on register prefetch, 2 persistent kernel on the LDS-DMA ring, 3 seven launches per layer.
+    // 0 not measured, 1 persistent kernel on register prefetch, 2 persistent kernel on the LDS-DMA ring, 3 seven launches per layer
+    // (RWKV-6; RWKV-4 / RWKV-7: 4 persistent kernel of persist_v47.hip, 3 the fused per-layer launches).
     // Clones reuse it instead of timing every path again.
     mutable std::atomic<int> decode_choice{0};
 
@@ -216,7 +217,10 @@ void *   mega_v6_create(const Model & m);   // nullptr: not applicable. RWKV_MI_
 void *   mega_v6_create_kind(const Model & m, int kind);   // 1: register prefetch, 2: LDS-DMA weight ring
 void     mega_v6_destroy(void * h);
 // logits != nullptr and mega_v6_folds_head(h): ln_out + the head projection run inside the launch (the caller skips its own)
-void     mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits = nullptr);
+void     mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits = nullptr, float * v_first = nullptr);
+// a layer range [l0, l1) of the stage (ring_v6.hip and persist_v47.hip have one; indices into the stage's own layers)
+void     mega_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1, float * v_first = nullptr);
+bool     mega_v6_has_range(void * h);
 bool     mega_v6_folds_head(void * h);
 bool     mega_v6_ctl_fetch(void * h, hipStream_t st);       // async copy of the control words into the pinned mirror
 bool     mega_v6_aborted_cached(void * h);                  // the mirror's abort word (valid after the stream was synchronised)
@@ -226,7 +230,19 @@ bool     mega_v6_set_tag(void * h, unsigned base, hipStream_t st);
 unsigned mega_v6_generation(void * h, hipStream_t st);   // the hand-over generation the next launch starts from
 uint64_t mega_v6_bytes(void * h);
 bool     mega_v6_trace(void * h, int layer, long long * out, bool fetch);
-int      mega_v6_kind(void * h);            // 1: register prefetch (mega_v6.hip), 2: LDS-DMA weight ring (ring_v6.hip)
+int      mega_v6_kind(void * h);            // 1: register prefetch (mega_v6.hip), 2: LDS-DMA weight ring (ring_v6.hip), 3: RWKV-4 / RWKV-7 (persist_v47.hip)
+// persistent single-launch RWKV-4 / RWKV-7 decode (persist_v47.hip); reached through the mega_v6_* entry points
+void *   p47_create(const Model & m);
+void     p47_destroy(void * h);
+void     p47_forward_range(void * h, float * x, float * v_first, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, int l0, int l1);
+int      p47_layers(void * h);
+bool     p47_ctl_fetch(void * h, hipStream_t st);
+bool     p47_aborted_cached(void * h);
+unsigned p47_generation_cached(void * h);
+bool     p47_clear_abort(void * h, hipStream_t st);
+bool     p47_set_tag(void * h, unsigned base, hipStream_t st);
+uint64_t p47_bytes(void * h);
+bool     p47_trace(void * h, int layer, long long * out, bool fetch);
 // the same persistent launch on the LDS-DMA weight ring (ring_v6.hip); reached through the mega_v6_* entry points
 void *   ring_v6_create(const Model & m);
 void     ring_v6_destroy(void * h);

@@ -1,0 +1,1035 @@
+// persist_v47.hip -- the RWKV-4 and RWKV-7 single-token (decode) step over all layers of a stage as ONE persistent launch
+// (rwkv_att_v4, rwkv_graph.inc:84-197; rwkv_ffn_v4_v5, :484-511; rwkv_att_v7, :387-482; rwkv_wkv_v7_impl,
+// rwkv_operators_wkv_v7.inc:37-107; rwkv_ffn_v7, rwkv_graph.inc:533-543).
+//
+// Why: the fused per-layer launches of fused_v7.hip (RWKV-7: five, RWKV-4: four per layer) spend ~5 us per dependent launch before a byte
+// moves -- 59.9 us per 66 MB layer of the 2.9B, 450 us per token on the 169M whose weights stream in 20 us. Here the
+// layer is a chain of tagged hand-overs inside one launch, as in mega_v6.hip, with the structure cut to these architectures:
+//
+//   RWKV-4 (four hand-overs per layer)     x -> [LN1, three lerps, K / V / R rows of the SAME channels on one wave, WKV-4 of those channels,
+//                                          sigmoid(r) * wkv] -> y -> [quantise, output rows + residual] -> x -> [LN2, two lerps, key rows
+//                                          (relu^2, quantised per 32) + receptance rows] -> kq -> [value rows, gate, residual] -> x
+//   RWKV-7 (five)                          x -> [LN1, six lerps, R / K / V rows + first low-rank stages] -> r k v lr1 -> [per head on its own
+//                                          workgroup: second stages, key normalisation, WKV-7, GroupNorm + bonus, gate, quantise] -> yq ->
+//                                          [output rows + residual] -> x -> [LN2, lerp, key rows] -> kq -> [value rows + residual] -> x
+//
+// Geometry (compile time, from D; F = 4 D for both architectures): the F / 32 key groups set the number of ROW workgroups NR = F / 32 / GPB
+// (GPB = 1, or 2 when that many workgroups + the heads do not fit the chip); a row workgroup has 8 worker waves, worker w of workgroup b
+// owns rows {e0, e0 + 64 (GPB = 2)} of EVERY D-row matrix (so the residual of those rows lives in its registers for the whole token and
+// RWKV-4's per-channel recurrence is wave-local) and four rows of each of its key groups; one more wave ("comm", wave 8) polls every
+// hand-over into LDS, runs the LayerNorm statistics on what it polled (the x units are laid out so that lane l receives the elements
+// l mod 64: exactly the partials of the specified reduction tree), quantises y (RWKV-4) and the key groups, and on
+// RWKV-7 runs the workgroup's share of the first low-rank stages. RWKV-7's heads run on H further workgroups that own no rows: their
+// comm wave polls r / k / v / lr1 and runs the recurrence of kdev's k7_head statement for statement, their eight workers the second stages.
+// Weights go global -> registers one phase ahead (no ring: a workgroup's share of a 169M layer is 55 KB, of a 2.9B layer 412 KB in four
+// phases). Arithmetic and reduction orders are those of fused_v7.hip / kernels.hip and of the CPU oracle: bit-identical.
+//
+// Residency and safety as mega_v6.hip: NR (+ H) <= CUs, polls are bounded by the abort word.
+#include "persist.h"
+
+#include <cstring>
+
+namespace rwkvmi {
+
+struct P47Layer {
+    long long ln1_w, ln1_b, ln2_w, ln2_b;
+    long long mix_a[6];            // inputs of R, K, V, then (v7) w, a, g: coefficient vectors (v4: time_mix_r / _k / _v; v7: rows of x_rwkvag)
+    long long mix_f[2];            // channel mixing: key input, receptance input (v4); v7: ffn.x_k
+    long long tf, td;              // v4: time_first, time_decay
+    M6Off wr, wk, wv, wo, fk, fr, fv;
+    long long lr1[4], lr2[4];      // v7: w, a, g, v first / second stages (F16), byte offsets
+    int rank[4], lbase[4];         // ranks and their offsets in the concatenated lr1 vector (w, a, g, v)
+    long long w0, a0, v0, k_k, k_a, r_k, lnx_w, lnx_b;
+    int has_v, layer0;             // v1 / v2 / v0 exist (not on absolute layer 0); this IS absolute layer 0
+    int lr_n;                      // lr1 values produced on this layer (lr_total, or lr_total - rank_v on layer 0)
+    int pad_;
+};
+
+struct P47 {
+    const P47Layer * layers; int l0, l1;
+    const unsigned char * arena;
+    float * x; float * v_first;
+    const float * sin; float * sout; long long state_stride;
+    void * xch; unsigned xch_bytes;
+    int u_a, u_lr1, u_y, u_xatt, u_kq, u_xffn;      // unit (16-byte) offsets of the tagged buffers in the exchange arena
+    unsigned * ctl;                                  // [0] tag generation, [1] abort
+    long long * trace; int trace_layer;
+};
+
+enum { S47_A = 0, S47_Y = 1, S47_XATT = 2, S47_KQ = 3, S47_XFFN = 4 };
+
+__device__ __forceinline__ unsigned lf_ld(const unsigned * f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lf_add(unsigned * f, unsigned v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) (void) __hip_atomic_fetch_add(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lf_wait(Poll & pl, const unsigned * f, unsigned want) {
+    for (unsigned spin = 0;; spin++) {
+        if ((int) (lf_ld(f) - want) >= 0 || pl.dead) break;
+        if ((spin & 1023u) == 1023u) {
+            if (__hip_atomic_load(pl.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) pl.dead = true;
+            else if (spin > 40000000u) { __hip_atomic_store(pl.ctl + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pl.dead = true; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+// R rows row0, row0 + rstride, ... of a quantised matrix with nbk blocks per row: every load of the batch in flight (fused_blocks.h's
+// batch_issue with a row stride; rows are always valid here)
+template <int FMT, int R, int U>
+__device__ __forceinline__ void rows_issue(Batch<FMT, R, U> & bt, const WPl & w, int row0, int rstride, int nbk, int lane) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int bb = u * WAVE + lane;
+        unsigned b = (unsigned) (bb < nbk ? bb : nbk - 1);
+        asm volatile("" : "+v"(b));
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t row = row0 + r * rstride;
+            const uint8_t * rq = w.qs + row * nbk * QF<FMT>::QS;
+            RawBlk<FMT> & o = bt.raw[u][r];
+            if constexpr (QF<FMT>::HM) o.sc = ldw4(reinterpret_cast<const uint32_t *>(w.sc) + row * nbk + b);
+            else o.sc = ldw2(reinterpret_cast<const uint16_t *>(w.sc) + row * nbk + b);
+            if constexpr (QF<FMT>::QH) o.qh = ldw4(w.qh + row * nbk + b);
+            o.q[0] = ldw16(rq + b * QF<FMT>::QS);
+            if constexpr (QF<FMT>::QS == 32) o.q[1] = ldw16(rq + b * QF<FMT>::QS + 16);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int FMT, int R, int U>
+__device__ __forceinline__ void rows_sum(const Batch<FMT, R, U> & bt, int nbk, int lane, const QVec & a, float (&res)[R]) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0f;
+    batch_consume<FMT, R, U>(bt, nbk, 0, lane, a, acc);
+#pragma unroll
+    for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
+}
+
+struct L47 { size_t x, sc, q, lr, yq, kq, out, fl, lr1, ch, hv, total; };
+__host__ __device__ inline L47 l47_lds(int D, bool v7) {
+    L47 o; size_t p = 0;
+    auto take = [&](size_t n) { const size_t r = p; p += m6_round16(n); return r; };
+    o.x = take((size_t) D * 4); o.sc = take(64);
+    o.q = take(3 * m6_round16(qvec_bytes(D)));
+    o.lr = take(v7 ? (size_t) 4 * D * 4 : 16);
+    o.yq = take(qvec_bytes(D)); o.kq = take(qvec_bytes(4 * (size_t) D)); o.out = take(64 * 4); o.fl = take(64);
+    // head workgroups (RWKV-7) use their own carving of the same allocation
+    size_t h = 0;
+    auto takeh = [&](size_t n) { const size_t r = h; h += m6_round16(n); return r; };
+    o.lr1 = takeh(2048 * 4); o.ch = takeh(4 * 64 * 4); o.hv = takeh(5 * 64 * 4);
+    o.total = p > h ? p : h;
+    return o;
+}
+
+#define T47(K) do { if (p.trace && li == p.trace_layer && (threadIdx.x & 63) == 0) p.trace[((long long) blockIdx.x * 9 + (threadIdx.x >> 6)) * 16 + (K)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
+
+// ARCH 4 / 7; HUB = 32-column steps of the longest second low-rank stage (max rank / 32); NL1 = 64-unit poll slots of the lr1 vector;
+// MAXJ = four-row jobs of the first low-rank stages per comm wave
+template <int ARCH, int FMT, int D, int HUB, int NL1, int MAXJ>
+struct K47 {
+    static constexpr bool V7 = ARCH == 7;
+    static constexpr int S = 64, H = D / 64;
+    static constexpr int F = 4 * D, nb = D / 32, nbF = F / 32, GK = nbF;
+    static constexpr int GPB = (GK + (V7 ? H : 0) <= 256) ? 1 : 2;
+    static constexpr int NR = GK / GPB;                     // row workgroups
+    static constexpr int NBLK = NR + (V7 ? H : 0);
+    static constexpr int UD = (nb + 63) / 64, UF = (nbF + 63) / 64;
+    static constexpr int NU = D / (64 * GPB);               // x units per lane of a comm wave
+    static constexpr int NG4 = D / 4, SL = (NG4 + 511) / 512;   // float4 groups of the prologues, slots per worker thread
+    static constexpr int DU = (3 * nb + 63) / 64, KQU = (3 * nbF + 63) / 64;
+    static constexpr int STEPS = D / 32;
+    static constexpr int NIA = V7 ? 6 : 3, NIF = V7 ? 1 : 2;
+    static_assert(D % 256 == 0 && GK % GPB == 0 && NR * 8 * GPB == D && NBLK <= 256 && NU <= 32 && KQU <= 32, "geometry");
+
+    struct Lds {
+        float * x; float * sc; unsigned char * q[3]; float * lr[4]; unsigned char * yq; unsigned char * kq; float * out; unsigned * fl;
+        float * lr1; float * ch; float * hv;
+    };
+    static __device__ __forceinline__ Lds carve(unsigned char * smem) {
+        const L47 lo = l47_lds(D, V7);
+        Lds l;
+        l.x = reinterpret_cast<float *>(smem + lo.x); l.sc = reinterpret_cast<float *>(smem + lo.sc);
+        for (int i = 0; i < 3; i++) l.q[i] = smem + lo.q + i * m6_round16(qvec_bytes(D));
+        for (int i = 0; i < 4; i++) l.lr[i] = reinterpret_cast<float *>(smem + lo.lr) + (V7 ? i * D : 0);
+        l.yq = smem + lo.yq; l.kq = smem + lo.kq; l.out = reinterpret_cast<float *>(smem + lo.out); l.fl = reinterpret_cast<unsigned *>(smem + lo.fl);
+        l.lr1 = reinterpret_cast<float *>(smem + lo.lr1); l.ch = reinterpret_cast<float *>(smem + lo.ch); l.hv = reinterpret_cast<float *>(smem + lo.hv);
+        return l;
+    }
+
+    // rows of the D-row matrices owned by worker `own` of row workgroup `blk`: unit u = 8 blk + own is polled by lane u % 64 in slot u / 64
+    static __device__ __forceinline__ int unit_of(int blk, int own) { return blk * 8 + own; }
+    static __device__ __forceinline__ int row0_of(int u) { return GPB == 1 ? u : (u & 63) + 128 * (u >> 6); }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // comm wave: an x-like vector (units in the layout above) polled into registers
+    // -----------------------------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void poll_x(Poll & pl, xrsrc xr, int src, unsigned tag, int lane, float (&xs)[NU][GPB]) {
+        // every slot of every lane carries a unit (NR * 8 = 64 NU): no per-slot validity -- a conditionally written xs[j] would be a
+        // phi(undef, value) the register allocator keeps alive around the whole layer loop
+        v4u v[NU];
+        const int mine = src + lane;
+        for (unsigned spin = 0;; spin++) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < NU; u++) v[u] = tg_load(xr, mine + u * 64);
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < NU; u++) ok = ok && tg_ok(v[u], tag);
+            if (__all(ok) || pl.dead) break;
+            if (poll_backoff(pl, spin)) break;
+        }
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+            xs[j][0] = __uint_as_float(v[j].x);
+            if constexpr (GPB == 2) xs[j][1] = __uint_as_float(v[j].y);
+        }
+    }
+    // LayerNorm statistics of the vector in xs (lane l holds the elements l + 64 s, s = GPB j + r): thread t < 256 of the specified
+    // reduction owns the partial over t, t + 256, ... -- lane l runs the four partials l, l + 64, l + 128, l + 192 itself, then the tree.
+    // Leaves x - mean in l.x and the scale in l.sc[0].
+    static __device__ __forceinline__ void ln_stats(const Lds & l, int lane, float (&xs)[NU][GPB]) {
+        double pp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+            if ((GPB * j) % 8 == 0) __builtin_amdgcn_sched_barrier(0);   // (eight elements at a time: unpinned, the scheduler converts all NU * GPB values at once and spills)
+#pragma unroll
+            for (int r = 0; r < GPB; r++) pp[(GPB * j + r) & 3] += (double) xs[j][r];
+        }
+        const float mean = (float) (wave_sum_d((pp[0] + pp[2]) + (pp[1] + pp[3])) / (double) D);
+        double qq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+            if ((GPB * j) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < GPB; r++) {
+                const float d = xs[j][r] - mean;
+                l.x[lane + 64 * (GPB * j + r)] = d;
+                qq[(GPB * j + r) & 3] += (double) (d * d);
+            }
+        }
+        const float var = (float) (wave_sum_d((qq[0] + qq[2]) + (qq[1] + qq[3])) / (double) D);
+        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        if (lane == 0) l.sc[0] = scale;
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // worker waves: elementwise part of a prologue (affine, token-shift lerps, quantisation) on the 512 worker threads
+    // -----------------------------------------------------------------------------------------------------------
+    // Slot 0 of every thread (groups tid) is loaded a phase ahead; the groups past 512 (D = 2560: 128 of them, waves 0 and 1) load theirs
+    // when they run -- two slots of RWKV-7's six coefficient vectors in registers next to the R / K / V rows in flight do not fit a wave.
+    template <int NI> struct Pro { float4 lw, lb, pv, cf[NI]; };
+    template <int NI> struct ProSrc { const float * lw; const float * lb; const float * pv; const float * cf[NI]; };
+
+    template <int NI>
+    static __device__ __forceinline__ void pro_load(Pro<NI> & pr, const ProSrc<NI> & src, int g) {
+        const int i = 4 * g;
+        pr.lw = *reinterpret_cast<const float4 *>(src.lw + i); pr.lb = *reinterpret_cast<const float4 *>(src.lb + i);
+        pr.pv = *reinterpret_cast<const float4 *>(src.pv + i);
+#pragma unroll
+        for (int c = 0; c < NI; c++) pr.cf[c] = *reinterpret_cast<const float4 *>(src.cf[c] + i);
+    }
+    template <int NI>
+    static __device__ __forceinline__ ProSrc<NI> pro_src(const M6Arena & ar, long long lw, long long lb, const long long * cf, const float * prev) {
+        ProSrc<NI> s;
+        s.lw = ar.f(lw); s.lb = ar.f(lb); s.pv = prev;
+#pragma unroll
+        for (int c = 0; c < NI; c++) s.cf[c] = ar.f(cf[c]);
+        return s;
+    }
+    // one group of four elements: affine, lerps, quantised images c < NQ; RWKV-7's time mixing also stores mixes 3, 4, 5 and 2 fp16-rounded in l.lr[0..3]
+    template <int NI, int NQ, bool LR>
+    static __device__ __forceinline__ void pro_group(const Lds & l, const Pro<NI> & pr, float scale, float * carry_out, bool write_state, int g, bool ok) {
+        const int i = 4 * g;
+        const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
+        const float xs[4] = {xc.x, xc.y, xc.z, xc.w};
+        const float lw[4] = {pr.lw.x, pr.lw.y, pr.lw.z, pr.lw.w}, lb[4] = {pr.lb.x, pr.lb.y, pr.lb.z, pr.lb.w};
+        const float pv[4] = {pr.pv.x, pr.pv.y, pr.pv.z, pr.pv.w};
+        float xn[4], mx[NI][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float y = xs[j] * scale;
+            const float yw = y * lw[j];
+            xn[j] = yw + lb[j];
+        }
+#pragma unroll
+        for (int c = 0; c < NI; c++) {
+            const float cf[4] = {pr.cf[c].x, pr.cf[c].y, pr.cf[c].z, pr.cf[c].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if constexpr (V7) {
+                    const float sx = pv[j] - xn[j];
+                    const float sm = sx * cf[j];
+                    mx[c][j] = sm + xn[j];
+                } else {
+                    const float xcf = xn[j] * cf[j], pc = pv[j] * cf[j];
+                    mx[c][j] = xcf + (pv[j] - pc);
+                }
+            }
+        }
+        if (write_state && ok) *reinterpret_cast<float4 *>(carry_out + i) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+#pragma unroll
+        for (int c = 0; c < NQ; c++) {
+            unsigned packed; float d16, s16; int isum;
+            quant_vec4(mx[c], packed, d16, s16, isum);
+            if (ok) qvec_store4(qvec_at(l.q[c], D), nb, i, packed, d16, s16, isum);
+        }
+        if constexpr (LR) {
+            if (ok) {
+                constexpr int src[4] = {3, 4, 5, 2};
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                    *reinterpret_cast<float4 *>(l.lr[m] + i) = make_float4(round_f16(mx[src[m]][0]), round_f16(mx[src[m]][1]), round_f16(mx[src[m]][2]), round_f16(mx[src[m]][3]));
+            }
+        }
+    }
+    template <int NI, int NQ, bool LR>
+    static __device__ __forceinline__ void pro_run(const Lds & l, const Pro<NI> & pr, const ProSrc<NI> & src, float * carry_out, bool write_state, int tid) {
+        const float scale = l.sc[0];
+        pro_group<NI, NQ, LR>(l, pr, scale, carry_out, write_state, tid < NG4 ? tid : 0, tid < NG4);
+#pragma unroll
+        for (int u = 1; u < SL; u++) {
+            const int wave0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
+            if (wave0 + 512 * u < NG4) {       // whole waves (NG4 % 64 == 0)
+                Pro<NI> p2;
+                pro_load<NI>(p2, src, tid + 512 * u);
+                pro_group<NI, NQ, LR>(l, p2, scale, carry_out, write_state, tid + 512 * u, true);
+            }
+        }
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // first low-rank stages (RWKV-7), four rows per job on a comm wave: lane = 16 row + q, lane q keeps partials 2q, 2q + 1 of ggml's 32
+    // -----------------------------------------------------------------------------------------------------------
+    struct Job { unsigned w[STEPS]; };
+    static __device__ __forceinline__ void job_issue(Job & jb, const unsigned char * W, int row, int lane) {
+        const uint32_t * base = reinterpret_cast<const uint32_t *>(W) + (long long) row * (D / 2) + (lane & 15);
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) jb.w[s] = ldw4(base + 16 * s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static __device__ __forceinline__ float job_row(const Job & jb, const float * l_x, int lane) {
+        const int q = lane & 15;
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const float2 xv = *reinterpret_cast<const float2 *>(l_x + 32 * s + 2 * q);
+            a0 = fmaf(h2f_bits((uint16_t) (jb.w[s] & 0xFFFFu)), xv.x, a0);
+            a1 = fmaf(h2f_bits((uint16_t) (jb.w[s] >> 16)), xv.y, a1);
+        }
+        // ggml's fold: ps[i] += ps[i + 16], ps[i] += ps[i + 8], ps[i] += ps[i + 4], (ps0 + ps1) + (ps2 + ps3)
+        a0 = a0 + __int_as_float(lane_xor8_i(__float_as_int(a0))); a1 = a1 + __int_as_float(lane_xor8_i(__float_as_int(a1)));
+        a0 = a0 + __int_as_float(lane_xor4_i(__float_as_int(a0))); a1 = a1 + __int_as_float(lane_xor4_i(__float_as_int(a1)));
+        a0 = a0 + __int_as_float(lane_xor2_i(__float_as_int(a0))); a1 = a1 + __int_as_float(lane_xor2_i(__float_as_int(a1)));
+        const float s01 = a0 + a1;
+        return s01 + __int_as_float(lane_xor1_i(__float_as_int(s01)));
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // row workgroup, comm wave
+    // -----------------------------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void row_comm(const P47 & p, const Lds & l, int lane0, unsigned base) {
+        const int blk = blockIdx.x;
+        Poll pl{p.ctl, false};
+        const M6Arena ar{p.arena};
+        const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
+        unsigned keys_done = 0;
+        for (int li = p.l0; li < p.l1; li++) {
+            const P47Layer & L = p.layers[li];
+            const unsigned tagL = base + (unsigned) (li - p.l0) * 8u;
+            T47(0);
+            // (per-phase opaque copies of the lane id: poll and LDS addresses derived from it are recomputed where they are used instead of
+            //  being hoisted out of the layer loop as ~100 loop-invariant registers -- and spilled)
+            // ---- A: x of the previous layer (or of the launch's input: the workers published it under the tag before this launch's first) ----
+            {
+                const int lane = opq(lane0);
+                float xs[NU][GPB];
+                poll_x(pl, xr, p.u_xffn, tagL - 8u + S47_XFFN, lane, xs);
+                T47(1);
+                ln_stats(l, lane, xs);
+            }
+            Job jb[V7 ? MAXJ : 1];
+            int jm[MAXJ], jrow[MAXJ]; bool jhas[MAXJ];
+            if constexpr (V7) {
+                __builtin_amdgcn_sched_barrier(0);   // (the job's loads stay behind the statistics: hoisted above them they cost the registers the poll needs)
+                const int lane = opq(lane0);
+#pragma unroll
+                for (int k = 0; k < MAXJ; k++) {
+                    const int r0 = 4 * (blk + NR * k);                       // first row of the job in the concatenated lr1 vector
+                    jhas[k] = r0 < L.lr_n;
+                    int m = 0;
+#pragma unroll
+                    for (int t = 1; t < 4; t++) if (r0 >= L.lbase[t]) m = t;
+                    jm[k] = jhas[k] ? m : 0;
+                    jrow[k] = jhas[k] ? r0 - L.lbase[m] + (lane >> 4) : 0;
+                    job_issue(jb[k], p.arena + L.lr1[jm[k]], jrow[k], lane);
+                }
+            }
+            T47(2);
+            __syncthreads();   // B1: x - mean and the scale are in LDS
+            __syncthreads();   // B2: the workers' images
+            if constexpr (V7) {
+                const int lane = opq(lane0);
+#pragma unroll
+                for (int k = 0; k < MAXJ; k++) {
+                    float v = job_row(jb[k], l.lr[0] + jm[k] * D, lane);   // (one base + offset: an indexed pointer array would live in scratch as generic pointers)
+                    if (jm[k] == 0) v = det_tanhf(v);
+                    else if (jm[k] == 2) v = sigmoid_f(v);
+                    if (jhas[k] && (lane & 15) == 0) tg_store(xr, p.u_lr1 + L.lbase[jm[k]] + jrow[k], __float_as_uint(v), 0u, 0u, 0u, tagL + S47_A);
+                }
+            }
+            T47(3);
+            // ---- C: y ----
+            if constexpr (V7) {
+                stage_qvec<DU, 64>(pl, xr, p.u_y, D, tagL + S47_Y, l.yq, opq(lane0));
+            } else {
+                const int lane = opq(lane0);
+                float ys[NU][GPB];
+                poll_x(pl, xr, p.u_y, tagL + S47_Y, lane, ys);
+                // lane l of slot s holds element l + 64 s: a half-wave is a 32-block (ggml quantize_row_q8_0 / q8_1)
+                float yv[NU * GPB]; int qi[NU * GPB], isum[NU * GPB]; float d16[NU * GPB], s16[NU * GPB];
+#pragma unroll
+                for (int j = 0; j < NU; j++)
+#pragma unroll
+                    for (int r = 0; r < GPB; r++) yv[GPB * j + r] = ys[j][r];
+                quant_blocks<NU * GPB>(yv, qi, d16, s16, isum);
+                const QVec lq = qvec_at(l.yq, D);
+#pragma unroll
+                for (int s = 0; s < NU * GPB; s++) qvec_store(lq, nb, 2 * s + (lane >> 5), lane & 31, qi[s], d16[s], s16[s], isum[s]);
+            }
+            T47(4);
+            __syncthreads();   // B3: yq
+            // ---- D: x after the time mixing ----
+            {
+                const int lane = opq(lane0);
+                float xs[NU][GPB];
+                poll_x(pl, xr, p.u_xatt, tagL + S47_XATT, lane, xs);
+                T47(5);
+                ln_stats(l, lane, xs);
+            }
+            T47(6);
+            __syncthreads();   // B4
+            __syncthreads();   // B5
+            // key groups of this workgroup: the workers' relu^2 outputs -> quantised 32-blocks (half-wave = group)
+            keys_done += 8u;
+            lf_wait(pl, l.fl, keys_done);
+            T47(7);
+            {
+                const int lane = opq(lane0);
+                const int gi = lane >> 5;
+                const bool valid = gi < GPB;
+                const float v = valid ? l.out[gi * 32 + (lane & 31)] : 0.0f;
+                int qi, isum; float d16, s16;
+                quant_block32(v, qi, d16, s16, isum);
+                tq_store_block(xr, p.u_kq, valid ? blk * GPB + gi : 0, lane & 31, qi, d16, s16, isum, tagL + S47_KQ, valid);
+            }
+            // ---- E: kq ----
+            stage_qvec<KQU, 64>(pl, xr, p.u_kq, F, tagL + S47_KQ, l.kq, opq(lane0));
+            T47(8);
+            __syncthreads();   // B6
+        }
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // row workgroup, worker waves
+    // -----------------------------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void row_worker(const P47 & p, const Lds & l, int tid0, int own, unsigned base) {
+        const int blk = blockIdx.x;
+        const M6Arena ar{p.arena};
+        const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
+        const int u = unit_of(blk, own), e0 = row0_of(u);
+        auto myrow_of = [&](int lane) { return e0 + 64 * (lane < GPB ? lane : 0); };   // lane r < GPB finishes row r
+        float xown[GPB];
+#pragma unroll
+        for (int r = 0; r < GPB; r++) xown[r] = p.x[e0 + 64 * r];
+        auto x_store = [&](int buf, unsigned tag) {
+            if ((threadIdx.x & 63) == 0) tg_store(xr, buf + u, __float_as_uint(xown[0]), __float_as_uint(xown[GPB - 1]), 0u, 0u, tag);
+        };
+        x_store(p.u_xffn, base - 8u + S47_XFFN);                             // the launch's input, as if a layer before the first had produced it
+
+        Pro<NIA> pa; Pro<NIF> pf;
+        ProSrc<NIA> sa; ProSrc<NIF> sf;
+        Batch<FMT, GPB, UD> wA[3], wC, wFr;
+        Batch<FMT, 4, UD> wK[GPB];
+        Batch<FMT, GPB, UF> wE;
+        float st4[5];                                                         // v4: aa, bb, pp, time_first, time_decay of this lane's channel
+
+        auto issue_A = [&](int li) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int tid = opq(tid0), lane = tid & 63, myrow = myrow_of(lane);
+            const P47Layer & L = p.layers[li];
+            const float * sin_l = p.sin + (long long) (li - p.l0) * p.state_stride;
+            sa = pro_src<NIA>(ar, L.ln1_w, L.ln1_b, L.mix_a, sin_l + D);
+            pro_load<NIA>(pa, sa, tid < NG4 ? tid : 0);
+            if constexpr (!V7) {
+                st4[0] = sin_l[2 * D + myrow]; st4[1] = sin_l[3 * D + myrow]; st4[2] = sin_l[4 * D + myrow];
+                st4[3] = ar.f(L.tf)[myrow]; st4[4] = ar.f(L.td)[myrow];
+            }
+            rows_issue<FMT, GPB, UD>(wA[0], ar.w(L.wr), e0, 64, nb, lane);
+            rows_issue<FMT, GPB, UD>(wA[1], ar.w(L.wk), e0, 64, nb, lane);
+            rows_issue<FMT, GPB, UD>(wA[2], ar.w(L.wv), e0, 64, nb, lane);
+        };
+        issue_A(p.l0);
+
+        for (int li = p.l0; li < p.l1; li++) {
+            const float * sin_l = p.sin + (long long) (li - p.l0) * p.state_stride;
+            float * sout_l = p.sout + (long long) (li - p.l0) * p.state_stride;
+            const unsigned tagL = base + (unsigned) (li - p.l0) * 8u;
+            const bool last = li + 1 == p.l1;
+            T47(0);
+            __syncthreads();   // B1
+            T47(1);
+            pro_run<NIA, 3, V7>(l, pa, sa, sout_l + D, blk == 0, opq(tid0));
+            T47(2);
+            __syncthreads();   // B2
+            // ---- A rows ----
+            {
+                const int lane = opq(tid0) & 63, myrow = myrow_of(lane);
+                float rr[GPB], kk[GPB], vv[GPB];
+                rows_sum<FMT, GPB, UD>(wA[0], nb, lane, qvec_at(l.q[0], D), rr);
+                rows_sum<FMT, GPB, UD>(wA[1], nb, lane, qvec_at(l.q[1], D), kk);
+                rows_sum<FMT, GPB, UD>(wA[2], nb, lane, qvec_at(l.q[2], D), vv);
+                const float rv = pick_lane<GPB>(rr, lane), kv = pick_lane<GPB>(kk, lane), vvv = pick_lane<GPB>(vv, lane);
+                if constexpr (V7) {
+                    if (lane < GPB) tg_store(xr, p.u_a + myrow, __float_as_uint(rv), __float_as_uint(kv), __float_as_uint(vvv), 0u, tagL + S47_A);
+                } else {
+                    // WKV-4 of this lane's channel (k_wkv4's statements, rwkv_graph.inc:119-161,178-195), then r * wkv
+                    const float aa = st4[0], bb = st4[1], pp = st4[2], uu = st4[3], w = st4[4];
+                    const float rs = sigmoid_f(rv);
+                    float ww = uu + kv;
+                    float qq = fmaxf(pp, ww);
+                    float e1 = det_expf(pp - qq), e2 = det_expf(ww - qq);
+                    const float a = e1 * aa + e2 * vvv;
+                    const float b = e1 * bb + e2;
+                    ww = pp + w;
+                    qq = fmaxf(ww, kv);
+                    e1 = det_expf(ww - qq); e2 = det_expf(kv - qq);
+                    if (lane < GPB) { sout_l[2 * D + myrow] = e1 * aa + e2 * vvv; sout_l[3 * D + myrow] = e1 * bb + e2; sout_l[4 * D + myrow] = qq; }
+                    const float y = rs * (a / b);
+                    const int y1 = __builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x101, 0xF, 0xF, true);   // lane 0 collects lane 1 (row_shl:1)
+                    if (lane == 0) tg_store(xr, p.u_y + u, __float_as_uint(y), (unsigned) y1, 0u, 0u, tagL + S47_Y);
+                }
+            }
+            T47(3);
+            // the channel-mixing prologue's parameters, then the output rows and the key (+ receptance) rows: they stream through the y hand-over
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                const int tid = opq(tid0), lane = tid & 63;
+                const P47Layer & L = p.layers[li];
+                sf = pro_src<NIF>(ar, L.ln2_w, L.ln2_b, L.mix_f, sin_l);
+                pro_load<NIF>(pf, sf, tid < NG4 ? tid : 0);
+                rows_issue<FMT, GPB, UD>(wC, ar.w(L.wo), e0, 64, nb, lane);
+#pragma unroll
+                for (int g = 0; g < GPB; g++) rows_issue<FMT, 4, UD>(wK[g], ar.w(L.fk), 32 * (blk * GPB + g) + 4 * own, 1, nb, lane);
+                if constexpr (!V7) rows_issue<FMT, GPB, UD>(wFr, ar.w(L.fr), e0, 64, nb, lane);
+            }
+            __syncthreads();   // B3: yq
+            T47(4);
+            {
+                const int lane = opq(tid0) & 63;
+                float res[GPB];
+                rows_sum<FMT, GPB, UD>(wC, nb, lane, qvec_at(l.yq, D), res);
+#pragma unroll
+                for (int r = 0; r < GPB; r++) xown[r] = xown[r] + res[r];
+                x_store(p.u_xatt, tagL + S47_XATT);
+            }
+            T47(5);
+            __syncthreads();   // B4
+            T47(6);
+            pro_run<NIF, NIF, false>(l, pf, sf, sout_l, blk == 0, opq(tid0));
+            __syncthreads();   // B5
+            T47(7);
+            float rgate[GPB];
+            {
+                const int lane = opq(tid0) & 63;
+#pragma unroll
+                for (int g = 0; g < GPB; g++) {
+                    float res[4];
+                    rows_sum<FMT, 4, UD>(wK[g], nb, lane, qvec_at(l.q[0], D), res);
+                    const float v = pick_lane<4>(res, lane);
+                    const float t = v > 0.0f ? v : 0.0f;
+                    if (lane < 4) l.out[32 * g + 4 * own + lane] = t * t;
+                }
+                lf_add(l.fl, 1u);
+                if constexpr (!V7) rows_sum<FMT, GPB, UD>(wFr, nb, lane, qvec_at(l.q[1], D), rgate);
+            }
+            T47(8);
+            __builtin_amdgcn_sched_barrier(0);
+            { const P47Layer & L = p.layers[li]; rows_issue<FMT, GPB, UF>(wE, ar.w(L.fv), e0, 64, nbF, opq(tid0) & 63); }
+            __syncthreads();   // B6: kq
+            T47(9);
+            {
+                const int lane = opq(tid0) & 63, myrow = myrow_of(lane);
+                float res[GPB];
+                rows_sum<FMT, GPB, UF>(wE, nbF, lane, qvec_at(l.kq, F), res);
+#pragma unroll
+                for (int r = 0; r < GPB; r++) {
+                    if constexpr (V7) xown[r] = xown[r] + res[r];
+                    else { const float gte = sigmoid_f(rgate[r]) * res[r]; xown[r] = xown[r] + gte; }
+                }
+                if (last) { const float xv = pick_lane<GPB>(xown, lane); if (lane < GPB) p.x[myrow] = xv; }
+                else x_store(p.u_xffn, tagL + S47_XFFN);
+            }
+            T47(10);
+            issue_A(last ? li : li + 1);
+        }
+    }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // head workgroup (RWKV-7): comm wave = the head's recurrence (lane = channel), workers = second low-rank stages
+    // -----------------------------------------------------------------------------------------------------------
+    struct HB { int4 r[HUB]; };   // 16 rows per pass: lane = 4 row + q, lane q keeps partials 8q .. 8q + 7; one 16-byte load per 32 columns
+    static __device__ __forceinline__ void hb_issue(HB & b, const unsigned char * W, long long row, int K, int lane) {
+        const int nsteps = K / 32;
+#pragma unroll
+        for (int s = 0; s < HUB; s++) {
+            const int sidx = s < nsteps ? s : nsteps - 1;
+            b.r[s] = ldw16(reinterpret_cast<const uint16_t *>(W) + row * K + 32 * sidx + 8 * (lane & 3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static __device__ __forceinline__ float hb_row(const HB & b, int K, const float * l_x, int lane) {
+        const int nsteps = K / 32, q = lane & 3;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < HUB; s++) {
+            if (s < nsteps) {
+                const unsigned uu[4] = {(unsigned) b.r[s].x, (unsigned) b.r[s].y, (unsigned) b.r[s].z, (unsigned) b.r[s].w};
+                float w[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { w[2 * i] = h2f_bits((uint16_t) (uu[i] & 0xFFFFu)); w[2 * i + 1] = h2f_bits((uint16_t) (uu[i] >> 16)); }
+                const float4 xa = *reinterpret_cast<const float4 *>(l_x + 32 * s + 8 * q);
+                const float4 xb = *reinterpret_cast<const float4 *>(l_x + 32 * s + 8 * q + 4);
+                acc[0] = fmaf(w[0], xa.x, acc[0]); acc[1] = fmaf(w[1], xa.y, acc[1]); acc[2] = fmaf(w[2], xa.z, acc[2]); acc[3] = fmaf(w[3], xa.w, acc[3]);
+                acc[4] = fmaf(w[4], xb.x, acc[4]); acc[5] = fmaf(w[5], xb.y, acc[5]); acc[6] = fmaf(w[6], xb.z, acc[6]); acc[7] = fmaf(w[7], xb.w, acc[7]);
+            }
+        }
+        float ps[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float v = acc[e];
+            v = v + __int_as_float(lane_xor2_i(__float_as_int(v)));   // ps[i] += ps[i + 16]
+            v = v + __int_as_float(lane_xor1_i(__float_as_int(v)));   // ps[i] += ps[i + 8]
+            ps[e] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) ps[e] += ps[e + 4];
+        return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    }
+
+    static __device__ __forceinline__ void head_comm(const P47 & p, const Lds & l, int lane0, unsigned base) {
+        const int hb = (int) blockIdx.x - NR;
+        Poll pl{p.ctl, false};
+        const M6Arena ar{p.arena};
+        const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
+        float vf = p.layers[p.l0].layer0 ? 0.0f : p.v_first[hb * S + lane0];
+        float s[S], cp[5];
+        // per-channel parameters a layer ahead; the state row (64 registers) only after the poll -- it lands under the workers' second stages
+        auto issue_cp = [&](int li) {
+            const int lane = opq(lane0), c = hb * S + lane;
+            const P47Layer & L = p.layers[li];
+            cp[0] = ar.f(L.k_k)[c]; cp[1] = ar.f(L.k_a)[c]; cp[2] = ar.f(L.r_k)[c]; cp[3] = ar.f(L.lnx_w)[c]; cp[4] = ar.f(L.lnx_b)[c];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto issue_state = [&](int li) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int lane = opq(lane0);
+            const float * st = p.sin + (long long) (li - p.l0) * p.state_stride + 2 * D + (long long) hb * S * S + (long long) lane * S;
+#pragma unroll
+            for (int j = 0; j < S; j += 4) { const float4 q4 = *reinterpret_cast<const float4 *>(st + j); s[j] = q4.x; s[j + 1] = q4.y; s[j + 2] = q4.z; s[j + 3] = q4.w; }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        issue_cp(p.l0);
+        for (int li = p.l0; li < p.l1; li++) {
+            const P47Layer & L = p.layers[li];
+            float * sout_l = p.sout + (long long) (li - p.l0) * p.state_stride;
+            const unsigned tagL = base + (unsigned) (li - p.l0) * 8u;
+            T47(0);
+            // r, k, v of this lane's channel (one unit) and the lr1 vector (fp16-rounded into LDS: what ggml feeds an F16 matrix)
+            float rv, kv0, vv;
+            {
+                const int lane = opq(lane0), c = hb * S + lane;
+                int ptr[NL1 + 1]; bool valid[NL1 + 1]; v4u dv[NL1 + 1];
+                ptr[0] = p.u_a + c; valid[0] = true;
+#pragma unroll
+                for (int k = 0; k < NL1; k++) { ptr[k + 1] = p.u_lr1 + lane + 64 * k; valid[k + 1] = lane + 64 * k < L.lr_n; }
+                poll_ptrs<NL1 + 1>(pl, xr, ptr, valid, tagL + S47_A, dv);
+                rv = __uint_as_float(dv[0].x); kv0 = __uint_as_float(dv[0].y); vv = __uint_as_float(dv[0].z);
+#pragma unroll
+                for (int k = 0; k < NL1; k++) l.lr1[lane + 64 * k] = round_f16(__uint_as_float(dv[k + 1].x));
+            }
+            T47(1);
+            issue_state(li);
+            __syncthreads();   // H1
+            __syncthreads();   // H2: the second stages' results are in l.ch
+            T47(2);
+            const int lane = opq(lane0), c = hb * S + lane;
+            const float c_kk = cp[0], c_ka = cp[1], c_rk = cp[2], c_lw = cp[3], c_lb = cp[4];
+            const float wv = l.ch[lane], av = l.ch[64 + lane], gv = l.ch[128 + lane];
+            // ---- key path, value residual (rwkv_graph.inc:432-453) ----
+            const float kkr = kv0 * c_kk;
+            const float ssum = wave_sum_f(kkr * kkr);
+            const float kscale = 1.0f / fmaxf(sqrtf(ssum), 1e-12f);
+            const float kk = kkr * kscale;
+            const float ka = kv0 * c_ka;
+            const float aka = av * ka;
+            const float kn = kv0 + (aka - ka);
+            if (L.layer0) { p.v_first[c] = vv; vf = vv; }
+            else { const float dv = (vf - vv) * l.ch[192 + lane]; vv = vv + dv; }
+            // {k, w, b, r}_j as one 16-byte broadcast read per step, l_a as sixteen; eight reads in flight at a time
+            float4 * bc = reinterpret_cast<float4 *>(l.hv);
+            float * l_a = l.hv + 256;
+            bc[lane] = make_float4(kn, wv, kk * av, rv);
+            l_a[lane] = -kk;
+            __builtin_amdgcn_wave_barrier();
+            // ---- WKV7 (rwkv_operators_wkv_v7.inc:37-107): lane i = value row i of state[h][i][:] ----
+            float sa = 0.0f;
+#pragma unroll
+            for (int j0 = 0; j0 < S; j0 += 32) {
+                float4 a4[8];
+                __builtin_amdgcn_sched_barrier(0);   // (pins the batch: left alone the scheduler hoists all 64 broadcast reads to the top -- 256 registers)
+#pragma unroll
+                for (int t = 0; t < 8; t++) a4[t] = reinterpret_cast<const float4 *>(l_a)[j0 / 4 + t];
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    sa += a4[t].x * s[j0 + 4 * t]; sa += a4[t].y * s[j0 + 4 * t + 1]; sa += a4[t].z * s[j0 + 4 * t + 2]; sa += a4[t].w * s[j0 + 4 * t + 3];
+                }
+            }
+            float res = 0.0f;
+#pragma unroll
+            for (int j0 = 0; j0 < S; j0 += 8) {
+                float4 b8[8];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 8; t++) b8[t] = bc[j0 + t];
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const int j = j0 + t;
+                    const float kvj = vv * b8[t].x;
+                    const float ns = (s[j] * b8[t].y + kvj) + sa * b8[t].z;
+                    s[j] = ns;
+                    res += ns * b8[t].w;
+                }
+            }
+            {
+                float * so = sout_l + 2 * D + (long long) hb * S * S + (long long) lane * S;
+#pragma unroll
+                for (int j = 0; j < S; j += 4) *reinterpret_cast<float4 *>(so + j) = make_float4(s[j], s[j + 1], s[j + 2], s[j + 3]);
+            }
+            // ---- GroupNorm over the head * ln_x, + v * sum_head(k r r_k), gate (rwkv_graph.inc:465-479) ----
+            const float mean = (float) (wave_sum_d((double) res) / (double) S);
+            const float dv2 = res - mean;
+            const float var = (float) (wave_sum_d((double) (dv2 * dv2)) / (double) S);
+            const float scale = 1.0f / sqrtf(var + 64e-5f);
+            const float bonus = wave_sum_f((kn * rv) * c_rk);
+            float y = dv2 * scale;
+            y = y * c_lw;
+            y = y + c_lb;
+            y += vv * bonus;
+            y *= gv;
+            int qi, isum; float d16, s16;
+            quant_block32(y, qi, d16, s16, isum);
+            tq_store_block(xr, p.u_y, 2 * hb + (lane >> 5), lane & 31, qi, d16, s16, isum, tagL + S47_Y);
+            T47(3);
+            issue_cp(li + 1 < p.l1 ? li + 1 : li);
+        }
+    }
+
+    static __device__ __forceinline__ void head_worker(const P47 & p, const Lds & l, int tid0, int wave) {
+        const int hb = (int) blockIdx.x - NR;
+        const M6Arena ar{p.arena};
+        const int mtx = wave & 3, half = wave >> 2;
+        HB ba, bb;
+        float e0[2];
+        auto issue = [&](int li) {
+            const int lane = opq(tid0) & 63;
+            const P47Layer & L = p.layers[li];
+            const bool has = mtx != 3 || L.has_v;
+            const int K = has ? L.rank[mtx] : 32;
+            const unsigned char * W = p.arena + (has ? L.lr2[mtx] : L.lr2[0]);
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) {
+                const long long row = has ? (long long) hb * S + (2 * half + ps) * 16 + (lane >> 2) : 0;
+                hb_issue(ps == 0 ? ba : bb, W, row, K, lane);
+                const long long ci = (long long) hb * S + (2 * half + ps) * 16 + (lane >> 2);
+                const long long off = mtx == 0 ? L.w0 : (mtx == 1 ? L.a0 : ((mtx == 3 && L.has_v) ? L.v0 : L.w0));
+                e0[ps] = ar.f(off)[ci];
+            }
+        };
+        issue(p.l0);
+        for (int li = p.l0; li < p.l1; li++) {
+            const P47Layer & L = p.layers[li];
+            __syncthreads();   // H1: lr1 staged
+            const int lane = opq(tid0) & 63;
+            const bool has = mtx != 3 || L.has_v;
+            if (has) {
+#pragma unroll
+                for (int ps = 0; ps < 2; ps++) {
+                    const int i = (2 * half + ps) * 16 + (lane >> 2);
+                    float v = hb_row(ps == 0 ? ba : bb, L.rank[mtx], l.lr1 + L.lbase[mtx], lane);
+                    if (mtx == 0) v = det_expf(sigmoid_f(v + e0[ps]) * -0.606531f);
+                    else if (mtx == 1) v = sigmoid_f(v + e0[ps]);
+                    else if (mtx == 3) v = sigmoid_f(v + e0[ps]);
+                    if ((lane & 3) == 0) l.ch[mtx * 64 + i] = v;
+                }
+            }
+            __syncthreads();   // H2
+            issue(li + 1 < p.l1 ? li + 1 : li);
+        }
+    }
+};
+
+template <int ARCH, int FMT, int D, int HUB, int NL1, int MAXJ>
+__global__ __launch_bounds__(576) void k47_persist(P47 p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef K47<ARCH, FMT, D, HUB, NL1, MAXJ> K;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const typename K::Lds l = K::carve(smem);
+    const unsigned base = p.ctl[0];
+    if (tid == 0) l.fl[0] = 0u;
+    __syncthreads();
+    if ((int) blockIdx.x < K::NR) {
+#ifndef P47_X_NO_ROW_COMM
+        if (wave == 8) K::row_comm(p, l, tid & 63, base);
+#endif
+#ifndef P47_X_NO_ROW_WORKER
+        if (wave != 8) K::row_worker(p, l, tid, wave, base);
+#endif
+    } else {
+        if constexpr (ARCH == 7) {
+#ifndef P47_X_NO_HEAD_COMM
+            if (wave == 8) K::head_comm(p, l, tid & 63, base);
+#endif
+#ifndef P47_X_NO_HEAD_WORKER
+            if (wave != 8) K::head_worker(p, l, tid, wave);
+#endif
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) p.ctl[0] = base + (unsigned) (p.l1 - p.l0) * 8u;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+
+struct P47Handle {
+    int kind = 3;                 // (mega_v6.hip dispatches on the first member: 1 register prefetch v6, 2 ring v6, 3 this file)
+    P47Layer * d_layers = nullptr;
+    void * xch = nullptr;
+    unsigned * ctl = nullptr;
+    unsigned * h_ctl = nullptr;
+    P47 proto{};
+    long long * trace = nullptr;
+    int variant = -1, n_blocks = 0, n_layers = 0;
+    size_t lds = 0;
+    std::vector<uint64_t> layer_bytes;   // algorithmic bytes per layer: every tensor once + the recurrent state read and written
+};
+
+typedef void (*P47Kernel)(P47);
+struct P47Variant { int arch, fmt, D, hub, nl1, maxj, nblk; P47Kernel fn; };
+
+#define P47_V4(FMT, DD) {4, FMT, DD, 1, 1, 1, K47<4, FMT, DD, 1, 1, 1>::NBLK, k47_persist<4, FMT, DD, 1, 1, 1>}
+#define P47_V7(FMT, DD, HUB, NL1, MAXJ) {7, FMT, DD, HUB, NL1, MAXJ, K47<7, FMT, DD, HUB, NL1, MAXJ>::NBLK, k47_persist<7, FMT, DD, HUB, NL1, MAXJ>}
+#ifndef P47_ONLY
+#define P47_ALL(FMT) \
+    P47_V4(FMT, 256), P47_V4(FMT, 768), \
+    P47_V7(FMT, 256, 4, 4, 2), P47_V7(FMT, 2560, 10, 9, 1)
+// (Q8_0 at D = 2560: eight 34-byte-block key rows per wave next to the output rows do not fit 168 registers -- that file keeps the fused launches)
+static const P47Variant g_p47[] = {P47_ALL(T_Q4_0), P47_ALL(T_Q4_1), P47_ALL(T_Q5_0), P47_ALL(T_Q5_1),
+                                   P47_V4(T_Q8_0, 256), P47_V4(T_Q8_0, 768), P47_V7(T_Q8_0, 256, 4, 4, 2)};
+#else    // (register-budget experiments: one instantiation)
+static const P47Variant g_p47[] = {P47_ONLY};
+#endif
+
+static int p47_variant(const Model & m, int n_cu) {
+    if ((m.arch_major != 4 && m.arch_major != 7) || m.layer_end <= m.layer_begin) return -1;
+    if (m.arch_major == 7 ? !fused_v7_supported(m) : !fused_v4_supported(m)) return -1;
+    const int64_t D = m.n_embed();
+    const int fmt = (int) m.header.data_type;
+    int lr_total = 0, max_rank = 0;
+    for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
+        const LayerW & L = m.layers[i];
+        if (L.ffn_key->ne[1] != 4 * D) return -1;
+        if (m.arch_major != 7) continue;
+        if (L.att_w1->type != T_F16) return -1;                       // (the low-rank stages of a file quantised from FP32 stay F32: fused path)
+        const DevTensor * l1[4] = {L.att_w1, L.att_a1, L.att_g1, L.att_v1};
+        int tot = 0;
+        for (int k = 0; k < 4; k++) {
+            const int rk = l1[k] ? (int) l1[k]->ne[1] : 0;
+            tot += rk;
+            if (rk > max_rank) max_rank = rk;
+        }
+        if (tot > lr_total) lr_total = tot;                           // (layer 0 has no v1: the widest layer sizes the buffers)
+    }
+    for (size_t v = 0; v < sizeof(g_p47) / sizeof(g_p47[0]); v++) {
+        const P47Variant & pv = g_p47[v];
+        if (pv.arch != m.arch_major || pv.fmt != fmt || pv.D != D || pv.nblk > n_cu) continue;
+        if (m.arch_major == 7) {
+            const int NR = (int) (D / 8) / ((D / 8 + D / 64 <= 256) ? 1 : 2);
+            if (max_rank > 32 * pv.hub || lr_total > 64 * pv.nl1 || lr_total > 2048 || lr_total / 4 > pv.maxj * NR) continue;
+        }
+        return (int) v;
+    }
+    return -1;
+}
+
+void p47_destroy(void * h) {
+    P47Handle * g = (P47Handle *) h;
+    if (!g) return;
+    if (g->d_layers) (void) hipFree(g->d_layers);
+    if (g->xch) (void) hipFree(g->xch);
+    if (g->ctl) (void) hipFree(g->ctl);
+    if (g->h_ctl) (void) hipHostFree(g->h_ctl);
+    if (g->trace) (void) hipFree(g->trace);
+    delete g;
+}
+
+// Returns nullptr when the model / device does not qualify (the caller keeps the fused per-layer launches).
+void * p47_create(const Model & m) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m.device) != hipSuccess) return nullptr;
+    const int v = p47_variant(m, prop.multiProcessorCount);
+    if (v < 0) return nullptr;
+    const P47Variant & pv = g_p47[v];
+    const int64_t D = m.n_embed(), F = 4 * D;
+    const bool v7 = m.arch_major == 7;
+    P47Handle * g = new P47Handle();
+    g->variant = v; g->n_blocks = pv.nblk;
+    g->lds = l47_lds((int) D, v7).total;
+    if (hipFuncSetAttribute((const void *) pv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) g->lds) != hipSuccess) { delete g; return nullptr; }
+    std::vector<P47Layer> hl;
+    const unsigned char * abase = (const unsigned char *) m.arena;
+    bool in_arena = true;
+    auto off = [&](const void * ptr) -> long long {
+        const long long o = (const unsigned char *) ptr - abase;
+        if (!ptr || o < 0 || (uint64_t) o >= m.arena_bytes) in_arena = false;
+        return o;
+    };
+    auto f = [&](const DevTensor * t) -> long long { return t ? off(t->data) : 0; };
+    auto pl3 = [&](const DevTensor * t) { M6Off o; o.qs = off(t->qs); o.qh = t->qh ? off(t->qh) : 0; o.sc = off(t->sc); return o; };
+    for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
+        const LayerW & L = m.layers[i];
+        P47Layer d{};
+        d.ln1_w = f(L.ln1_w); d.ln1_b = f(L.ln1_b); d.ln2_w = f(L.ln2_w); d.ln2_b = f(L.ln2_b);
+        d.wr = pl3(L.att_receptance); d.wk = pl3(L.att_key); d.wv = pl3(L.att_value); d.wo = pl3(L.att_output);
+        d.fk = pl3(L.ffn_key); d.fv = pl3(L.ffn_value);
+        uint64_t bytes = 0;
+        std::vector<const DevTensor *> all = {L.ln1_w, L.ln1_b, L.ln2_w, L.ln2_b, L.att_receptance, L.att_key, L.att_value, L.att_output, L.ffn_key, L.ffn_value};
+        if (!v7) {
+            d.mix_a[0] = f(L.att_time_mix_r); d.mix_a[1] = f(L.att_time_mix_k); d.mix_a[2] = f(L.att_time_mix_v);
+            d.mix_f[0] = f(L.ffn_time_mix_k); d.mix_f[1] = f(L.ffn_time_mix_r);
+            d.tf = f(L.att_time_first); d.td = f(L.att_time_decay);
+            d.fr = pl3(L.ffn_receptance);
+            for (const DevTensor * t : {L.att_time_mix_r, L.att_time_mix_k, L.att_time_mix_v, L.ffn_time_mix_k, L.ffn_time_mix_r, L.att_time_first, L.att_time_decay, L.ffn_receptance}) all.push_back(t);
+        } else {
+            const long long xm = f(L.att_x_rwkvag);   // rows r, w, k, v, a, g
+            const int order[6] = {0, 2, 3, 1, 4, 5};
+            for (int k = 0; k < 6; k++) d.mix_a[k] = xm + (long long) order[k] * D * 4;
+            d.mix_f[0] = f(L.ffn_x_k); d.mix_f[1] = d.mix_f[0];
+            d.fr = d.fk;
+            const DevTensor * l1[4] = {L.att_w1, L.att_a1, L.att_g1, L.att_v1}, * l2[4] = {L.att_w2, L.att_a2, L.att_g2, L.att_v2};
+            int basev = 0;
+            for (int k = 0; k < 4; k++) {
+                d.lr1[k] = l1[k] ? f(l1[k]) : f(l1[0]); d.lr2[k] = l2[k] ? f(l2[k]) : f(l2[0]);
+                d.rank[k] = l1[k] ? (int) l1[k]->ne[1] : 0; d.lbase[k] = basev; basev += d.rank[k];
+                if (d.rank[k] % 4 != 0) in_arena = false;
+                if (l1[k]) all.push_back(l1[k]);
+                if (l2[k]) all.push_back(l2[k]);
+            }
+            d.has_v = L.att_v1 ? 1 : 0; d.layer0 = i == 0 ? 1 : 0; d.lr_n = basev;
+            if (!d.has_v) d.lbase[3] = basev;
+            d.w0 = f(L.att_w0); d.a0 = f(L.att_a0); d.v0 = L.att_v0 ? f(L.att_v0) : d.w0;
+            d.k_k = f(L.att_k_k); d.k_a = f(L.att_k_a); d.r_k = f(L.att_r_k); d.lnx_w = f(L.att_ln_x_w); d.lnx_b = f(L.att_ln_x_b);
+            for (const DevTensor * t : {L.att_x_rwkvag, L.ffn_x_k, L.att_w0, L.att_a0, L.att_v0, L.att_k_k, L.att_k_a, L.att_r_k, L.att_ln_x_w, L.att_ln_x_b}) all.push_back(t);
+        }
+        for (const DevTensor * t : all) if (t) bytes += t->nbytes;
+        bytes += 2 * (uint64_t) m.state_per_layer() * sizeof(float);
+        g->layer_bytes.push_back(bytes);
+        hl.push_back(d);
+    }
+    if (!in_arena) { delete g; return nullptr; }
+    g->n_layers = (int) hl.size();
+    const int64_t nbD = D / 32, nbF = F / 32;
+    const int64_t PAD = 2048;   // polls read whole 64-lane rounds: keep every buffer readable past its end
+    auto up = [](int64_t x) { return (x + 63) / 64 * 64; };
+    const int64_t sizes[6] = {up(D) + PAD, 2048 + PAD, up(3 * nbD > D ? 3 * nbD : D) + PAD, up(D) + PAD, up(3 * nbF) + PAD, up(D) + PAD};
+    int64_t units = 0;
+    for (int64_t z : sizes) units += z;
+    bool ok = hipMalloc((void **) &g->d_layers, hl.size() * sizeof(P47Layer)) == hipSuccess
+           && hipMemcpy(g->d_layers, hl.data(), hl.size() * sizeof(P47Layer), hipMemcpyHostToDevice) == hipSuccess
+           && hipMalloc(&g->xch, (size_t) units * 16) == hipSuccess && hipMemset(g->xch, 0, (size_t) units * 16) == hipSuccess
+           && hipMalloc((void **) &g->ctl, 256) == hipSuccess
+           && hipHostMalloc((void **) &g->h_ctl, 64, hipHostMallocDefault) == hipSuccess;
+    if (ok) { g->h_ctl[0] = 16u; g->h_ctl[1] = 0u; }
+    const unsigned init[2] = {16u, 0u};
+    ok = ok && hipMemcpy(g->ctl, init, sizeof(init), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { p47_destroy(g); return nullptr; }
+    P47 & q = g->proto;
+    q.layers = g->d_layers; q.l0 = 0; q.l1 = g->n_layers;
+    q.arena = abase;
+    q.state_stride = m.state_per_layer();
+    q.xch = g->xch; q.xch_bytes = (unsigned) (units * 16);
+    int u = 0;
+    int * slots[6] = {&q.u_a, &q.u_lr1, &q.u_y, &q.u_xatt, &q.u_kq, &q.u_xffn};
+    for (int i = 0; i < 6; i++) { *slots[i] = u; u += (int) sizes[i]; }
+    q.ctl = g->ctl;
+    return g;
+}
+
+uint64_t p47_bytes(void * h) { uint64_t s = 0; for (uint64_t b : ((P47Handle *) h)->layer_bytes) s += b; return s; }
+
+// layers [l0, l1) of the stage (indices into the stage's own layer table); sin / sout: state of layer l0
+void p47_forward_range(void * h, float * x, float * v_first, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, int l0, int l1) {
+    P47Handle * g = (P47Handle *) h;
+    P47 q = g->proto;
+    q.x = x; q.v_first = v_first; q.sin = sin; q.sout = sout; q.l0 = l0; q.l1 = l1;
+    const P47Kernel fn = g_p47[g->variant].fn;
+    if (pf && pf->on) {
+        if (pf->used * 2 + 2 > pf->events.size()) {
+            hipEvent_t a = nullptr, c = nullptr;
+            (void) hipEventCreate(&a); (void) hipEventCreate(&c);
+            pf->events.push_back(a); pf->events.push_back(c); pf->bytes.push_back(0);
+        }
+        uint64_t bytes = 0;
+        for (int i = l0; i < l1; i++) bytes += g->layer_bytes[(size_t) i];
+        pf->bytes[pf->used] = bytes;
+        hipExtLaunchKernelGGL(fn, dim3((unsigned) g->n_blocks), dim3(576), (uint32_t) g->lds, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, q);
+        pf->used++;
+    } else {
+        hipLaunchKernelGGL(fn, dim3((unsigned) g->n_blocks), dim3(576), g->lds, st, q);
+    }
+}
+int p47_layers(void * h) { return ((P47Handle *) h)->n_layers; }
+
+bool p47_ctl_fetch(void * h, hipStream_t st) {
+    P47Handle * g = (P47Handle *) h;
+    return hipMemcpyAsync(g->h_ctl, g->ctl, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess;
+}
+bool p47_aborted_cached(void * h) { return ((P47Handle *) h)->h_ctl[1] != 0; }
+unsigned p47_generation_cached(void * h) { return ((P47Handle *) h)->h_ctl[0]; }
+bool p47_clear_abort(void * h, hipStream_t st) {
+    P47Handle * g = (P47Handle *) h;
+    g->h_ctl[1] = 0u;
+    return hipMemsetAsync(g->ctl + 1, 0, sizeof(unsigned), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+}
+bool p47_set_tag(void * h, unsigned base, hipStream_t st) {
+    P47Handle * g = (P47Handle *) h;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    return hipMemcpy(g->ctl, &base, sizeof(unsigned), hipMemcpyHostToDevice) == hipSuccess;
+}
+// real-time-counter stamps of one layer (16 per wave, 9 waves per workgroup) for the next launches; out holds n_blocks * 9 * 16 values
+bool p47_trace(void * h, int layer, long long * out, bool fetch) {
+    P47Handle * g = (P47Handle *) h;
+    const size_t n = (size_t) 256 * 9 * 16;
+    if (!g->trace) { if (hipMalloc((void **) &g->trace, n * 8) != hipSuccess) return false; (void) hipMemset(g->trace, 0, n * 8); }
+    g->proto.trace = g->trace; g->proto.trace_layer = layer;
+    if (fetch) return hipMemcpy(out, g->trace, n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    return true;
+}
+
+}  // namespace rwkvmi

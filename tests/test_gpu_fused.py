@@ -32,7 +32,11 @@ def test_fused_layer_matches_oracle_and_generic_path(tmp_path, name, fmt, direct
     library()
     p = _file(tmp_path, name, fmt, direct)
     om = O.OracleModel(p)
-    m = model(p)
+    os.environ["RWKV_MI_NO_MEGA"] = "1"     # (the persistent launch of persist_v47.hip takes these models by default: tests/test_gpu_persist_v47.py)
+    try:
+        m = model(p)
+    finally:
+        del os.environ["RWKV_MI_NO_MEGA"]
     assert m.decode_path() == 1, "fused path not selected"
     os.environ["RWKV_MI_NO_FUSED"] = "1"
     try:

@@ -19,13 +19,19 @@ pytestmark = pytest.mark.gpu
 TOKENS = [1, 2, 3, 400, 5, 77, 300, 9, 11, 12]
 
 
-def _check(tmp_path, name, fmt, seed, want_path, env_off):
+def _check(tmp_path, name, fmt, seed, want_path, env_off, env_on=None):
     library()
     p = str(tmp_path / "m.bin")
     spec = synth.CONFIGS[name]
     synth.write_model(p, spec, fmt, seed=seed)
     om = O.OracleModel(p)
-    m = model(p)
+    if env_on:
+        os.environ[env_on] = "1"
+    try:
+        m = model(p)
+    finally:
+        if env_on:
+            del os.environ[env_on]
     assert m.decode_path() == want_path, (name, m.decode_path())
     os.environ[env_off] = "1"
     try:
@@ -63,12 +69,23 @@ def _check(tmp_path, name, fmt, seed, want_path, env_off):
 
 @pytest.mark.parametrize("fmt", ["Q5_1", "Q4_0"])
 def test_rwkv7_2b9_slice(tmp_path, fmt):
-    _check(tmp_path, "slice-v7-2560", fmt, 61, 1, "RWKV_MI_NO_FUSED")
+    """fused launches (fused_v7.hip) + one kernel per op"""
+    _check(tmp_path, "slice-v7-2560", fmt, 61, 1, "RWKV_MI_NO_FUSED", "RWKV_MI_NO_MEGA")
 
 
 @pytest.mark.parametrize("fmt", ["Q5_1"])
 def test_rwkv4_169m_slice(tmp_path, fmt):
-    _check(tmp_path, "slice-v4-768", fmt, 67, 1, "RWKV_MI_NO_FUSED")
+    _check(tmp_path, "slice-v4-768", fmt, 67, 1, "RWKV_MI_NO_FUSED", "RWKV_MI_NO_MEGA")
+
+
+@pytest.mark.parametrize("name,fmt", [("slice-v7-2560", "Q5_1"), ("slice-v7-2560", "Q4_0"), ("slice-v4-768", "Q5_1")])
+def test_real_geometry_on_the_persistent_launch(tmp_path, name, fmt):
+    """the default path of these geometries: one persistent launch per token (persist_v47.hip) + the fused launches beside it"""
+    os.environ["RWKV_MI_NO_AUTOTUNE"] = "1"
+    try:
+        _check(tmp_path, name, fmt, 79, 2, "RWKV_MI_NO_MEGA")
+    finally:
+        del os.environ["RWKV_MI_NO_AUTOTUNE"]
 
 
 @pytest.mark.parametrize("kind", ["ring", "regs"])

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-5 GPU sessions, one parameterised script (replaces the per-session gpu_r4_s*.sh files): tools/gpu_r5.sh <step> [args]
+#   p47        the persistent RWKV-4 / RWKV-7 launch: its tests, then the C2 / C4 decode lines with parity
+#   p47bench   only the two decode lines (+ kernel stats)
+#   suite      the whole -m gpu suite (evidence: gpurun_out/r05/pytest.txt), refuses to continue when it did not finish
+set -u
+cd "$(dirname "$0")/.."
+STEP=${1:-p47}; shift || true
+O=gpurun_out/r05_$STEP; mkdir -p $O
+export TMPDIR=/tmp RWKV_BENCH_DIR=/tmp RWKV_BENCH_NO_COLD=1
+line() { python -c "
+import json,sys
+for l in sys.stdin.read().strip().splitlines()[-1:]:
+    d=json.loads(l); r=d.get('roofline',{}); print('$1', round(d['value'],1), d['unit'], round(d['ms_per_step'],4), 'ms', 'frac', r.get('frac'), 'parity', d.get('parity'), 'abi', d.get('abi'), 'path', d.get('config',{}).get('decode_path'), flush=True)
+"; }
+bench_one() {   # name config dtype extra...
+  local n=$1 c=$2 t=$3; shift 3
+  timeout 300 python bench.py --config $c --dtype $t --steps 256 --warmup 16 --cpu-seconds 0 "$@" > $O/bench_$n.json 2> $O/bench_$n.err; tail -1 $O/bench_$n.json | line $n
+}
+case $STEP in
+p47)
+  ( timeout 900 python -m pytest tests/test_gpu_persist_v47.py -m gpu -q -x -p no:cacheprovider "$@" 2>&1 | tail -25 ) > $O/pytest_p47.txt; cat $O/pytest_p47.txt
+  bench_one v4 rwkv4-169m Q5_1
+  bench_one v7 rwkv7-2b9 Q5_1
+  ;;
+p47bench)
+  bench_one v4 rwkv4-169m Q5_1 "$@"
+  bench_one v7 rwkv7-2b9 Q5_1 "$@"
+  ;;
+suite)
+  ( timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15 ) > $O/pytest.txt; cat $O/pytest.txt
+  grep -q " passed" $O/pytest.txt || { echo "SUITE DID NOT FINISH: no evidence recorded"; exit 1; }
+  ;;
+esac
