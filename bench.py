@@ -28,7 +28,8 @@ MFMA_F16_PEAK_TOPS = 2500.0
 
 
 KERNEL_SOURCES = {2: ["rwkv.cpp_amd/csrc/ring_v6.hip", "rwkv.cpp_amd/csrc/ring_geom.h", "rwkv.cpp_amd/csrc/persist.h", "rwkv.cpp_amd/csrc/fused_blocks.h", "rwkv.cpp_amd/csrc/kdev.h"],
-                  1: ["rwkv.cpp_amd/csrc/mega_v6.hip", "rwkv.cpp_amd/csrc/persist.h", "rwkv.cpp_amd/csrc/fused_blocks.h", "rwkv.cpp_amd/csrc/kdev.h"]}
+                  1: ["rwkv.cpp_amd/csrc/mega_v6.hip", "rwkv.cpp_amd/csrc/persist.h", "rwkv.cpp_amd/csrc/fused_blocks.h", "rwkv.cpp_amd/csrc/kdev.h"],
+                  3: ["rwkv.cpp_amd/csrc/persist_v47.hip", "rwkv.cpp_amd/csrc/persist.h", "rwkv.cpp_amd/csrc/fused_blocks.h", "rwkv.cpp_amd/csrc/kdev.h"]}
 
 
 def kernel_source_stamp(kind):
@@ -240,6 +241,7 @@ def load_leg(pkg, lib, path, spec):
 
 KERNEL_NAMES = {2: "k6_ring (persistent decode kernel: all layers of the stage in one launch, weights streamed through an LDS ring by LDS-DMA)",
                 3: "k6_mega (persistent decode kernel: all layers of the stage in one launch, weights prefetched into registers)",
+                4: "k47_persist (persistent RWKV-4 / RWKV-7 decode kernel: all layers of the stage in one launch, weights prefetched into registers a phase ahead)",
                 1: "fused single-token layer kernels (quantised row phases)",
                 0: "k_mvq_t1 (quantised single-token projection)"}
 
@@ -280,7 +282,7 @@ def bench_decode(args, pkg, lib, path, spec, torch):
         if p["launches"] > 0:
             ach = p["bytes"] / max(p["kernel_ms"], 1e-9) / 1e6
             traffic, traffic_src = pmc_traffic(path_id, args, model.persist_kind())
-            kname = KERNEL_NAMES[3 if (path_id == 2 and model.persist_kind() == 1) else path_id]
+            kname = KERNEL_NAMES[(3 if model.persist_kind() == 1 else 4 if model.persist_kind() == 3 else 2) if path_id == 2 else path_id]
             result["roofline"] = {"bound": "hbm", "kernel": kname + f" [{args.dtype}]", "achieved": ach,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                   "launches": p["launches"], "avg_launch_us": p["kernel_ms"] * 1e3 / p["launches"],
