@@ -313,11 +313,35 @@ struct K47 {
     static __device__ __forceinline__ float job_row(const Job & jb, const float * l_x, int lane) {
         const int q = lane & 15;
         float a0 = 0.0f, a1 = 0.0f;
+        // The activation reads go out sixteen steps at a time, the next batch under the current one's FMAs, pinned by scheduling barriers:
+        // left alone the compiler pairs every read with a wait in front of its FMA -- 40 LDS round trips in a row (5.3 us per job at D = 2560).
+        constexpr int BS = 16, NBAT = (STEPS + BS - 1) / BS;
+        float2 xa[BS], xb[BS];
+        auto rd = [&](float2 (&dst)[BS], int bi) {
 #pragma unroll
-        for (int s = 0; s < STEPS; s++) {
-            const float2 xv = *reinterpret_cast<const float2 *>(l_x + 32 * s + 2 * q);
-            a0 = fmaf(h2f_bits((uint16_t) (jb.w[s] & 0xFFFFu)), xv.x, a0);
-            a1 = fmaf(h2f_bits((uint16_t) (jb.w[s] >> 16)), xv.y, a1);
+            for (int t = 0; t < BS; t++) { const int s = bi * BS + t; if (s < STEPS) dst[t] = *reinterpret_cast<const float2 *>(l_x + 32 * s + 2 * q); }
+        };
+        auto fm = [&](const float2 (&src)[BS], int bi) {
+#pragma unroll
+            for (int t = 0; t < BS; t++) {
+                const int s = bi * BS + t;
+                if (s < STEPS) {
+                    a0 = fmaf(h2f_bits((uint16_t) (jb.w[s] & 0xFFFFu)), src[t].x, a0);
+                    a1 = fmaf(h2f_bits((uint16_t) (jb.w[s] >> 16)), src[t].y, a1);
+                }
+            }
+        };
+        rd(xa, 0);
+#pragma unroll
+        for (int bi = 0; bi < NBAT; bi += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (bi + 1 < NBAT) rd(xb, bi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            fm(xa, bi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (bi + 2 < NBAT) rd(xa, bi + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (bi + 1 < NBAT) fm(xb, bi + 1);
         }
         // ggml's fold: ps[i] += ps[i + 16], ps[i] += ps[i + 8], ps[i] += ps[i + 4], (ps0 + ps1) + (ps2 + ps3)
         a0 = a0 + __int_as_float(lane_xor8_i(__float_as_int(a0))); a1 = a1 + __int_as_float(lane_xor8_i(__float_as_int(a1)));
@@ -388,16 +412,26 @@ struct K47 {
                 const int lane = opq(lane0);
                 float ys[NU][GPB];
                 poll_x(pl, xr, p.u_y, tagL + S47_Y, lane, ys);
-                // lane l of slot s holds element l + 64 s: a half-wave is a 32-block (ggml quantize_row_q8_0 / q8_1)
-                float yv[NU * GPB]; int qi[NU * GPB], isum[NU * GPB]; float d16[NU * GPB], s16[NU * GPB];
+                // Polled layout: lane l of slot s holds element l + 64 s. Quantising in that layout (one 32-block per half-wave and slot) costs
+                // two f32 divisions + a rounding per element on this one wave (2.3 us of the y hand-over at D = 768); through LDS (l.x is free
+                // between the time-mixing prologue and the next statistics) the vector comes back four consecutive elements per lane, eight
+                // lanes per block: the prologues' quantiser, a quarter of the instructions. Max and integer sum are order-free: same codes.
 #pragma unroll
                 for (int j = 0; j < NU; j++)
 #pragma unroll
-                    for (int r = 0; r < GPB; r++) yv[GPB * j + r] = ys[j][r];
-                quant_blocks<NU * GPB>(yv, qi, d16, s16, isum);
+                    for (int r = 0; r < GPB; r++) l.x[lane + 64 * (GPB * j + r)] = ys[j][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
                 const QVec lq = qvec_at(l.yq, D);
 #pragma unroll
-                for (int s = 0; s < NU * GPB; s++) qvec_store(lq, nb, 2 * s + (lane >> 5), lane & 31, qi[s], d16[s], s16[s], isum[s]);
+                for (int pz = 0; pz < D / 256; pz++) {
+                    const int i = 4 * (lane + 64 * pz);
+                    const float4 y4 = *reinterpret_cast<const float4 *>(l.x + i);
+                    const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+                    unsigned packed; float d16, s16; int isum;
+                    quant_vec4(yv, packed, d16, s16, isum);
+                    qvec_store4(lq, nb, i, packed, d16, s16, isum);
+                }
             }
             T47(4);
             __syncthreads();   // B3: yq
@@ -425,6 +459,7 @@ struct K47 {
                 quant_block32(v, qi, d16, s16, isum);
                 tq_store_block(xr, p.u_kq, valid ? blk * GPB + gi : 0, lane & 31, qi, d16, s16, isum, tagL + S47_KQ, valid);
             }
+            T47(9);
             // ---- E: kq ----
             stage_qvec<KQU, 64>(pl, xr, p.u_kq, F, tagL + S47_KQ, l.kq, opq(lane0));
             T47(8);
@@ -491,25 +526,35 @@ struct K47 {
                 rows_sum<FMT, GPB, UD>(wA[0], nb, lane, qvec_at(l.q[0], D), rr);
                 rows_sum<FMT, GPB, UD>(wA[1], nb, lane, qvec_at(l.q[1], D), kk);
                 rows_sum<FMT, GPB, UD>(wA[2], nb, lane, qvec_at(l.q[2], D), vv);
-                const float rv = pick_lane<GPB>(rr, lane), kv = pick_lane<GPB>(kk, lane), vvv = pick_lane<GPB>(vv, lane);
                 if constexpr (V7) {
+                    const float rv = pick_lane<GPB>(rr, lane), kv = pick_lane<GPB>(kk, lane), vvv = pick_lane<GPB>(vv, lane);
                     if (lane < GPB) tg_store(xr, p.u_a + myrow, __float_as_uint(rv), __float_as_uint(kv), __float_as_uint(vvv), 0u, tagL + S47_A);
                 } else {
-                    // WKV-4 of this lane's channel (k_wkv4's statements, rwkv_graph.inc:119-161,178-195), then r * wkv
-                    const float aa = st4[0], bb = st4[1], pp = st4[2], uu = st4[3], w = st4[4];
-                    const float rs = sigmoid_f(rv);
-                    float ww = uu + kv;
-                    float qq = fmaxf(pp, ww);
-                    float e1 = det_expf(pp - qq), e2 = det_expf(ww - qq);
-                    const float a = e1 * aa + e2 * vvv;
-                    const float b = e1 * bb + e2;
-                    ww = pp + w;
-                    qq = fmaxf(ww, kv);
-                    e1 = det_expf(ww - qq); e2 = det_expf(kv - qq);
-                    if (lane < GPB) { sout_l[2 * D + myrow] = e1 * aa + e2 * vvv; sout_l[3 * D + myrow] = e1 * bb + e2; sout_l[4 * D + myrow] = qq; }
-                    const float y = rs * (a / b);
-                    const int y1 = __builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x101, 0xF, 0xF, true);   // lane 0 collects lane 1 (row_shl:1)
-                    if (lane == 0) tg_store(xr, p.u_y + u, __float_as_uint(y), (unsigned) y1, 0u, 0u, tagL + S47_Y);
+                    // WKV-4 of this wave's channel(s) (k_wkv4's statements, rwkv_graph.inc:119-161,178-195), then r * wkv. Every operand is
+                    // wave-uniform, so the five exponentials of a channel (two per softmax pair + the sigmoid's) run as ONE call with a
+                    // different argument per lane and come back through readlane: five double-precision polynomials in a row were a quarter
+                    // of this phase.
+                    float yout[GPB];
+#pragma unroll
+                    for (int r = 0; r < GPB; r++) {
+                        auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), r)); };
+                        const float aa = bc(st4[0]), bb = bc(st4[1]), pp = bc(st4[2]), uu = bc(st4[3]), w = bc(st4[4]);
+                        const float kv = kk[r], vvv = vv[r], rv = rr[r];
+                        const float ww1 = uu + kv;
+                        const float qq1 = fmaxf(pp, ww1);
+                        const float ww2 = pp + w;
+                        const float qq2 = fmaxf(ww2, kv);
+                        const float arg = lane == 0 ? pp - qq1 : (lane == 1 ? ww1 - qq1 : (lane == 2 ? ww2 - qq2 : (lane == 3 ? kv - qq2 : -rv)));
+                        const float ex = det_expf(arg);
+                        auto rl = [&](int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), i)); };
+                        const float e1 = rl(0), e2 = rl(1), f1 = rl(2), f2 = rl(3), er = rl(4);
+                        const float rs = 1.0f / (1.0f + er);
+                        const float a = e1 * aa + e2 * vvv;
+                        const float b = e1 * bb + e2;
+                        if (lane == 0) { sout_l[2 * D + e0 + 64 * r] = f1 * aa + f2 * vvv; sout_l[3 * D + e0 + 64 * r] = f1 * bb + f2; sout_l[4 * D + e0 + 64 * r] = qq2; }
+                        yout[r] = rs * (a / b);
+                    }
+                    if (lane == 0) tg_store(xr, p.u_y + u, __float_as_uint(yout[0]), __float_as_uint(yout[GPB - 1]), 0u, 0u, tagL + S47_Y);
                 }
             }
             T47(3);
@@ -595,18 +640,48 @@ struct K47 {
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[e] = 0.0f;
+        // activation reads in pinned batches of three steps (six 16-byte reads), the next batch under the current one's FMAs
+        constexpr int BS = 3, NBAT = (HUB + BS - 1) / BS;
+        float4 xa[BS][2], xb[BS][2];
+        auto rd = [&](float4 (&dst)[BS][2], int bi) {
 #pragma unroll
-        for (int s = 0; s < HUB; s++) {
-            if (s < nsteps) {
-                const unsigned uu[4] = {(unsigned) b.r[s].x, (unsigned) b.r[s].y, (unsigned) b.r[s].z, (unsigned) b.r[s].w};
-                float w[8];
-#pragma unroll
-                for (int i = 0; i < 4; i++) { w[2 * i] = h2f_bits((uint16_t) (uu[i] & 0xFFFFu)); w[2 * i + 1] = h2f_bits((uint16_t) (uu[i] >> 16)); }
-                const float4 xa = *reinterpret_cast<const float4 *>(l_x + 32 * s + 8 * q);
-                const float4 xb = *reinterpret_cast<const float4 *>(l_x + 32 * s + 8 * q + 4);
-                acc[0] = fmaf(w[0], xa.x, acc[0]); acc[1] = fmaf(w[1], xa.y, acc[1]); acc[2] = fmaf(w[2], xa.z, acc[2]); acc[3] = fmaf(w[3], xa.w, acc[3]);
-                acc[4] = fmaf(w[4], xb.x, acc[4]); acc[5] = fmaf(w[5], xb.y, acc[5]); acc[6] = fmaf(w[6], xb.z, acc[6]); acc[7] = fmaf(w[7], xb.w, acc[7]);
+            for (int t = 0; t < BS; t++) {
+                const int s = bi * BS + t;
+                if (s < HUB) {
+                    const int sc = s < nsteps ? s : 0;
+                    dst[t][0] = *reinterpret_cast<const float4 *>(l_x + 32 * sc + 8 * q);
+                    dst[t][1] = *reinterpret_cast<const float4 *>(l_x + 32 * sc + 8 * q + 4);
+                }
             }
+        };
+        auto fm = [&](const float4 (&src)[BS][2], int bi) {
+#pragma unroll
+            for (int t = 0; t < BS; t++) {
+                const int s = bi * BS + t;
+                if (s < HUB) {
+                    if (s < nsteps) {
+                        const unsigned uu[4] = {(unsigned) b.r[s].x, (unsigned) b.r[s].y, (unsigned) b.r[s].z, (unsigned) b.r[s].w};
+                        float w[8];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { w[2 * i] = h2f_bits((uint16_t) (uu[i] & 0xFFFFu)); w[2 * i + 1] = h2f_bits((uint16_t) (uu[i] >> 16)); }
+                        const float4 xa4 = src[t][0], xb4 = src[t][1];
+                        acc[0] = fmaf(w[0], xa4.x, acc[0]); acc[1] = fmaf(w[1], xa4.y, acc[1]); acc[2] = fmaf(w[2], xa4.z, acc[2]); acc[3] = fmaf(w[3], xa4.w, acc[3]);
+                        acc[4] = fmaf(w[4], xb4.x, acc[4]); acc[5] = fmaf(w[5], xb4.y, acc[5]); acc[6] = fmaf(w[6], xb4.z, acc[6]); acc[7] = fmaf(w[7], xb4.w, acc[7]);
+                    }
+                }
+            }
+        };
+        rd(xa, 0);
+#pragma unroll
+        for (int bi = 0; bi < NBAT; bi += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (bi + 1 < NBAT) rd(xb, bi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            fm(xa, bi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (bi + 2 < NBAT) rd(xa, bi + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (bi + 1 < NBAT) fm(xb, bi + 1);
         }
         float ps[8];
 #pragma unroll
@@ -619,6 +694,37 @@ struct K47 {
 #pragma unroll
         for (int e = 0; e < 4; e++) ps[e] += ps[e + 4];
         return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    }
+
+    // 2 NB columns of the WKV-7 update: ba holds {k, w, b, r} of columns J0 .. J0 + NB - 1 (read by the caller / the previous pair), bb is
+    // read here for the next NB under the first NB columns' arithmetic, ba is refilled for the next pair under the second NB
+    static constexpr int NBW = 4;
+    template <int J0>
+    static __device__ __forceinline__ void wkv_pair(float (&s)[S], const float4 * bc, float4 (&ba)[NBW], float4 (&bb)[NBW], float vv, float sa, float & res) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NBW; t++) bb[t] = bc[J0 + NBW + t];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NBW; t++) {
+            const float kvj = vv * ba[t].x;
+            const float ns = (s[J0 + t] * ba[t].y + kvj) + sa * ba[t].z;
+            s[J0 + t] = ns;
+            res += ns * ba[t].w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (J0 + 2 * NBW < S) {
+#pragma unroll
+            for (int t = 0; t < NBW; t++) ba[t] = bc[J0 + 2 * NBW + t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NBW; t++) {
+            const float kvj = vv * bb[t].x;
+            const float ns = (s[J0 + NBW + t] * bb[t].y + kvj) + sa * bb[t].z;
+            s[J0 + NBW + t] = ns;
+            res += ns * bb[t].w;
+        }
     }
 
     static __device__ __forceinline__ void head_comm(const P47 & p, const Lds & l, int lane0, unsigned base) {
@@ -687,33 +793,29 @@ struct K47 {
             l_a[lane] = -kk;
             __builtin_amdgcn_wave_barrier();
             // ---- WKV7 (rwkv_operators_wkv_v7.inc:37-107): lane i = value row i of state[h][i][:] ----
+            // broadcast reads double-buffered and pinned: a batch is in flight under the arithmetic of the one before it
             float sa = 0.0f;
+            {
+                const float4 * la4 = reinterpret_cast<const float4 *>(l_a);
+                float4 a0[8], a1[8];
 #pragma unroll
-            for (int j0 = 0; j0 < S; j0 += 32) {
-                float4 a4[8];
-                __builtin_amdgcn_sched_barrier(0);   // (pins the batch: left alone the scheduler hoists all 64 broadcast reads to the top -- 256 registers)
-#pragma unroll
-                for (int t = 0; t < 8; t++) a4[t] = reinterpret_cast<const float4 *>(l_a)[j0 / 4 + t];
-#pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    sa += a4[t].x * s[j0 + 4 * t]; sa += a4[t].y * s[j0 + 4 * t + 1]; sa += a4[t].z * s[j0 + 4 * t + 2]; sa += a4[t].w * s[j0 + 4 * t + 3];
-                }
-            }
-            float res = 0.0f;
-#pragma unroll
-            for (int j0 = 0; j0 < S; j0 += 8) {
-                float4 b8[8];
+                for (int t = 0; t < 8; t++) a0[t] = la4[t];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 8; t++) b8[t] = bc[j0 + t];
+                for (int t = 0; t < 8; t++) a1[t] = la4[8 + t];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    const int j = j0 + t;
-                    const float kvj = vv * b8[t].x;
-                    const float ns = (s[j] * b8[t].y + kvj) + sa * b8[t].z;
-                    s[j] = ns;
-                    res += ns * b8[t].w;
-                }
+                for (int t = 0; t < 8; t++) { sa += a0[t].x * s[4 * t]; sa += a0[t].y * s[4 * t + 1]; sa += a0[t].z * s[4 * t + 2]; sa += a0[t].w * s[4 * t + 3]; }
+#pragma unroll
+                for (int t = 0; t < 8; t++) { sa += a1[t].x * s[32 + 4 * t]; sa += a1[t].y * s[33 + 4 * t]; sa += a1[t].z * s[34 + 4 * t]; sa += a1[t].w * s[35 + 4 * t]; }
+            }
+            float res = 0.0f;
+            {
+                float4 ba[NBW], bb[NBW];
+#pragma unroll
+                for (int t = 0; t < NBW; t++) ba[t] = bc[t];
+                wkv_pair<0>(s, bc, ba, bb, vv, sa, res); wkv_pair<8>(s, bc, ba, bb, vv, sa, res); wkv_pair<16>(s, bc, ba, bb, vv, sa, res); wkv_pair<24>(s, bc, ba, bb, vv, sa, res);
+                wkv_pair<32>(s, bc, ba, bb, vv, sa, res); wkv_pair<40>(s, bc, ba, bb, vv, sa, res); wkv_pair<48>(s, bc, ba, bb, vv, sa, res); wkv_pair<56>(s, bc, ba, bb, vv, sa, res);
             }
             {
                 float * so = sout_l + 2 * D + (long long) hb * S * S + (long long) lane * S;

@@ -18,6 +18,9 @@ bench_one() {   # name config dtype extra...
   timeout 300 python bench.py --config $c --dtype $t --steps 256 --warmup 16 --cpu-seconds 0 "$@" > $O/bench_$n.json 2> $O/bench_$n.err; tail -1 $O/bench_$n.json | line $n
 }
 case $STEP in
+p47all)
+  bash $0 p47 "$@"; bash $0 p47trace
+  ;;
 p47)
   ( timeout 900 python -m pytest tests/test_gpu_persist_v47.py -m gpu -q -x -p no:cacheprovider "$@" 2>&1 | tail -25 ) > $O/pytest_p47.txt; cat $O/pytest_p47.txt
   bench_one v4 rwkv4-169m Q5_1
@@ -26,6 +29,15 @@ p47)
 p47bench)
   bench_one v4 rwkv4-169m Q5_1 "$@"
   bench_one v7 rwkv7-2b9 Q5_1 "$@"
+  ;;
+p47trace)
+  timeout 200 python tools/trace_p47.py rwkv4-169m Q5_1 5 > $O/trace_v4.txt 2>&1; cat $O/trace_v4.txt | tail -40
+  timeout 300 python tools/trace_p47.py rwkv7-2b9 Q5_1 9 > $O/trace_v7.txt 2>&1; cat $O/trace_v7.txt | tail -45
+  R=$PWD
+  for c in "v4 rwkv4-169m" "v7 rwkv7-2b9"; do n=${c% *}; cfg=${c#* }
+    ( cd /tmp && rm -rf /tmp/prof_$n && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -o p -- python $R/bench.py --config $cfg --dtype Q5_1 --steps 64 --warmup 8 --cpu-seconds 0 --abi-tokens 0 --no-profile > /tmp/prof_$n.log 2>&1 ) || tail -3 /tmp/prof_$n.log
+    f=$(find /tmp/prof_$n -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f $O/decode_${n}_kernel_stats.csv; head -8 $f | cut -c1-160; fi
+  done
   ;;
 suite)
   ( timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15 ) > $O/pytest.txt; cat $O/pytest.txt

@@ -1,0 +1,65 @@
+"""Phase trace of the persistent RWKV-4 / RWKV-7 decode launch (csrc/persist_v47.hip): stamps of the 100 MHz real-time counter (consistent
+across XCDs) per wave in one layer, printed as microseconds since the earliest stamp of the layer.
+usage: python tools/trace_p47.py <config> <dtype> [layer]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'tests'))
+import torch  # noqa: E402
+torch.cuda.init()
+from gpu_lib import library, model, synth  # noqa: E402
+
+lib = library()
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'rwkv4-169m'
+dt = sys.argv[2] if len(sys.argv) > 2 else 'Q5_1'
+layer = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+p = '/tmp/synthetic-%s-%s-seed42.bin' % (cfg, dt)
+spec = synth.CONFIGS[cfg]
+if not os.path.exists(p):
+    synth.write_model(p, spec, dt, seed=42)
+os.environ['RWKV_MI_NO_AUTOTUNE'] = '1'
+m = model(p)
+assert m.persist_kind() == 3, m.persist_kind()
+m.state_load(None)
+m.decode_greedy(5, 8)
+L = lib.library
+L.rwkv_mi_trace_phases.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+L.rwkv_mi_trace_phases.restype = ctypes.c_bool
+out = np.zeros(256 * 8 * 32, dtype=np.int64)
+assert L.rwkv_mi_trace_phases(m._ctx.ptr, 5, layer, 3, out.ctypes.data)
+t = out[:256 * 9 * 16].reshape(256, 9, 16).astype(float) / 100.0      # microseconds
+D = spec.n_embed
+v7 = spec.arch == '7'
+GK = D // 8
+GPB = 1 if GK + (D // 64 if v7 else 0) <= 256 else 2
+NR = GK // GPB
+H = D // 64 if v7 else 0
+rows = t[:NR]
+t0 = rows[:, :8, 0].min()
+print(f'{cfg} {dt} layer {layer}: NR {NR} row workgroups, {H} head workgroups, GPB {GPB}; microseconds since the first worker entered the layer')
+
+
+def show(name, a):
+    print('  %-46s mean %7.2f   min %7.2f   max %7.2f' % (name, a.mean() - t0, a.min() - t0, a.max() - t0))
+
+
+print('row workgroups, WORKER waves (stamp = reached)')
+wn = ['0 layer top', '1 B1 passed (x - mean, scale in LDS)', '2 prologue A done', '3 B2 passed + A rows + epilogue stored', '4 B3 passed (yq staged)', '5 output rows, x_att stored',
+      '6 B4 passed (stats of x_att)', '7 prologue F done + B5', '8 key (+ receptance) rows done', '9 B6 passed (kq staged)', '10 value rows, x stored']
+for k, n in enumerate(wn):
+    show(n, rows[:, :8, k])
+print('row workgroups, COMM wave')
+cn = ['0 layer top', '1 x gathered', '2 stats done (+ lr1 jobs issued)', '3 B1 B2 passed (+ lr1 rows stored)', '4 y gathered / quantised', '5 B3 passed + x_att gathered', '6 stats done',
+      '7 B4 B5 passed + key flag seen', '8 kq stored + gathered']
+for k, n in enumerate(cn):
+    show(n, rows[:, 8, k])
+if H:
+    hd = t[NR:NR + H]
+    print('head workgroups, COMM wave')
+    for k, n in enumerate(['0 layer top', '1 r k v lr1 gathered', '2 H1 H2 passed (second stages done)', '3 WKV-7 .. yq stored']):
+        show(n, hd[:, 8, k])
+print('layer wall (first worker in -> last worker out): %.2f us' % (rows[:, :8, 10].max() - t0))
+m.free()
