@@ -108,7 +108,7 @@ __device__ __forceinline__ void rows_sum(const Batch<FMT, R, U> & bt, int nbk, i
     for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
 }
 
-struct L47 { size_t x, sc, q, lr, yq, kq, out, fl, lr1, ch, hv, total; };
+struct L47 { size_t x, sc, q, lr, yq, kq, out, fl, lr1, ch, hv, st, total; };
 __host__ __device__ inline L47 l47_lds(int D, bool v7) {
     L47 o; size_t p = 0;
     auto take = [&](size_t n) { const size_t r = p; p += m6_round16(n); return r; };
@@ -119,7 +119,7 @@ __host__ __device__ inline L47 l47_lds(int D, bool v7) {
     // head workgroups (RWKV-7) use their own carving of the same allocation
     size_t h = 0;
     auto takeh = [&](size_t n) { const size_t r = h; h += m6_round16(n); return r; };
-    o.lr1 = takeh(2048 * 4); o.ch = takeh(4 * 64 * 4); o.hv = takeh(5 * 64 * 4);
+    o.lr1 = takeh(2048 * 4); o.ch = takeh(4 * 64 * 4); o.hv = takeh(5 * 64 * 4); o.st = takeh(64 * 68 * 4);
     o.total = p > h ? p : h;
     return o;
 }
@@ -146,7 +146,7 @@ struct K47 {
 
     struct Lds {
         float * x; float * sc; unsigned char * q[3]; float * lr[4]; unsigned char * yq; unsigned char * kq; float * out; unsigned * fl;
-        float * lr1; float * ch; float * hv;
+        float * lr1; float * ch; float * hv; float * st;
     };
     static __device__ __forceinline__ Lds carve(unsigned char * smem) {
         const L47 lo = l47_lds(D, V7);
@@ -155,7 +155,7 @@ struct K47 {
         for (int i = 0; i < 3; i++) l.q[i] = smem + lo.q + i * m6_round16(qvec_bytes(D));
         for (int i = 0; i < 4; i++) l.lr[i] = reinterpret_cast<float *>(smem + lo.lr) + (V7 ? i * D : 0);
         l.yq = smem + lo.yq; l.kq = smem + lo.kq; l.out = reinterpret_cast<float *>(smem + lo.out); l.fl = reinterpret_cast<unsigned *>(smem + lo.fl);
-        l.lr1 = reinterpret_cast<float *>(smem + lo.lr1); l.ch = reinterpret_cast<float *>(smem + lo.ch); l.hv = reinterpret_cast<float *>(smem + lo.hv);
+        l.lr1 = reinterpret_cast<float *>(smem + lo.lr1); l.ch = reinterpret_cast<float *>(smem + lo.ch); l.hv = reinterpret_cast<float *>(smem + lo.hv); l.st = reinterpret_cast<float *>(smem + lo.st);
         return l;
     }
 
@@ -396,6 +396,7 @@ struct K47 {
             __syncthreads();   // B2: the workers' images
             if constexpr (V7) {
                 const int lane = opq(lane0);
+                __builtin_amdgcn_s_setprio(3);   // (two worker waves of this SIMD run their row phase beside it: the heads wait for THIS wave)
 #pragma unroll
                 for (int k = 0; k < MAXJ; k++) {
                     float v = job_row(jb[k], l.lr[0] + jm[k] * D, lane);   // (one base + offset: an indexed pointer array would live in scratch as generic pointers)
@@ -403,6 +404,7 @@ struct K47 {
                     else if (jm[k] == 2) v = sigmoid_f(v);
                     if (jhas[k] && (lane & 15) == 0) tg_store(xr, p.u_lr1 + L.lbase[jm[k]] + jrow[k], __float_as_uint(v), 0u, 0u, 0u, tagL + S47_A);
                 }
+                __builtin_amdgcn_s_setprio(0);
             }
             T47(3);
             // ---- C: y ----
@@ -741,12 +743,23 @@ struct K47 {
             cp[0] = ar.f(L.k_k)[c]; cp[1] = ar.f(L.k_a)[c]; cp[2] = ar.f(L.r_k)[c]; cp[3] = ar.f(L.lnx_w)[c]; cp[4] = ar.f(L.lnx_b)[c];
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto issue_state = [&](int li) {
+        // The head's state (64 x 64 floats, contiguous) goes HBM -> LDS at the layer top, long before r / k / v arrive: sixteen coalesced
+        // 1 KiB loads (a row per lane straight into registers is 64 lanes x 16 B on 64 different lines per instruction -- measured: the
+        // recurrence waited ~4 us for it), parked in a tile with a 68-float row pitch (16-byte reads of a row per lane are conflict-free),
+        // so the registers are free for the poll. After H2 lane i reads row i back.
+        auto stage_state = [&](int li) {
             __builtin_amdgcn_sched_barrier(0);
             const int lane = opq(lane0);
-            const float * st = p.sin + (long long) (li - p.l0) * p.state_stride + 2 * D + (long long) hb * S * S + (long long) lane * S;
+            const float * st = p.sin + (long long) (li - p.l0) * p.state_stride + 2 * D + (long long) hb * S * S;
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f ta[8], tb[8];   // (two arrays of eight native vectors: one array of sixteen float4 structs was left in scratch)
 #pragma unroll
-            for (int j = 0; j < S; j += 4) { const float4 q4 = *reinterpret_cast<const float4 *>(st + j); s[j] = q4.x; s[j + 1] = q4.y; s[j + 2] = q4.z; s[j + 3] = q4.w; }
+            for (int k = 0; k < 8; k++) { ta[k] = *reinterpret_cast<const v4f *>(st + 256 * k + 4 * lane); tb[k] = *reinterpret_cast<const v4f *>(st + 256 * (8 + k) + 4 * lane); }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                *reinterpret_cast<v4f *>(l.st + (4 * k + (lane >> 4)) * 68 + 4 * (lane & 15)) = ta[k];
+                *reinterpret_cast<v4f *>(l.st + (4 * (8 + k) + (lane >> 4)) * 68 + 4 * (lane & 15)) = tb[k];
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         issue_cp(p.l0);
@@ -755,6 +768,7 @@ struct K47 {
             float * sout_l = p.sout + (long long) (li - p.l0) * p.state_stride;
             const unsigned tagL = base + (unsigned) (li - p.l0) * 8u;
             T47(0);
+            stage_state(li);
             // r, k, v of this lane's channel (one unit) and the lr1 vector (fp16-rounded into LDS: what ggml feeds an F16 matrix)
             float rv, kv0, vv;
             {
@@ -769,11 +783,12 @@ struct K47 {
                 for (int k = 0; k < NL1; k++) l.lr1[lane + 64 * k] = round_f16(__uint_as_float(dv[k + 1].x));
             }
             T47(1);
-            issue_state(li);
             __syncthreads();   // H1
             __syncthreads();   // H2: the second stages' results are in l.ch
             T47(2);
             const int lane = opq(lane0), c = hb * S + lane;
+#pragma unroll
+            for (int j = 0; j < S; j += 4) { const float4 q4 = *reinterpret_cast<const float4 *>(l.st + lane * 68 + j); s[j] = q4.x; s[j + 1] = q4.y; s[j + 2] = q4.z; s[j + 3] = q4.w; }
             const float c_kk = cp[0], c_ka = cp[1], c_rk = cp[2], c_lw = cp[3], c_lb = cp[4];
             const float wv = l.ch[lane], av = l.ch[64 + lane], gv = l.ch[128 + lane];
             // ---- key path, value residual (rwkv_graph.inc:432-453) ----
@@ -817,11 +832,6 @@ struct K47 {
                 wkv_pair<0>(s, bc, ba, bb, vv, sa, res); wkv_pair<8>(s, bc, ba, bb, vv, sa, res); wkv_pair<16>(s, bc, ba, bb, vv, sa, res); wkv_pair<24>(s, bc, ba, bb, vv, sa, res);
                 wkv_pair<32>(s, bc, ba, bb, vv, sa, res); wkv_pair<40>(s, bc, ba, bb, vv, sa, res); wkv_pair<48>(s, bc, ba, bb, vv, sa, res); wkv_pair<56>(s, bc, ba, bb, vv, sa, res);
             }
-            {
-                float * so = sout_l + 2 * D + (long long) hb * S * S + (long long) lane * S;
-#pragma unroll
-                for (int j = 0; j < S; j += 4) *reinterpret_cast<float4 *>(so + j) = make_float4(s[j], s[j + 1], s[j + 2], s[j + 3]);
-            }
             // ---- GroupNorm over the head * ln_x, + v * sum_head(k r r_k), gate (rwkv_graph.inc:465-479) ----
             const float mean = (float) (wave_sum_d((double) res) / (double) S);
             const float dv2 = res - mean;
@@ -837,6 +847,17 @@ struct K47 {
             quant_block32(y, qi, d16, s16, isum);
             tq_store_block(xr, p.u_y, 2 * hb + (lane >> 5), lane & 31, qi, d16, s16, isum, tagL + S47_Y);
             T47(3);
+            {   // the new state, behind the hand-over: back through the tile, sixteen coalesced 1 KiB stores
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < S; j += 4) *reinterpret_cast<float4 *>(l.st + lane * 68 + j) = make_float4(s[j], s[j + 1], s[j + 2], s[j + 3]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                float * so = sout_l + 2 * D + (long long) hb * S * S;
+#pragma unroll
+                for (int k = 0; k < 16; k++) *reinterpret_cast<float4 *>(so + 256 * k + 4 * lane) = *reinterpret_cast<const float4 *>(l.st + (4 * k + (lane >> 4)) * 68 + 4 * (lane & 15));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the tile is rewritten at the next layer's top)
+            }
             issue_cp(li + 1 < p.l1 ? li + 1 : li);
         }
     }

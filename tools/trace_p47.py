@@ -53,8 +53,8 @@ for k, n in enumerate(wn):
     show(n, rows[:, :8, k])
 print('row workgroups, COMM wave')
 cn = ['0 layer top', '1 x gathered', '2 stats done (+ lr1 jobs issued)', '3 B1 B2 passed (+ lr1 rows stored)', '4 y gathered / quantised', '5 B3 passed + x_att gathered', '6 stats done',
-      '7 B4 B5 passed + key flag seen', '8 kq stored + gathered']
-for k, n in enumerate(cn):
+      '7 B4 B5 passed + key flag seen', '8 kq gathered (all groups staged)', '9 own key groups quantised + stored']
+for k, n in ((0, cn[0]), (1, cn[1]), (2, cn[2]), (3, cn[3]), (4, cn[4]), (5, cn[5]), (6, cn[6]), (7, cn[7]), (9, cn[9]), (8, cn[8])):
     show(n, rows[:, 8, k])
 if H:
     hd = t[NR:NR + H]
