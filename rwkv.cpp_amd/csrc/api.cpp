@@ -290,16 +290,24 @@ RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_to
     HIP_CTX_OK(ctx, hipMalloc((void **) &hist.p, n_tokens * sizeof(uint32_t)));
     uint32_t * d_hist = hist.p;
     HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
+    // persist_v47.hip: the launch itself picks the token, leaves it where its own embedding lookup reads it and appends it to the history
+    const bool in_launch = folded_argmax_target(ctx) == ctx->d_tokens && mega_v6_set_history(ctx->mega, d_hist, ctx->stream);
     HIP_CTX_OK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     bool ok = true;
     for (size_t i = 0; i < n_tokens && ok; i++) {
         ok = forward_decode(ctx, true);
         if (!ok) break;
+        if (in_launch) continue;
         // next token = argmax(logits), written where the embedding kernel reads it; no host round trip
-        launch_argmax(ctx->d_logits, (int64_t) n_vocab, ctx->d_tokens, ctx->stream);
+        if (folded_argmax_target(ctx) != ctx->d_tokens) launch_argmax(ctx->d_logits, (int64_t) n_vocab, ctx->d_tokens, ctx->stream);
         if (hipMemcpyAsync(d_hist + i, ctx->d_tokens, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) ok = false;
     }
-    if (ok) {
+    if (in_launch && ctx->mega) {
+        const bool drained = hipEventRecord(ctx->ev1, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+        ok = mega_v6_set_history(ctx->mega, nullptr, ctx->stream) && drained && ok;
+        if (ok && elapsed_ms) ok = hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1) == hipSuccess;
+        if (ok && tokens_out) ok = hipMemcpyAsync(tokens_out, d_hist, n_tokens * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    } else if (ok) {
         ok = hipEventRecord(ctx->ev1, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
         if (ok && elapsed_ms) ok = hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1) == hipSuccess;
         if (ok && tokens_out) ok = hipMemcpyAsync(tokens_out, d_hist, n_tokens * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
@@ -378,7 +386,7 @@ RWKV_API bool rwkv_mi_profile_decode(struct rwkv_context * ctx, uint32_t first_t
         const bool ok = forward(ctx, 1, true);
         pf.on = false;
         if (!ok) return false;
-        launch_argmax(ctx->d_logits, (int64_t) n_vocab, ctx->d_tokens, ctx->stream);
+        if (folded_argmax_target(ctx) != ctx->d_tokens) launch_argmax(ctx->d_logits, (int64_t) n_vocab, ctx->d_tokens, ctx->stream);
         HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
         for (size_t k = 0; k < pf.used; k++) {
             float ms = 0.0f;

@@ -576,6 +576,7 @@ struct Runner {
     }
 
     void run_embed() {
+        if (T == 1 && ctx->mega && m.has_embed && mega_v6_folds_embed(ctx->mega)) return;   // inside the persistent launch
         if (m.has_embed) launch_embed_ln0(*m.emb, ctx->d_tokens, T, D, f(m.ln0_w), f(m.ln0_b), b.x, st);
     }
     // layers [lb, le) of the stage (absolute layer ids); returns true when the launch also produced the logits (ring kernel, last layers)
@@ -588,12 +589,15 @@ struct Runner {
             const bool head_done = want_logits && m.has_head && le == m.layer_end && mega_v6_folds_head(ctx->mega);
             const float * s0 = sin + (int64_t) m.layer_begin * per_layer;
             float * o0 = sout + (int64_t) m.layer_begin * per_layer;
-            if (whole) mega_v6_forward(ctx->mega, b.x, s0, o0, st, &ctx->prof, head_done ? ctx->d_logits : nullptr, b.v_first);
+            // (persist_v47.hip: the launch starts from the token id and ends with the argmax where the stage has embedding / head)
+            const uint32_t * tok = (lb == m.layer_begin && m.has_embed && mega_v6_folds_embed(ctx->mega)) ? ctx->d_tokens : nullptr;
+            uint32_t * ntok = tok ? ctx->d_tokens : ctx->d_next_token;    // the greedy loops read the next token where the embedding reads it
+            if (whole) mega_v6_forward(ctx->mega, b.x, s0, o0, st, &ctx->prof, head_done ? ctx->d_logits : nullptr, b.v_first, tok, ntok);
             else {
                 // (a range's state pointers are those of ITS first layer for persist_v47.hip, of the stage's first layer for the ring kernel)
                 const bool own_base = mega_v6_kind(ctx->mega) == 3;
                 const int64_t so = own_base ? (int64_t) (lb - m.layer_begin) * per_layer : 0;
-                mega_v6_forward_range(ctx->mega, b.x, s0 + so, o0 + so, st, nullptr, head_done ? ctx->d_logits : nullptr, (int) (lb - m.layer_begin), (int) (le - m.layer_begin), b.v_first);
+                mega_v6_forward_range(ctx->mega, b.x, s0 + so, o0 + so, st, nullptr, head_done ? ctx->d_logits : nullptr, (int) (lb - m.layer_begin), (int) (le - m.layer_begin), b.v_first, tok, ntok);
             }
             return head_done;
         }
@@ -630,6 +634,13 @@ struct Runner {
 };
 
 }  // namespace
+
+// Where a single-token step that produces logits has ALSO left their argmax (persist_v47.hip folds it into the launch), or nullptr: the
+// greedy loops then need no argmax launch -- and no copy when that is where their next step reads the token.
+uint32_t * folded_argmax_target(const rwkv_context * ctx) {
+    if (!ctx->mega || !ctx->model->has_head || !mega_v6_folds_argmax(ctx->mega)) return nullptr;
+    return (ctx->model->has_embed && mega_v6_folds_embed(ctx->mega)) ? ctx->d_tokens : ctx->d_next_token;
+}
 
 int64_t handoff_len(const Model & m) { return m.arch_major == 7 ? 2 * m.n_embed() : m.n_embed(); }
 

@@ -937,17 +937,22 @@ int mega_v6_kind(void * h) { return h ? *(const int *) h : 0; }
 uint64_t mega_v6_bytes(void * h) { if (is_ring(h)) return ring_v6_bytes(h); if (is_p47(h)) return p47_bytes(h); return ((MegaV6 *) h)->bytes; }
 
 // sin / sout: state of the stage's FIRST layer. One launch covers every layer of the stage.
-bool mega_v6_folds_head(void * h) { return is_ring(h) && ring_v6_folds_head(h); }
+bool mega_v6_folds_head(void * h) { return (is_ring(h) && ring_v6_folds_head(h)) || (is_p47(h) && p47_folds_head(h)); }
 
 bool mega_v6_has_range(void * h) { return is_ring(h) || is_p47(h); }
-void mega_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1, float * v_first) {
-    if (is_p47(h)) { p47_forward_range(h, x, v_first, sin, sout, st, pf, l0, l1); return; }
+bool mega_v6_folds_embed(void * h) { return is_p47(h) && p47_folds_embed(h); }
+bool mega_v6_folds_argmax(void * h) { return is_p47(h) && p47_folds_head(h); }
+bool mega_v6_set_history(void * h, uint32_t * hist, hipStream_t st) { return is_p47(h) && p47_set_history(h, hist, st); }
+void mega_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1, float * v_first,
+                           const uint32_t * tok, uint32_t * next_tok) {
+    if (is_p47(h)) { p47_forward_range(h, x, v_first, sin, sout, st, pf, l0, l1, logits, tok, next_tok); return; }
     ring_v6_forward_range(h, x, sin, sout, st, pf, logits, l0, l1);
 }
 
-void mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, float * v_first) {
+void mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, float * v_first,
+                     const uint32_t * tok, uint32_t * next_tok) {
     if (is_ring(h)) { ring_v6_forward(h, x, sin, sout, st, pf, logits); return; }
-    if (is_p47(h)) { p47_forward_range(h, x, v_first, sin, sout, st, pf, 0, p47_layers(h)); return; }
+    if (is_p47(h)) { p47_forward_range(h, x, v_first, sin, sout, st, pf, 0, p47_layers(h), logits, tok, next_tok); return; }
     MegaV6 * mg = (MegaV6 *) h;
     M6P q = mg->proto;
     q.x = x; q.sin = sin; q.sout = sout;

@@ -217,10 +217,15 @@ void *   mega_v6_create(const Model & m);   // nullptr: not applicable. RWKV_MI_
 void *   mega_v6_create_kind(const Model & m, int kind);   // 1: register prefetch, 2: LDS-DMA weight ring
 void     mega_v6_destroy(void * h);
 // logits != nullptr and mega_v6_folds_head(h): ln_out + the head projection run inside the launch (the caller skips its own)
-void     mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits = nullptr, float * v_first = nullptr);
+void     mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits = nullptr, float * v_first = nullptr,
+                         const uint32_t * tok = nullptr, uint32_t * next_tok = nullptr);
 // a layer range [l0, l1) of the stage (ring_v6.hip and persist_v47.hip have one; indices into the stage's own layers)
-void     mega_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1, float * v_first = nullptr);
+void     mega_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1, float * v_first = nullptr,
+                               const uint32_t * tok = nullptr, uint32_t * next_tok = nullptr);
 bool     mega_v6_has_range(void * h);
+bool     mega_v6_folds_embed(void * h);      // the launch starts from the token id: the caller skips its embedding + ln0 launch
+bool     mega_v6_folds_argmax(void * h);     // a launch that produces logits also writes their argmax to next_tok
+bool     mega_v6_set_history(void * h, uint32_t * hist, hipStream_t st);   // (folds_argmax) tokens appended on the device, no copy per token
 bool     mega_v6_folds_head(void * h);
 bool     mega_v6_ctl_fetch(void * h, hipStream_t st);       // async copy of the control words into the pinned mirror
 bool     mega_v6_aborted_cached(void * h);                  // the mirror's abort word (valid after the stream was synchronised)
@@ -234,7 +239,11 @@ int      mega_v6_kind(void * h);            // 1: register prefetch (mega_v6.hip
 // persistent single-launch RWKV-4 / RWKV-7 decode (persist_v47.hip); reached through the mega_v6_* entry points
 void *   p47_create(const Model & m);
 void     p47_destroy(void * h);
-void     p47_forward_range(void * h, float * x, float * v_first, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, int l0, int l1);
+void     p47_forward_range(void * h, float * x, float * v_first, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, int l0, int l1,
+                           float * logits = nullptr, const uint32_t * tok = nullptr, uint32_t * next_tok = nullptr);
+bool     p47_folds_embed(void * h);
+bool     p47_folds_head(void * h);
+bool     p47_set_history(void * h, uint32_t * hist, hipStream_t st);
 int      p47_layers(void * h);
 bool     p47_ctl_fetch(void * h, hipStream_t st);
 bool     p47_aborted_cached(void * h);
@@ -276,6 +285,7 @@ void abi_streamer_free(void * p);
 bool forward_decode(rwkv_context * ctx, bool want_logits);
 // grows the per-context activation scratch to hold T tokens
 bool ensure_scratch(rwkv_context * ctx, int64_t T);
+uint32_t * folded_argmax_target(const rwkv_context * ctx);
 // hand-off buffer size in floats: D, or 2 D for RWKV-7 (x and v_first travel together)
 int64_t handoff_len(const Model & m);
 

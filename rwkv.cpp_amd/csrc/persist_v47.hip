@@ -54,9 +54,13 @@ struct P47 {
     int u_a, u_lr1, u_y, u_xatt, u_kq, u_xffn;      // unit (16-byte) offsets of the tagged buffers in the exchange arena
     unsigned * ctl;                                  // [0] tag generation, [1] abort
     long long * trace; int trace_layer;
+    // embedding + ln0 inside the launch (first stage, rwkv_graph.inc:655-658): tok != nullptr -> x is LN0(emb[*tok]) instead of the plain input
+    const uint32_t * tok; const void * emb; int emb_f16; long long ln0_w, ln0_b;
+    // ln_out + head + argmax inside the launch (last stage, rwkv_graph.inc:704-708): logits != nullptr; every workgroup of the grid takes rows
+    float * logits; uint32_t * next_tok; const void * head; long long lnout_w, lnout_b; int V; int u_am; int n_spare;
 };
 
-enum { S47_A = 0, S47_Y = 1, S47_XATT = 2, S47_KQ = 3, S47_XFFN = 4 };
+enum { S47_A = 0, S47_Y = 1, S47_XATT = 2, S47_KQ = 3, S47_XFFN = 4, S47_AM = 5 };
 
 __device__ __forceinline__ unsigned lf_ld(const unsigned * f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lf_add(unsigned * f, unsigned v) {
@@ -108,7 +112,7 @@ __device__ __forceinline__ void rows_sum(const Batch<FMT, R, U> & bt, int nbk, i
     for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
 }
 
-struct L47 { size_t x, sc, q, lr, yq, kq, out, fl, lr1, ch, hv, st, total; };
+struct L47 { size_t x, sc, q, lr, yq, kq, out, fl, hx, am, lr1, ch, hv, st, total; };
 __host__ __device__ inline L47 l47_lds(int D, bool v7) {
     L47 o; size_t p = 0;
     auto take = [&](size_t n) { const size_t r = p; p += m6_round16(n); return r; };
@@ -116,6 +120,7 @@ __host__ __device__ inline L47 l47_lds(int D, bool v7) {
     o.q = take(3 * m6_round16(qvec_bytes(D)));
     o.lr = take(v7 ? (size_t) 4 * D * 4 : 16);
     o.yq = take(qvec_bytes(D)); o.kq = take(qvec_bytes(4 * (size_t) D)); o.out = take(64 * 4); o.fl = take(64);
+    o.hx = take((size_t) D * 4); o.am = take(2 * 16 * 4);
     // head workgroups (RWKV-7) use their own carving of the same allocation
     size_t h = 0;
     auto takeh = [&](size_t n) { const size_t r = h; h += m6_round16(n); return r; };
@@ -146,7 +151,7 @@ struct K47 {
 
     struct Lds {
         float * x; float * sc; unsigned char * q[3]; float * lr[4]; unsigned char * yq; unsigned char * kq; float * out; unsigned * fl;
-        float * lr1; float * ch; float * hv; float * st;
+        float * lr1; float * ch; float * hv; float * st; float * hx; int * am;
     };
     static __device__ __forceinline__ Lds carve(unsigned char * smem) {
         const L47 lo = l47_lds(D, V7);
@@ -156,6 +161,7 @@ struct K47 {
         for (int i = 0; i < 4; i++) l.lr[i] = reinterpret_cast<float *>(smem + lo.lr) + (V7 ? i * D : 0);
         l.yq = smem + lo.yq; l.kq = smem + lo.kq; l.out = reinterpret_cast<float *>(smem + lo.out); l.fl = reinterpret_cast<unsigned *>(smem + lo.fl);
         l.lr1 = reinterpret_cast<float *>(smem + lo.lr1); l.ch = reinterpret_cast<float *>(smem + lo.ch); l.hv = reinterpret_cast<float *>(smem + lo.hv); l.st = reinterpret_cast<float *>(smem + lo.st);
+        l.hx = reinterpret_cast<float *>(smem + lo.hx); l.am = reinterpret_cast<int *>(smem + lo.am);
         return l;
     }
 
@@ -190,7 +196,7 @@ struct K47 {
     // LayerNorm statistics of the vector in xs (lane l holds the elements l + 64 s, s = GPB j + r): thread t < 256 of the specified
     // reduction owns the partial over t, t + 256, ... -- lane l runs the four partials l, l + 64, l + 128, l + 192 itself, then the tree.
     // Leaves x - mean in l.x and the scale in l.sc[0].
-    static __device__ __forceinline__ void ln_stats(const Lds & l, int lane, float (&xs)[NU][GPB]) {
+    static __device__ __forceinline__ void ln_meanvar(float (&xs)[NU][GPB], float & mean_out, float & scale_out) {   // xs <- xs - mean
         double pp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < NU; j++) {
@@ -206,13 +212,51 @@ struct K47 {
 #pragma unroll
             for (int r = 0; r < GPB; r++) {
                 const float d = xs[j][r] - mean;
-                l.x[lane + 64 * (GPB * j + r)] = d;
+                xs[j][r] = d;
                 qq[(GPB * j + r) & 3] += (double) (d * d);
             }
         }
         const float var = (float) (wave_sum_d((qq[0] + qq[2]) + (qq[1] + qq[3])) / (double) D);
-        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        mean_out = mean;
+        scale_out = 1.0f / sqrtf(var + 1e-5f);
+    }
+    static __device__ __forceinline__ void ln_stats(const Lds & l, int lane, float (&xs)[NU][GPB]) {
+        float mean, scale;
+        ln_meanvar(xs, mean, scale);
+#pragma unroll
+        for (int j = 0; j < NU; j++)
+#pragma unroll
+            for (int r = 0; r < GPB; r++) l.x[lane + 64 * (GPB * j + r)] = xs[j][r];
         if (lane == 0) l.sc[0] = scale;
+    }
+    // embedding row of the token + ln0 (rwkv_graph.inc:655-658; k_embed_ln0's statements) in the polled layout
+    static __device__ __forceinline__ float emb_at(const P47 & p, long long row, int e) {
+        if (p.emb_f16) return __half2float(reinterpret_cast<const __half *>(p.emb)[row * D + e]);
+        return reinterpret_cast<const float *>(p.emb)[row * D + e];
+    }
+    static __device__ __forceinline__ long long emb_row(const P47 & p) { const unsigned tk = p.tok[0]; return tk < (unsigned) p.V ? (long long) tk : 0ll; }
+    static __device__ __forceinline__ void embed_ln0(const P47 & p, const Lds & l, int lane, float (&xs)[NU][GPB]) {
+        const M6Arena ar{p.arena};
+        const long long row = emb_row(p);
+        float w0[NU][GPB], b0[NU][GPB];
+#pragma unroll
+        for (int j = 0; j < NU; j++)
+#pragma unroll
+            for (int r = 0; r < GPB; r++) {
+                const int e = lane + 64 * (GPB * j + r);
+                xs[j][r] = emb_at(p, row, e); w0[j][r] = ar.f(p.ln0_w)[e]; b0[j][r] = ar.f(p.ln0_b)[e];
+            }
+        float mean, scale;
+        ln_meanvar(xs, mean, scale);
+#pragma unroll
+        for (int j = 0; j < NU; j++)
+#pragma unroll
+            for (int r = 0; r < GPB; r++) { const float y = xs[j][r] * scale; const float yw = y * w0[j][r]; xs[j][r] = yw + b0[j][r]; }
+        // the residual stream of layer 0: the workers pick their own rows out of l.hx behind B1 (the buffer is the head phase's otherwise)
+#pragma unroll
+        for (int j = 0; j < NU; j++)
+#pragma unroll
+            for (int r = 0; r < GPB; r++) l.hx[lane + 64 * (GPB * j + r)] = xs[j][r];
     }
 
     // -----------------------------------------------------------------------------------------------------------
@@ -370,7 +414,8 @@ struct K47 {
             {
                 const int lane = opq(lane0);
                 float xs[NU][GPB];
-                poll_x(pl, xr, p.u_xffn, tagL - 8u + S47_XFFN, lane, xs);
+                if (li == p.l0 && p.tok) embed_ln0(p, l, lane, xs);
+                else poll_x(pl, xr, p.u_xffn, tagL - 8u + S47_XFFN, lane, xs);
                 T47(1);
                 ln_stats(l, lane, xs);
             }
@@ -479,12 +524,17 @@ struct K47 {
         const int u = unit_of(blk, own), e0 = row0_of(u);
         auto myrow_of = [&](int lane) { return e0 + 64 * (lane < GPB ? lane : 0); };   // lane r < GPB finishes row r
         float xown[GPB];
-#pragma unroll
-        for (int r = 0; r < GPB; r++) xown[r] = p.x[e0 + 64 * r];
         auto x_store = [&](int buf, unsigned tag) {
             if ((threadIdx.x & 63) == 0) tg_store(xr, buf + u, __float_as_uint(xown[0]), __float_as_uint(xown[GPB - 1]), 0u, 0u, tag);
         };
-        x_store(p.u_xffn, base - 8u + S47_XFFN);                             // the launch's input, as if a layer before the first had produced it
+        if (p.tok) {   // first stage: the residual of this wave's rows is LN0 of the embedding row, left in LDS by the comm wave (read behind B1)
+#pragma unroll
+            for (int r = 0; r < GPB; r++) xown[r] = 0.0f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < GPB; r++) xown[r] = p.x[e0 + 64 * r];
+            x_store(p.u_xffn, base - 8u + S47_XFFN);                         // the launch's input, as if a layer before the first had produced it
+        }
 
         Pro<NIA> pa; Pro<NIF> pf;
         ProSrc<NIA> sa; ProSrc<NIF> sf;
@@ -518,6 +568,10 @@ struct K47 {
             T47(0);
             __syncthreads();   // B1
             T47(1);
+            if (li == p.l0 && p.tok) {
+#pragma unroll
+                for (int r = 0; r < GPB; r++) xown[r] = l.hx[e0 + 64 * r];
+            }
             pro_run<NIA, 3, V7>(l, pa, sa, sout_l + D, blk == 0, opq(tid0));
             T47(2);
             __syncthreads();   // B2
@@ -616,8 +670,8 @@ struct K47 {
                     if constexpr (V7) xown[r] = xown[r] + res[r];
                     else { const float gte = sigmoid_f(rgate[r]) * res[r]; xown[r] = xown[r] + gte; }
                 }
-                if (last) { const float xv = pick_lane<GPB>(xown, lane); if (lane < GPB) p.x[myrow] = xv; }
-                else x_store(p.u_xffn, tagL + S47_XFFN);
+                if (last && !p.logits) { const float xv = pick_lane<GPB>(xown, lane); if (lane < GPB) p.x[myrow] = xv; }
+                else x_store(p.u_xffn, tagL + S47_XFFN);        // (the last layer's x goes to every workgroup's ln_out when the head follows in this launch)
             }
             T47(10);
             issue_A(last ? li : li + 1);
@@ -904,6 +958,174 @@ struct K47 {
             issue(li + 1 < p.l1 ? li + 1 : li);
         }
     }
+
+    // -----------------------------------------------------------------------------------------------------------
+    // ln_out + head + argmax inside the launch (rwkv_graph.inc:704-708; k_mvf's order: 32 partials per row, each a chain of FMAs in
+    // increasing k on fp16-rounded activations, ggml's fold). Every wave of the grid takes "passes" of eight rows (eight lanes per row,
+    // lane q keeps partials 4q .. 4q + 3) in chunks of CH 32-column steps through NHB register buffers. The head does not depend on the
+    // token: spare workgroups (CUs the layers do not use: 160 of 256 at D = 768) put their first chunks in flight when the launch starts,
+    // the others when their last layer is done -- E passes per spare wave are reserved for that, the rest is dealt evenly.
+    // -----------------------------------------------------------------------------------------------------------
+    static constexpr int CH = STEPS <= 24 ? 24 : 16, CPP = (STEPS + CH - 1) / CH, NHB = 2;
+    static constexpr int ESP = CPP >= NHB ? 1 : NHB / CPP;
+    struct HJ {
+        int2 buf[NHB][CH];
+        int c1, c2, sw, gw, ns, nwt, p1;      // passes of the spare region / the regular region owned by this wave, and where they start
+        int nitems;
+    };
+    static __device__ __forceinline__ int hj_pass(const HJ & h, int k) { return k < h.c1 ? h.sw + k * h.ns : h.p1 + h.gw + (k - h.c1) * h.nwt; }
+    static __device__ __forceinline__ void hj_init(HJ & h, const P47 & p, int wave) {
+        const int np = (p.V + 7) / 8, blk = blockIdx.x;
+        h.ns = p.n_spare * 9; h.nwt = (int) gridDim.x * 9;
+        h.gw = blk * 9 + wave;
+        h.sw = blk >= NBLK ? (blk - NBLK) * 9 + wave : -1;
+        h.p1 = np < ESP * h.ns ? np : ESP * h.ns;
+        h.c1 = (h.sw >= 0 && h.sw < h.p1) ? (h.p1 - h.sw + h.ns - 1) / h.ns : 0;
+        h.c2 = h.p1 + h.gw < np ? (np - h.p1 - h.gw + h.nwt - 1) / h.nwt : 0;
+        h.nitems = (h.c1 + h.c2) * CPP;
+    }
+    // chunk `it` of this wave's work into buffer b; past the end: row 0, in range (no control flow around the loads: the waits stay counted)
+    template <int B>
+    static __device__ __forceinline__ void hj_issue(HJ & h, const P47 & p, int it, int lane) {
+        const bool has = it < h.nitems;
+        const int k = it / CPP, c = it - k * CPP;
+        long long row = has ? (long long) hj_pass(h, k) * 8 + (lane >> 3) : 0;
+        if (row >= p.V) row = p.V - 1;
+        const uint16_t * base = reinterpret_cast<const uint16_t *>(p.head) + row * D + 4 * (lane & 7);
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            int st = c * CH + u; if (st >= STEPS) st = STEPS - 1;
+            { typedef int wv2i __attribute__((ext_vector_type(2))); const wv2i t = __builtin_nontemporal_load(reinterpret_cast<const wv2i *>(base + 32 * st)); h.buf[B][u] = make_int2(t.x, t.y); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int B>
+    static __device__ __forceinline__ void hj_consume(HJ & h, const P47 & p, const Lds & l, int it, int lane, float (&acc)[4], float & best, int & bi) {
+        const bool has = it < h.nitems;
+        const int k = it / CPP, c = it - k * CPP, q = lane & 7;
+        if (c == 0) { acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f; }
+#pragma unroll
+        for (int u0 = 0; u0 < CH; u0 += 8) {
+            float4 xv[8];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; t++) { int st = c * CH + u0 + t; if (st >= STEPS) st = STEPS - 1; xv[t] = *reinterpret_cast<const float4 *>(l.hx + 32 * st + 4 * q); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const bool on = c * CH + u0 + t < STEPS;
+                const unsigned w0 = (unsigned) h.buf[B][u0 + t].x, w1 = (unsigned) h.buf[B][u0 + t].y;
+                const float a0 = fmaf(h2f_bits((uint16_t) (w0 & 0xFFFFu)), xv[t].x, acc[0]), a1 = fmaf(h2f_bits((uint16_t) (w0 >> 16)), xv[t].y, acc[1]);
+                const float a2 = fmaf(h2f_bits((uint16_t) (w1 & 0xFFFFu)), xv[t].z, acc[2]), a3 = fmaf(h2f_bits((uint16_t) (w1 >> 16)), xv[t].w, acc[3]);
+                acc[0] = on ? a0 : acc[0]; acc[1] = on ? a1 : acc[1]; acc[2] = on ? a2 : acc[2]; acc[3] = on ? a3 : acc[3];
+            }
+        }
+        if (c == CPP - 1) {
+            // ggml's fold of the 32 partials: ps[i] += ps[i + 16], ps[i] += ps[i + 8], ps[i] += ps[i + 4], (ps0 + ps1) + (ps2 + ps3)
+            float ps[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v = acc[e];
+                v = v + __int_as_float(lane_xor4_i(__float_as_int(v)));
+                v = v + __int_as_float(lane_xor2_i(__float_as_int(v)));
+                v = v + __int_as_float(lane_xor1_i(__float_as_int(v)));
+                ps[e] = v;
+            }
+            const float sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            const long long row = has ? (long long) hj_pass(h, k) * 8 + (lane >> 3) : p.V;
+            if (q == 0 && row < p.V) {
+                p.logits[row] = sum;
+                if (sum > best) { best = sum; bi = (int) row; }      // rows come in increasing order per lane: ties keep the smallest index
+            }
+        }
+    }
+    static __device__ __forceinline__ void hj_prefetch(HJ & h, const P47 & p, int lane) {
+        hj_issue<0>(h, p, 0, lane);
+        if constexpr (NHB > 1) hj_issue<1>(h, p, 1, lane);
+    }
+    static __device__ __forceinline__ void am_merge(float & best, int & bi, float ov, int oi) { if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } }
+    static __device__ __forceinline__ void am_wave(float & best, int & bi) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(best, o, WAVE); const int oi = __shfl_xor(bi, o, WAVE); am_merge(best, bi, ov, oi); }
+    }
+
+    // every workgroup of the grid, after its layers (spare workgroups: straight away); prefetched = hj_prefetch ran already
+    static __device__ __forceinline__ void tail(const P47 & p, const Lds & l, HJ & h, int tid0, int wave, unsigned base) {
+        const unsigned tagT = base + (unsigned) (p.l1 - p.l0 - 1) * 8u;
+        Poll pl{p.ctl, false};
+        const M6Arena ar{p.arena};
+        const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
+        if (wave == 8) {   // ln_out statistics on what the last layer published
+            const int lane = opq(tid0) & 63;
+            float xs[NU][GPB];
+            poll_x(pl, xr, p.u_xffn, tagT + S47_XFFN, lane, xs);
+            ln_stats(l, lane, xs);
+            hj_init(h, p, wave);
+            hj_prefetch(h, p, lane);
+        }
+        __syncthreads();   // T1
+        {
+            const int tid = opq(tid0);
+            const float scale = l.sc[0];
+            for (int g = tid; g < NG4; g += 576) {
+                const float4 xc = *reinterpret_cast<const float4 *>(l.x + 4 * g);
+                const float4 w4 = *reinterpret_cast<const float4 *>(ar.f(p.lnout_w) + 4 * g), b4 = *reinterpret_cast<const float4 *>(ar.f(p.lnout_b) + 4 * g);
+                const float xs4[4] = {xc.x, xc.y, xc.z, xc.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const float y = xs4[j] * scale; const float yw = y * ww[j]; o[j] = round_f16(yw + bb[j]); }   // (fp16-rounded: what ggml feeds an F16 matrix)
+                *reinterpret_cast<float4 *>(l.hx + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __syncthreads();   // T2
+        float best = -INFINITY; int bi = 0x7fffffff;
+        {
+            const int lane = opq(tid0) & 63;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int it = 0; it < h.nitems; it += NHB) {
+                hj_consume<0>(h, p, l, it, lane, acc, best, bi);
+                hj_issue<0>(h, p, it + NHB, lane);
+                if constexpr (NHB > 1) {
+                    hj_consume<1>(h, p, l, it + 1, lane, acc, best, bi);
+                    hj_issue<1>(h, p, it + 1 + NHB, lane);
+                }
+            }
+        }
+        // ---- argmax: lanes -> wave -> workgroup -> one tagged unit per workgroup -> workgroup 0 (k_argmax's rule: greatest, then smallest index) ----
+        am_wave(best, bi);
+        if ((tid0 & 63) == 0) { l.am[wave] = __float_as_int(best); l.am[16 + wave] = bi; }
+        __syncthreads();   // T3
+        if (wave == 0) {
+            const int lane = opq(tid0) & 63;
+            float b2 = lane < 9 ? __int_as_float(l.am[lane < 9 ? lane : 0]) : -INFINITY;
+            int i2 = lane < 9 ? l.am[16 + (lane < 9 ? lane : 0)] : 0x7fffffff;
+            am_wave(b2, i2);
+            if (lane == 0) tg_store(xr, p.u_am + (int) blockIdx.x, __float_as_uint(b2), (unsigned) i2, 0u, 0u, tagT + S47_AM);
+            if (blockIdx.x == 0) {
+                const int G = (int) gridDim.x;
+                int ptr[4]; bool valid[4]; v4u dv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { ptr[k] = p.u_am + lane + 64 * k; valid[k] = lane + 64 * k < G; }
+                poll_ptrs<4>(pl, xr, ptr, valid, tagT + S47_AM, dv);
+                float b3 = -INFINITY; int i3 = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (valid[k]) am_merge(b3, i3, __uint_as_float(dv[k].x), (int) dv[k].y);
+                am_wave(b3, i3);
+                // (no element compared greater than -inf: every logit is NaN or -inf -- the token feeds the next embedding lookup and must stay a row of the table)
+                if (lane == 0) {
+                    const unsigned tokn = i3 == 0x7fffffff ? 0u : (unsigned) i3;
+                    if (p.next_tok) p.next_tok[0] = tokn;
+                    // greedy loops park a history pointer in the control words (ctl[4..5], position ctl[3]): no copy node per token on the stream
+                    if (p.ctl[2] != 0u) {
+                        unsigned * hist = reinterpret_cast<unsigned *>((unsigned long long) p.ctl[4] | ((unsigned long long) p.ctl[5] << 32));
+                        const unsigned pos = p.ctl[3];
+                        hist[pos] = tokn;
+                        p.ctl[3] = pos + 1u;
+                    }
+                }
+            }
+        }
+    }
 };
 
 template <int ARCH, int FMT, int D, int HUB, int NL1, int MAXJ>
@@ -916,23 +1138,34 @@ __global__ __launch_bounds__(576) void k47_persist(P47 p) {
     const unsigned base = p.ctl[0];
     if (tid == 0) l.fl[0] = 0u;
     __syncthreads();
+    typename K::HJ hj;
+    const bool fold_head = p.logits != nullptr;
     if ((int) blockIdx.x < K::NR) {
 #ifndef P47_X_NO_ROW_COMM
         if (wave == 8) K::row_comm(p, l, tid & 63, base);
 #endif
 #ifndef P47_X_NO_ROW_WORKER
-        if (wave != 8) K::row_worker(p, l, tid, wave, base);
+        if (wave != 8) { K::row_worker(p, l, tid, wave, base); if (fold_head) { K::hj_init(hj, p, wave); K::hj_prefetch(hj, p, tid & 63); } }
 #endif
-    } else {
+    } else if ((int) blockIdx.x < K::NBLK) {
         if constexpr (ARCH == 7) {
 #ifndef P47_X_NO_HEAD_COMM
             if (wave == 8) K::head_comm(p, l, tid & 63, base);
 #endif
 #ifndef P47_X_NO_HEAD_WORKER
-            if (wave != 8) K::head_worker(p, l, tid, wave);
+            if (wave != 8) { K::head_worker(p, l, tid, wave); if (fold_head) { K::hj_init(hj, p, wave); K::hj_prefetch(hj, p, tid & 63); } }
 #endif
         }
+    } else {
+        // spare workgroup: only rows of the head; its waves that do not poll start their stream now
+        if (fold_head && wave != 8) { K::hj_init(hj, p, wave); K::hj_prefetch(hj, p, tid & 63); }
     }
+#ifndef P47_X_NO_TAIL
+    if (fold_head) {
+        // (the polling waves issue theirs behind the poll inside tail(): results return in order per wave)
+        K::tail(p, l, hj, tid, wave, base);
+    }
+#endif
     if (blockIdx.x == 0 && tid == 0) p.ctl[0] = base + (unsigned) (p.l1 - p.l0) * 8u;
 }
 
@@ -948,9 +1181,11 @@ struct P47Handle {
     unsigned * h_ctl = nullptr;
     P47 proto{};
     long long * trace = nullptr;
-    int variant = -1, n_blocks = 0, n_layers = 0;
+    int variant = -1, n_blocks = 0, n_layers = 0, n_cu = 0;
     size_t lds = 0;
     std::vector<uint64_t> layer_bytes;   // algorithmic bytes per layer: every tensor once + the recurrent state read and written
+    bool fold_embed = false, fold_head = false;
+    uint64_t embed_bytes = 0, head_bytes = 0;
 };
 
 typedef void (*P47Kernel)(P47);
@@ -1022,7 +1257,7 @@ void * p47_create(const Model & m) {
     const int64_t D = m.n_embed(), F = 4 * D;
     const bool v7 = m.arch_major == 7;
     P47Handle * g = new P47Handle();
-    g->variant = v; g->n_blocks = pv.nblk;
+    g->variant = v; g->n_blocks = pv.nblk; g->n_cu = prop.multiProcessorCount;
     g->lds = l47_lds((int) D, v7).total;
     if (hipFuncSetAttribute((const void *) pv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) g->lds) != hipSuccess) { delete g; return nullptr; }
     std::vector<P47Layer> hl;
@@ -1080,7 +1315,7 @@ void * p47_create(const Model & m) {
     const int64_t nbD = D / 32, nbF = F / 32;
     const int64_t PAD = 2048;   // polls read whole 64-lane rounds: keep every buffer readable past its end
     auto up = [](int64_t x) { return (x + 63) / 64 * 64; };
-    const int64_t sizes[6] = {up(D) + PAD, 2048 + PAD, up(3 * nbD > D ? 3 * nbD : D) + PAD, up(D) + PAD, up(3 * nbF) + PAD, up(D) + PAD};
+    const int64_t sizes[7] = {up(D) + PAD, 2048 + PAD, up(3 * nbD > D ? 3 * nbD : D) + PAD, up(D) + PAD, up(3 * nbF) + PAD, up(D) + PAD, 256 + PAD};
     int64_t units = 0;
     for (int64_t z : sizes) units += z;
     bool ok = hipMalloc((void **) &g->d_layers, hl.size() * sizeof(P47Layer)) == hipSuccess
@@ -1098,19 +1333,44 @@ void * p47_create(const Model & m) {
     q.state_stride = m.state_per_layer();
     q.xch = g->xch; q.xch_bytes = (unsigned) (units * 16);
     int u = 0;
-    int * slots[6] = {&q.u_a, &q.u_lr1, &q.u_y, &q.u_xatt, &q.u_kq, &q.u_xffn};
-    for (int i = 0; i < 6; i++) { *slots[i] = u; u += (int) sizes[i]; }
+    int * slots[7] = {&q.u_a, &q.u_lr1, &q.u_y, &q.u_xatt, &q.u_kq, &q.u_xffn, &q.u_am};
+    for (int i = 0; i < 7; i++) { *slots[i] = u; u += (int) sizes[i]; }
     q.ctl = g->ctl;
+    q.V = (int) m.n_vocab();
+    // embedding + ln0 and ln_out + head + argmax inside the launch where the stage has them in a dtype the kernel reads (RWKV_MI_P47_NOFOLD=1: measurement aid)
+    const char * nofold = getenv("RWKV_MI_P47_NOFOLD");
+    const bool fold = !(nofold && nofold[0] == '1');
+    if (fold && m.has_embed && m.emb && m.ln0_w && m.ln0_b && (m.emb->type == T_F16 || m.emb->type == T_F32)) {
+        g->fold_embed = true;
+        q.emb = m.emb->data; q.emb_f16 = m.emb->type == T_F16 ? 1 : 0; q.ln0_w = f(m.ln0_w); q.ln0_b = f(m.ln0_b);
+        g->embed_bytes = (uint64_t) D * (m.emb->type == T_F16 ? 2 : 4) + m.ln0_w->nbytes + m.ln0_b->nbytes;
+    }
+    if (fold && m.has_head && m.head && m.ln_out_w && m.ln_out_b && m.head->type == T_F16 && g->n_cu <= 256) {
+        g->fold_head = true;
+        q.head = m.head->data; q.lnout_w = f(m.ln_out_w); q.lnout_b = f(m.ln_out_b);
+        q.n_spare = g->n_cu - g->n_blocks;
+        g->head_bytes = m.head->nbytes + m.ln_out_w->nbytes + m.ln_out_b->nbytes + (uint64_t) m.n_vocab() * 4;
+    }
+    if (!in_arena) { p47_destroy(g); return nullptr; }
     return g;
 }
 
-uint64_t p47_bytes(void * h) { uint64_t s = 0; for (uint64_t b : ((P47Handle *) h)->layer_bytes) s += b; return s; }
+uint64_t p47_bytes(void * h) { P47Handle * g = (P47Handle *) h; uint64_t s = g->embed_bytes + g->head_bytes; for (uint64_t b : g->layer_bytes) s += b; return s; }
 
-// layers [l0, l1) of the stage (indices into the stage's own layer table); sin / sout: state of layer l0
-void p47_forward_range(void * h, float * x, float * v_first, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, int l0, int l1) {
+// layers [l0, l1) of the stage (indices into the stage's own layer table); sin / sout: state of layer l0. tok (device): the launch starts
+// from LN0(emb[*tok]) instead of x when it begins at the stage's first layer and the handle folds the embedding; logits (device): ln_out +
+// head + argmax (into next_tok) run inside the launch when it ends at the stage's last layer and the handle folds the head.
+bool p47_folds_embed(void * h) { return ((P47Handle *) h)->fold_embed; }
+bool p47_folds_head(void * h) { return ((P47Handle *) h)->fold_head; }
+void p47_forward_range(void * h, float * x, float * v_first, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, int l0, int l1,
+                       float * logits, const uint32_t * tok, uint32_t * next_tok) {
     P47Handle * g = (P47Handle *) h;
     P47 q = g->proto;
     q.x = x; q.v_first = v_first; q.sin = sin; q.sout = sout; q.l0 = l0; q.l1 = l1;
+    q.tok = (g->fold_embed && l0 == 0) ? tok : nullptr;
+    q.logits = (g->fold_head && l1 == g->n_layers) ? logits : nullptr;
+    q.next_tok = next_tok;
+    const unsigned grid = (unsigned) (q.logits ? g->n_cu : g->n_blocks);
     const P47Kernel fn = g_p47[g->variant].fn;
     if (pf && pf->on) {
         if (pf->used * 2 + 2 > pf->events.size()) {
@@ -1118,14 +1378,21 @@ void p47_forward_range(void * h, float * x, float * v_first, const float * sin, 
             (void) hipEventCreate(&a); (void) hipEventCreate(&c);
             pf->events.push_back(a); pf->events.push_back(c); pf->bytes.push_back(0);
         }
-        uint64_t bytes = 0;
+        uint64_t bytes = (q.tok ? g->embed_bytes : 0) + (q.logits ? g->head_bytes : 0);
         for (int i = l0; i < l1; i++) bytes += g->layer_bytes[(size_t) i];
         pf->bytes[pf->used] = bytes;
-        hipExtLaunchKernelGGL(fn, dim3((unsigned) g->n_blocks), dim3(576), (uint32_t) g->lds, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, q);
+        hipExtLaunchKernelGGL(fn, dim3(grid), dim3(576), (uint32_t) g->lds, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, q);
         pf->used++;
     } else {
-        hipLaunchKernelGGL(fn, dim3((unsigned) g->n_blocks), dim3(576), g->lds, st, q);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(576), g->lds, st, q);
     }
+}
+// greedy loops: the kernel appends every token it picks to hist (device memory, n entries) from position 0; nullptr switches it off
+bool p47_set_history(void * h, uint32_t * hist, hipStream_t st) {
+    P47Handle * g = (P47Handle *) h;
+    const unsigned long long a = (unsigned long long) hist;
+    const unsigned w[4] = {hist ? 1u : 0u, 0u, (unsigned) (a & 0xFFFFFFFFull), (unsigned) (a >> 32)};
+    return hipMemcpyAsync(g->ctl + 2, w, sizeof(w), hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
 }
 int p47_layers(void * h) { return ((P47Handle *) h)->n_layers; }
 

@@ -265,7 +265,7 @@ bool stage_iteration(StagePart & p, rwkv_context * err, size_t t, int j) {
     if (m.has_head) {
         // the chosen token: where this context's embedding reads it (a one-stage "chain"), else in the slot the feedback hop sends from
         uint32_t * dst = m.has_embed ? c->d_tokens : c->d_next_token;
-        launch_argmax(c->d_logits, m.n_vocab(), dst, c->stream);
+        if (folded_argmax_target(c) != dst) launch_argmax(c->d_logits, m.n_vocab(), dst, c->stream);   // (else the persistent launch left it there)
         if (hipMemcpyAsync(p.d_hist + (size_t) j * p.n_tokens + t, dst, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail();
         if (p.tok_out && t + 1 < p.n_tokens && !p.tok_out->send(j, 0, dst, sizeof(uint32_t), c->stream)) return fail();
     } else {
