@@ -79,6 +79,26 @@ __device__ __forceinline__ void lf_wait(Poll & pl, const unsigned * f, unsigned 
     asm volatile("" ::: "memory");
 }
 
+// acc + f16(w) * x with the f16 operand converted inside the instruction (v_fma_mix_f32: exact conversion, one rounding -- the same value as
+// v_cvt_f32_f16 + v_fma_f32, in half the issue slots; P47_FMA_MIX=0 builds the two-instruction form for A/B runs)
+#ifndef P47_FMA_MIX
+#define P47_FMA_MIX 1
+#endif
+__device__ __forceinline__ float fma_h_lo(unsigned wpair, float x, float acc) {
+#if P47_FMA_MIX
+    float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(wpair), "v"(x), "v"(acc)); return d;
+#else
+    return fmaf(h2f_bits((uint16_t) (wpair & 0xFFFFu)), x, acc);
+#endif
+}
+__device__ __forceinline__ float fma_h_hi(unsigned wpair, float x, float acc) {
+#if P47_FMA_MIX
+    float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(wpair), "v"(x), "v"(acc)); return d;
+#else
+    return fmaf(h2f_bits((uint16_t) (wpair >> 16)), x, acc);
+#endif
+}
+
 // R rows row0, row0 + rstride, ... of a quantised matrix with nbk blocks per row: every load of the batch in flight (fused_blocks.h's
 // batch_issue with a row stride; rows are always valid here)
 template <int FMT, int R, int U>
@@ -129,6 +149,7 @@ __host__ __device__ inline L47 l47_lds(int D, bool v7) {
     return o;
 }
 
+#define TT47(K) do { if (p.trace && (threadIdx.x & 63) == 0) p.trace[((long long) blockIdx.x * 9 + (threadIdx.x >> 6)) * 16 + (K)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
 #define T47(K) do { if (p.trace && li == p.trace_layer && (threadIdx.x & 63) == 0) p.trace[((long long) blockIdx.x * 9 + (threadIdx.x >> 6)) * 16 + (K)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
 
 // ARCH 4 / 7; HUB = 32-column steps of the longest second low-rank stage (max rank / 32); NL1 = 64-unit poll slots of the lr1 vector;
@@ -370,8 +391,8 @@ struct K47 {
             for (int t = 0; t < BS; t++) {
                 const int s = bi * BS + t;
                 if (s < STEPS) {
-                    a0 = fmaf(h2f_bits((uint16_t) (jb.w[s] & 0xFFFFu)), src[t].x, a0);
-                    a1 = fmaf(h2f_bits((uint16_t) (jb.w[s] >> 16)), src[t].y, a1);
+                    a0 = fma_h_lo(jb.w[s], src[t].x, a0);
+                    a1 = fma_h_hi(jb.w[s], src[t].y, a1);
                 }
             }
         };
@@ -543,22 +564,24 @@ struct K47 {
         Batch<FMT, GPB, UF> wE;
         float st4[5];                                                         // v4: aa, bb, pp, time_first, time_decay of this lane's channel
 
-        auto issue_A = [&](int li) {
+        // has = false (behind the last layer): every lane loads block 0 of row 0 / group 0 -- one request per instruction, and the issue stays
+        // straight-line code (a branch around it leaves the buffers conditionally defined: they would live, and spill, around the whole loop)
+        auto issue_A = [&](int li, bool has) {
             __builtin_amdgcn_sched_barrier(0);
-            const int tid = opq(tid0), lane = tid & 63, myrow = myrow_of(lane);
+            const int tid = opq(tid0), lane = has ? (tid & 63) : 0, myrow = myrow_of(tid & 63);
             const P47Layer & L = p.layers[li];
             const float * sin_l = p.sin + (long long) (li - p.l0) * p.state_stride;
             sa = pro_src<NIA>(ar, L.ln1_w, L.ln1_b, L.mix_a, sin_l + D);
-            pro_load<NIA>(pa, sa, tid < NG4 ? tid : 0);
+            pro_load<NIA>(pa, sa, (has && tid < NG4) ? tid : 0);
             if constexpr (!V7) {
                 st4[0] = sin_l[2 * D + myrow]; st4[1] = sin_l[3 * D + myrow]; st4[2] = sin_l[4 * D + myrow];
                 st4[3] = ar.f(L.tf)[myrow]; st4[4] = ar.f(L.td)[myrow];
             }
-            rows_issue<FMT, GPB, UD>(wA[0], ar.w(L.wr), e0, 64, nb, lane);
-            rows_issue<FMT, GPB, UD>(wA[1], ar.w(L.wk), e0, 64, nb, lane);
-            rows_issue<FMT, GPB, UD>(wA[2], ar.w(L.wv), e0, 64, nb, lane);
+            rows_issue<FMT, GPB, UD>(wA[0], ar.w(L.wr), has ? e0 : 0, has ? 64 : 0, has ? nb : 1, lane);
+            rows_issue<FMT, GPB, UD>(wA[1], ar.w(L.wk), has ? e0 : 0, has ? 64 : 0, has ? nb : 1, lane);
+            rows_issue<FMT, GPB, UD>(wA[2], ar.w(L.wv), has ? e0 : 0, has ? 64 : 0, has ? nb : 1, lane);
         };
-        issue_A(p.l0);
+        issue_A(p.l0, true);
 
         for (int li = p.l0; li < p.l1; li++) {
             const float * sin_l = p.sin + (long long) (li - p.l0) * p.state_stride;
@@ -674,7 +697,7 @@ struct K47 {
                 else x_store(p.u_xffn, tagL + S47_XFFN);        // (the last layer's x goes to every workgroup's ln_out when the head follows in this launch)
             }
             T47(10);
-            issue_A(last ? li : li + 1);
+            issue_A(last ? li : li + 1, !last);
         }
     }
 
@@ -717,12 +740,9 @@ struct K47 {
                 if (s < HUB) {
                     if (s < nsteps) {
                         const unsigned uu[4] = {(unsigned) b.r[s].x, (unsigned) b.r[s].y, (unsigned) b.r[s].z, (unsigned) b.r[s].w};
-                        float w[8];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) { w[2 * i] = h2f_bits((uint16_t) (uu[i] & 0xFFFFu)); w[2 * i + 1] = h2f_bits((uint16_t) (uu[i] >> 16)); }
                         const float4 xa4 = src[t][0], xb4 = src[t][1];
-                        acc[0] = fmaf(w[0], xa4.x, acc[0]); acc[1] = fmaf(w[1], xa4.y, acc[1]); acc[2] = fmaf(w[2], xa4.z, acc[2]); acc[3] = fmaf(w[3], xa4.w, acc[3]);
-                        acc[4] = fmaf(w[4], xb4.x, acc[4]); acc[5] = fmaf(w[5], xb4.y, acc[5]); acc[6] = fmaf(w[6], xb4.z, acc[6]); acc[7] = fmaf(w[7], xb4.w, acc[7]);
+                        acc[0] = fma_h_lo(uu[0], xa4.x, acc[0]); acc[1] = fma_h_hi(uu[0], xa4.y, acc[1]); acc[2] = fma_h_lo(uu[1], xa4.z, acc[2]); acc[3] = fma_h_hi(uu[1], xa4.w, acc[3]);
+                        acc[4] = fma_h_lo(uu[2], xb4.x, acc[4]); acc[5] = fma_h_hi(uu[2], xb4.y, acc[5]); acc[6] = fma_h_lo(uu[3], xb4.z, acc[6]); acc[7] = fma_h_hi(uu[3], xb4.w, acc[7]);
                     }
                 }
             }
@@ -968,6 +988,7 @@ struct K47 {
     // -----------------------------------------------------------------------------------------------------------
     static constexpr int CH = STEPS <= 24 ? 24 : 16, CPP = (STEPS + CH - 1) / CH, NHB = 2;
     static constexpr int ESP = CPP >= NHB ? 1 : NHB / CPP;
+    static constexpr int HXB = NHB > 2 ? 4 : 8;   // activation reads per pinned batch
     struct HJ {
         int2 buf[NHB][CH];
         int c1, c2, sw, gw, ns, nwt, p1;      // passes of the spare region / the regular region owned by this wave, and where they start
@@ -1005,19 +1026,18 @@ struct K47 {
         const int k = it / CPP, c = it - k * CPP, q = lane & 7;
         if (c == 0) { acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f; }
 #pragma unroll
-        for (int u0 = 0; u0 < CH; u0 += 8) {
-            float4 xv[8];
+        for (int u0 = 0; u0 < CH; u0 += HXB) {
+            float4 xv[HXB];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 8; t++) { int st = c * CH + u0 + t; if (st >= STEPS) st = STEPS - 1; xv[t] = *reinterpret_cast<const float4 *>(l.hx + 32 * st + 4 * q); }
+            for (int t = 0; t < HXB; t++) { int st = c * CH + u0 + t; if (st >= STEPS) st = STEPS - 1; xv[t] = *reinterpret_cast<const float4 *>(l.hx + 32 * st + 4 * q); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const bool on = c * CH + u0 + t < STEPS;
+            for (int t = 0; t < HXB; t++) {
                 const unsigned w0 = (unsigned) h.buf[B][u0 + t].x, w1 = (unsigned) h.buf[B][u0 + t].y;
-                const float a0 = fmaf(h2f_bits((uint16_t) (w0 & 0xFFFFu)), xv[t].x, acc[0]), a1 = fmaf(h2f_bits((uint16_t) (w0 >> 16)), xv[t].y, acc[1]);
-                const float a2 = fmaf(h2f_bits((uint16_t) (w1 & 0xFFFFu)), xv[t].z, acc[2]), a3 = fmaf(h2f_bits((uint16_t) (w1 >> 16)), xv[t].w, acc[3]);
-                acc[0] = on ? a0 : acc[0]; acc[1] = on ? a1 : acc[1]; acc[2] = on ? a2 : acc[2]; acc[3] = on ? a3 : acc[3];
+                const float a0 = fma_h_lo(w0, xv[t].x, acc[0]), a1 = fma_h_hi(w0, xv[t].y, acc[1]), a2 = fma_h_lo(w1, xv[t].z, acc[2]), a3 = fma_h_hi(w1, xv[t].w, acc[3]);
+                if constexpr (CH * CPP == STEPS) { acc[0] = a0; acc[1] = a1; acc[2] = a2; acc[3] = a3; }     // (every step of every chunk is a step of the row)
+                else { const bool on = c * CH + u0 + t < STEPS; acc[0] = on ? a0 : acc[0]; acc[1] = on ? a1 : acc[1]; acc[2] = on ? a2 : acc[2]; acc[3] = on ? a3 : acc[3]; }
             }
         }
         if (c == CPP - 1) {
@@ -1035,13 +1055,14 @@ struct K47 {
             const long long row = has ? (long long) hj_pass(h, k) * 8 + (lane >> 3) : p.V;
             if (q == 0 && row < p.V) {
                 p.logits[row] = sum;
-                if (sum > best) { best = sum; bi = (int) row; }      // rows come in increasing order per lane: ties keep the smallest index
+                if (sum > best || (sum == best && (int) row < bi)) { best = sum; bi = (int) row; }
             }
         }
     }
     static __device__ __forceinline__ void hj_prefetch(HJ & h, const P47 & p, int lane) {
         hj_issue<0>(h, p, 0, lane);
         if constexpr (NHB > 1) hj_issue<1>(h, p, 1, lane);
+        if constexpr (NHB > 2) hj_issue<2>(h, p, 2, lane);
     }
     static __device__ __forceinline__ void am_merge(float & best, int & bi, float ov, int oi) { if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } }
     static __device__ __forceinline__ void am_wave(float & best, int & bi) {
@@ -1052,6 +1073,7 @@ struct K47 {
     // every workgroup of the grid, after its layers (spare workgroups: straight away); prefetched = hj_prefetch ran already
     static __device__ __forceinline__ void tail(const P47 & p, const Lds & l, HJ & h, int tid0, int wave, unsigned base) {
         const unsigned tagT = base + (unsigned) (p.l1 - p.l0 - 1) * 8u;
+        TT47(11);
         Poll pl{p.ctl, false};
         const M6Arena ar{p.arena};
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
@@ -1064,6 +1086,7 @@ struct K47 {
             hj_prefetch(h, p, lane);
         }
         __syncthreads();   // T1
+        TT47(12);
         {
             const int tid = opq(tid0);
             const float scale = l.sc[0];
@@ -1078,6 +1101,7 @@ struct K47 {
             }
         }
         __syncthreads();   // T2
+        TT47(13);
         float best = -INFINITY; int bi = 0x7fffffff;
         {
             const int lane = opq(tid0) & 63;
@@ -1089,8 +1113,13 @@ struct K47 {
                     hj_consume<1>(h, p, l, it + 1, lane, acc, best, bi);
                     hj_issue<1>(h, p, it + 1 + NHB, lane);
                 }
+                if constexpr (NHB > 2) {
+                    hj_consume<2>(h, p, l, it + 2, lane, acc, best, bi);
+                    hj_issue<2>(h, p, it + 2 + NHB, lane);
+                }
             }
         }
+        TT47(14);
         // ---- argmax: lanes -> wave -> workgroup -> one tagged unit per workgroup -> workgroup 0 (k_argmax's rule: greatest, then smallest index) ----
         am_wave(best, bi);
         if ((tid0 & 63) == 0) { l.am[wave] = __float_as_int(best); l.am[16 + wave] = bi; }
@@ -1116,6 +1145,7 @@ struct K47 {
                     const unsigned tokn = i3 == 0x7fffffff ? 0u : (unsigned) i3;
                     if (p.next_tok) p.next_tok[0] = tokn;
                     // greedy loops park a history pointer in the control words (ctl[4..5], position ctl[3]): no copy node per token on the stream
+                    TT47(15);
                     if (p.ctl[2] != 0u) {
                         unsigned * hist = reinterpret_cast<unsigned *>((unsigned long long) p.ctl[4] | ((unsigned long long) p.ctl[5] << 32));
                         const unsigned pos = p.ctl[3];
@@ -1321,7 +1351,7 @@ void * p47_create(const Model & m) {
     bool ok = hipMalloc((void **) &g->d_layers, hl.size() * sizeof(P47Layer)) == hipSuccess
            && hipMemcpy(g->d_layers, hl.data(), hl.size() * sizeof(P47Layer), hipMemcpyHostToDevice) == hipSuccess
            && hipMalloc(&g->xch, (size_t) units * 16) == hipSuccess && hipMemset(g->xch, 0, (size_t) units * 16) == hipSuccess
-           && hipMalloc((void **) &g->ctl, 256) == hipSuccess
+           && hipMalloc((void **) &g->ctl, 256) == hipSuccess && hipMemset(g->ctl, 0, 256) == hipSuccess   // (ctl[2..5]: the greedy history words)
            && hipHostMalloc((void **) &g->h_ctl, 64, hipHostMallocDefault) == hipSuccess;
     if (ok) { g->h_ctl[0] = 16u; g->h_ctl[1] = 0u; }
     const unsigned init[2] = {16u, 0u};

@@ -22,7 +22,7 @@ p47all)
   bash $0 p47 "$@"; bash $0 p47trace
   ;;
 p47)
-  ( timeout 900 python -m pytest tests/test_gpu_persist_v47.py -m gpu -q -x -p no:cacheprovider "$@" 2>&1 | tail -25 ) > $O/pytest_p47.txt; cat $O/pytest_p47.txt
+  timeout 900 python -X faulthandler -m pytest tests/test_gpu_persist_v47.py -m gpu -v -x -p no:cacheprovider "$@" > $O/pytest_p47_full.txt 2>&1; grep -v "^  File\|^$" $O/pytest_p47_full.txt | head -60 > $O/pytest_p47.txt; tail -5 $O/pytest_p47_full.txt >> $O/pytest_p47.txt; cat $O/pytest_p47.txt
   bench_one v4 rwkv4-169m Q5_1
   bench_one v7 rwkv7-2b9 Q5_1
   ;;
@@ -31,7 +31,7 @@ p47bench)
   bench_one v7 rwkv7-2b9 Q5_1 "$@"
   ;;
 p47trace)
-  timeout 200 python tools/trace_p47.py rwkv4-169m Q5_1 5 > $O/trace_v4.txt 2>&1; cat $O/trace_v4.txt | tail -40
+  timeout 200 python tools/trace_p47.py rwkv4-169m Q5_1 11 > $O/trace_v4.txt 2>&1; cat $O/trace_v4.txt | tail -40
   timeout 300 python tools/trace_p47.py rwkv7-2b9 Q5_1 9 > $O/trace_v7.txt 2>&1; cat $O/trace_v7.txt | tail -45
   R=$PWD
   for c in "v4 rwkv4-169m" "v7 rwkv7-2b9"; do n=${c% *}; cfg=${c#* }

@@ -62,4 +62,20 @@ if H:
     for k, n in enumerate(['0 layer top', '1 r k v lr1 gathered', '2 H1 H2 passed (second stages done)', '3 WKV-7 .. yq stored']):
         show(n, hd[:, 8, k])
 print('layer wall (first worker in -> last worker out): %.2f us' % (rows[:, :8, 10].max() - t0))
+# the tail (ln_out + head + argmax inside the launch): stamps 11..15 of every wave of the whole grid, relative to the first wave entering it
+ta = t[:, :, 11:16]
+if ta[:NR].max() > 0:
+    live = ta[:, :, 0] > 0
+    z = ta[:, :, 0][live].min()
+    def show2(name, a, mask):
+        a = a[mask]
+        print('  %-46s mean %7.2f   min %7.2f   max %7.2f' % (name, a.mean() - z, a.min() - z, a.max() - z))
+    nblk = NR + H
+    for nm, sel in (('row workgroups', slice(0, NR)), ('head workgroups', slice(NR, nblk)), ('spare workgroups', slice(nblk, 256))):
+        if sel.stop <= sel.start or not live[sel].any():
+            continue
+        print('tail,', nm)
+        for k, n in enumerate(['11 entered', '12 T1 passed (ln_out statistics)', '13 T2 passed (normalised x in LDS)', '14 head rows done']):
+            show2(n, ta[sel, :, k], live[sel])
+    print('  argmax written by workgroup 0: %.2f' % (ta[0, 0, 4] - z))
 m.free()
