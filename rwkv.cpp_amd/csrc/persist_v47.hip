@@ -60,7 +60,7 @@ struct P47 {
     float * logits; uint32_t * next_tok; const void * head; long long lnout_w, lnout_b; int V; int u_am; int n_spare;
 };
 
-enum { S47_A = 0, S47_Y = 1, S47_XATT = 2, S47_KQ = 3, S47_XFFN = 4, S47_AM = 5 };
+enum { S47_A = 0, S47_Y = 1, S47_XATT = 2, S47_KQ = 3, S47_XFFN = 4, S47_AM = 5, S47_IN = 6 };
 
 __device__ __forceinline__ unsigned lf_ld(const unsigned * f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lf_add(unsigned * f, unsigned v) {
@@ -153,8 +153,8 @@ __host__ __device__ inline L47 l47_lds(int D, bool v7) {
 #define T47(K) do { if (p.trace && li == p.trace_layer && (threadIdx.x & 63) == 0) p.trace[((long long) blockIdx.x * 9 + (threadIdx.x >> 6)) * 16 + (K)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
 
 // ARCH 4 / 7; HUB = 32-column steps of the longest second low-rank stage (max rank / 32); NL1 = 64-unit poll slots of the lr1 vector;
-// MAXJ = four-row jobs of the first low-rank stages per comm wave
-template <int ARCH, int FMT, int D, int HUB, int NL1, int MAXJ>
+// MAXJ = four-row jobs of the first low-rank stages per comm wave; HUB2 = steps of the longest of w2 / a2 / v2 (HUB then is g2's)
+template <int ARCH, int FMT, int D, int HUB, int NL1, int MAXJ, int HUB2>
 struct K47 {
     static constexpr bool V7 = ARCH == 7;
     static constexpr int S = 64, H = D / 64;
@@ -436,7 +436,7 @@ struct K47 {
                 const int lane = opq(lane0);
                 float xs[NU][GPB];
                 if (li == p.l0 && p.tok) embed_ln0(p, l, lane, xs);
-                else poll_x(pl, xr, p.u_xffn, tagL - 8u + S47_XFFN, lane, xs);
+                else poll_x(pl, xr, p.u_xffn, tagL - 8u + (li == p.l0 ? S47_IN : S47_XFFN), lane, xs);
                 T47(1);
                 ln_stats(l, lane, xs);
             }
@@ -526,6 +526,7 @@ struct K47 {
                 int qi, isum; float d16, s16;
                 quant_block32(v, qi, d16, s16, isum);
                 tq_store_block(xr, p.u_kq, valid ? blk * GPB + gi : 0, lane & 31, qi, d16, s16, isum, tagL + S47_KQ, valid);
+                if constexpr (UF >= 4) lf_add(l.fl + 1, 1u);
             }
             T47(9);
             // ---- E: kq ----
@@ -554,7 +555,9 @@ struct K47 {
         } else {
 #pragma unroll
             for (int r = 0; r < GPB; r++) xown[r] = p.x[e0 + 64 * r];
-            x_store(p.u_xffn, base - 8u + S47_XFFN);                         // the launch's input, as if a layer before the first had produced it
+            // the launch's input, as if a layer before the first had produced it -- under a slot of its own: with the head folded the last layer
+            // of the PREVIOUS launch published its x under (its tag) + S47_XFFN, which is exactly this launch's (base - 8) + S47_XFFN
+            x_store(p.u_xffn, base - 8u + S47_IN);
         }
 
         Pro<NIA> pa; Pro<NIF> pf;
@@ -563,6 +566,8 @@ struct K47 {
         Batch<FMT, 4, UD> wK[GPB];
         Batch<FMT, GPB, UF> wE;
         float st4[5];                                                         // v4: aa, bb, pp, time_first, time_decay of this lane's channel
+        Poll plw{p.ctl, false};
+        unsigned kq_seen = 0;
 
         // has = false (behind the last layer): every lane loads block 0 of row 0 / group 0 -- one request per instruction, and the issue stays
         // straight-line code (a branch around it leaves the buffers conditionally defined: they would live, and spill, around the whole loop)
@@ -680,6 +685,12 @@ struct K47 {
                 if constexpr (!V7) rows_sum<FMT, GPB, UD>(wFr, nb, lane, qvec_at(l.q[1], D), rgate);
             }
             T47(8);
+            if constexpr (UF >= 4) {
+                // (long rows: 77 KB per workgroup at 2.9B. Issued before the comm wave has stored this workgroup's key groups they sit in the
+                //  CU's memory pipe in front of that store -- and 159 other workgroups wait for it: measured 1.6 us on the slowest)
+                kq_seen += 1u;
+                lf_wait(plw, l.fl + 1, kq_seen);
+            }
             __builtin_amdgcn_sched_barrier(0);
             { const P47Layer & L = p.layers[li]; rows_issue<FMT, GPB, UF>(wE, ar.w(L.fv), e0, 64, nbF, opq(tid0) & 63); }
             __syncthreads();   // B6: kq
@@ -704,29 +715,32 @@ struct K47 {
     // -----------------------------------------------------------------------------------------------------------
     // head workgroup (RWKV-7): comm wave = the head's recurrence (lane = channel), workers = second low-rank stages
     // -----------------------------------------------------------------------------------------------------------
-    struct HB { int4 r[HUB]; };   // 16 rows per pass: lane = 4 row + q, lane q keeps partials 8q .. 8q + 7; one 16-byte load per 32 columns
-    static __device__ __forceinline__ void hb_issue(HB & b, const unsigned char * W, long long row, int K, int lane) {
+    // 16 rows per pass: lane = 4 row + q, lane q keeps partials 8q .. 8q + 7; one 16-byte load per 32 columns, NS steps at most
+    template <int NS> struct HB { int4 r[NS]; };
+    template <int NS>
+    static __device__ __forceinline__ void hb_issue(HB<NS> & b, const unsigned char * W, long long row, int K, int lane) {
         const int nsteps = K / 32;
 #pragma unroll
-        for (int s = 0; s < HUB; s++) {
+        for (int s = 0; s < NS; s++) {
             const int sidx = s < nsteps ? s : nsteps - 1;
             b.r[s] = ldw16(reinterpret_cast<const uint16_t *>(W) + row * K + 32 * sidx + 8 * (lane & 3));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    static __device__ __forceinline__ float hb_row(const HB & b, int K, const float * l_x, int lane) {
+    template <int NS>
+    static __device__ __forceinline__ float hb_row(const HB<NS> & b, int K, const float * l_x, int lane) {
         const int nsteps = K / 32, q = lane & 3;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[e] = 0.0f;
         // activation reads in pinned batches of three steps (six 16-byte reads), the next batch under the current one's FMAs
-        constexpr int BS = 3, NBAT = (HUB + BS - 1) / BS;
+        constexpr int BS = 3, NBAT = (NS + BS - 1) / BS;
         float4 xa[BS][2], xb[BS][2];
         auto rd = [&](float4 (&dst)[BS][2], int bi) {
 #pragma unroll
             for (int t = 0; t < BS; t++) {
                 const int s = bi * BS + t;
-                if (s < HUB) {
+                if (s < NS) {
                     const int sc = s < nsteps ? s : 0;
                     dst[t][0] = *reinterpret_cast<const float4 *>(l_x + 32 * sc + 8 * q);
                     dst[t][1] = *reinterpret_cast<const float4 *>(l_x + 32 * sc + 8 * q + 4);
@@ -737,7 +751,7 @@ struct K47 {
 #pragma unroll
             for (int t = 0; t < BS; t++) {
                 const int s = bi * BS + t;
-                if (s < HUB) {
+                if (s < NS) {
                     if (s < nsteps) {
                         const unsigned uu[4] = {(unsigned) b.r[s].x, (unsigned) b.r[s].y, (unsigned) b.r[s].z, (unsigned) b.r[s].w};
                         const float4 xa4 = src[t][0], xb4 = src[t][1];
@@ -936,25 +950,34 @@ struct K47 {
         }
     }
 
+    // Second low-rank stages of one head: 64 rows of w2 / a2 / v2 (K = their ranks, at most 32 HUB2) and of g2 (K up to 32 HUB: 320 at 2.9B).
+    // Row-steps, not rows, are what a wave pays: waves 0..3 take sixteen rows of g2 each (one pass), waves 4..7 three passes of sixteen rows
+    // out of the twelve of [w2, a2, v2] -- 10 against 9 steps per wave at 2.9B where two waves per matrix ran 20 against 6.
     static __device__ __forceinline__ void head_worker(const P47 & p, const Lds & l, int tid0, int wave) {
         const int hb = (int) blockIdx.x - NR;
         const M6Arena ar{p.arena};
-        const int mtx = wave & 3, half = wave >> 2;
-        HB ba, bb;
-        float e0[2];
+        const bool gw = wave < 4;
+        HB<HUB> bg; HB<HUB2> bs[3];
+        float e0[3];
+        // pass j of a wave of the second kind: matrix (0 w, 1 a, 3 v) and first row
+        auto pmtx = [&](int j) { const int pp = 3 * (wave - 4) + j; const int t = pp >> 2; return t == 2 ? 3 : t; };
+        auto prow = [&](int j) { const int pp = 3 * (wave - 4) + j; return 16 * (pp & 3); };
         auto issue = [&](int li) {
             const int lane = opq(tid0) & 63;
             const P47Layer & L = p.layers[li];
-            const bool has = mtx != 3 || L.has_v;
-            const int K = has ? L.rank[mtx] : 32;
-            const unsigned char * W = p.arena + (has ? L.lr2[mtx] : L.lr2[0]);
+            {   // g2 rows (every wave issues: the absent kind loads row 0 of w2 -- one request -- so the issue stays straight-line)
+                const long long row = gw ? (long long) hb * S + 16 * wave + (lane >> 2) : 0;
+                hb_issue<HUB>(bg, p.arena + L.lr2[gw ? 2 : 0], row, gw ? L.rank[2] : 32, gw ? lane : 0);
+            }
 #pragma unroll
-            for (int ps = 0; ps < 2; ps++) {
-                const long long row = has ? (long long) hb * S + (2 * half + ps) * 16 + (lane >> 2) : 0;
-                hb_issue(ps == 0 ? ba : bb, W, row, K, lane);
-                const long long ci = (long long) hb * S + (2 * half + ps) * 16 + (lane >> 2);
-                const long long off = mtx == 0 ? L.w0 : (mtx == 1 ? L.a0 : ((mtx == 3 && L.has_v) ? L.v0 : L.w0));
-                e0[ps] = ar.f(off)[ci];
+            for (int j = 0; j < 3; j++) {
+                const int m = gw ? 0 : pmtx(j);
+                const bool has = !gw && (m != 3 || L.has_v);
+                const long long row = has ? (long long) hb * S + prow(j) + (lane >> 2) : 0;
+                hb_issue<HUB2>(bs[j], p.arena + L.lr2[has ? m : 0], row, has ? L.rank[m] : 32, has ? lane : 0);
+                const long long ci = (long long) hb * S + (gw ? 0 : prow(j)) + (lane >> 2);
+                const long long off = (has && m == 1) ? L.a0 : ((has && m == 3) ? L.v0 : L.w0);
+                e0[j] = ar.f(off)[ci];
             }
         };
         issue(p.l0);
@@ -962,16 +985,19 @@ struct K47 {
             const P47Layer & L = p.layers[li];
             __syncthreads();   // H1: lr1 staged
             const int lane = opq(tid0) & 63;
-            const bool has = mtx != 3 || L.has_v;
-            if (has) {
+            if (gw) {
+                const float v = hb_row<HUB>(bg, L.rank[2], l.lr1 + L.lbase[2], lane);
+                if ((lane & 3) == 0) l.ch[2 * 64 + 16 * wave + (lane >> 2)] = v;
+            } else {
 #pragma unroll
-                for (int ps = 0; ps < 2; ps++) {
-                    const int i = (2 * half + ps) * 16 + (lane >> 2);
-                    float v = hb_row(ps == 0 ? ba : bb, L.rank[mtx], l.lr1 + L.lbase[mtx], lane);
-                    if (mtx == 0) v = det_expf(sigmoid_f(v + e0[ps]) * -0.606531f);
-                    else if (mtx == 1) v = sigmoid_f(v + e0[ps]);
-                    else if (mtx == 3) v = sigmoid_f(v + e0[ps]);
-                    if ((lane & 3) == 0) l.ch[mtx * 64 + i] = v;
+                for (int j = 0; j < 3; j++) {
+                    const int m = pmtx(j);
+                    if (m != 3 || L.has_v) {
+                        float v = hb_row<HUB2>(bs[j], L.rank[m], l.lr1 + L.lbase[m], lane);
+                        if (m == 0) v = det_expf(sigmoid_f(v + e0[j]) * -0.606531f);
+                        else v = sigmoid_f(v + e0[j]);
+                        if ((lane & 3) == 0) l.ch[m * 64 + prow(j) + (lane >> 2)] = v;
+                    }
                 }
             }
             __syncthreads();   // H2
@@ -1158,15 +1184,15 @@ struct K47 {
     }
 };
 
-template <int ARCH, int FMT, int D, int HUB, int NL1, int MAXJ>
+template <int ARCH, int FMT, int D, int HUB, int NL1, int MAXJ, int HUB2>
 __global__ __launch_bounds__(576) void k47_persist(P47 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef K47<ARCH, FMT, D, HUB, NL1, MAXJ> K;
+    typedef K47<ARCH, FMT, D, HUB, NL1, MAXJ, HUB2> K;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const typename K::Lds l = K::carve(smem);
     const unsigned base = p.ctl[0];
-    if (tid == 0) l.fl[0] = 0u;
+    if (tid == 0) { l.fl[0] = 0u; l.fl[1] = 0u; }
     __syncthreads();
     typename K::HJ hj;
     const bool fold_head = p.logits != nullptr;
@@ -1219,17 +1245,17 @@ struct P47Handle {
 };
 
 typedef void (*P47Kernel)(P47);
-struct P47Variant { int arch, fmt, D, hub, nl1, maxj, nblk; P47Kernel fn; };
+struct P47Variant { int arch, fmt, D, hub, nl1, maxj, hub2, nblk; P47Kernel fn; };
 
-#define P47_V4(FMT, DD) {4, FMT, DD, 1, 1, 1, K47<4, FMT, DD, 1, 1, 1>::NBLK, k47_persist<4, FMT, DD, 1, 1, 1>}
-#define P47_V7(FMT, DD, HUB, NL1, MAXJ) {7, FMT, DD, HUB, NL1, MAXJ, K47<7, FMT, DD, HUB, NL1, MAXJ>::NBLK, k47_persist<7, FMT, DD, HUB, NL1, MAXJ>}
+#define P47_V4(FMT, DD) {4, FMT, DD, 1, 1, 1, 1, K47<4, FMT, DD, 1, 1, 1, 1>::NBLK, k47_persist<4, FMT, DD, 1, 1, 1, 1>}
+#define P47_V7(FMT, DD, HUB, NL1, MAXJ, HUB2) {7, FMT, DD, HUB, NL1, MAXJ, HUB2, K47<7, FMT, DD, HUB, NL1, MAXJ, HUB2>::NBLK, k47_persist<7, FMT, DD, HUB, NL1, MAXJ, HUB2>}
 #ifndef P47_ONLY
 #define P47_ALL(FMT) \
     P47_V4(FMT, 256), P47_V4(FMT, 768), \
-    P47_V7(FMT, 256, 4, 4, 2), P47_V7(FMT, 2560, 10, 9, 1)
+    P47_V7(FMT, 256, 4, 4, 2, 2), P47_V7(FMT, 2560, 10, 9, 1, 3)
 // (Q8_0 at D = 2560: eight 34-byte-block key rows per wave next to the output rows do not fit 168 registers -- that file keeps the fused launches)
 static const P47Variant g_p47[] = {P47_ALL(T_Q4_0), P47_ALL(T_Q4_1), P47_ALL(T_Q5_0), P47_ALL(T_Q5_1),
-                                   P47_V4(T_Q8_0, 256), P47_V4(T_Q8_0, 768), P47_V7(T_Q8_0, 256, 4, 4, 2)};
+                                   P47_V4(T_Q8_0, 256), P47_V4(T_Q8_0, 768), P47_V7(T_Q8_0, 256, 4, 4, 2, 2)};
 #else    // (register-budget experiments: one instantiation)
 static const P47Variant g_p47[] = {P47_ONLY};
 #endif
@@ -1239,7 +1265,7 @@ static int p47_variant(const Model & m, int n_cu) {
     if (m.arch_major == 7 ? !fused_v7_supported(m) : !fused_v4_supported(m)) return -1;
     const int64_t D = m.n_embed();
     const int fmt = (int) m.header.data_type;
-    int lr_total = 0, max_rank = 0;
+    int lr_total = 0, max_rank = 0, max_rank_wav = 0;
     for (uint32_t i = m.layer_begin; i < m.layer_end; i++) {
         const LayerW & L = m.layers[i];
         if (L.ffn_key->ne[1] != 4 * D) return -1;
@@ -1251,6 +1277,7 @@ static int p47_variant(const Model & m, int n_cu) {
             const int rk = l1[k] ? (int) l1[k]->ne[1] : 0;
             tot += rk;
             if (rk > max_rank) max_rank = rk;
+            if (k != 2 && rk > max_rank_wav) max_rank_wav = rk;
         }
         if (tot > lr_total) lr_total = tot;                           // (layer 0 has no v1: the widest layer sizes the buffers)
     }
@@ -1259,7 +1286,7 @@ static int p47_variant(const Model & m, int n_cu) {
         if (pv.arch != m.arch_major || pv.fmt != fmt || pv.D != D || pv.nblk > n_cu) continue;
         if (m.arch_major == 7) {
             const int NR = (int) (D / 8) / ((D / 8 + D / 64 <= 256) ? 1 : 2);
-            if (max_rank > 32 * pv.hub || lr_total > 64 * pv.nl1 || lr_total > 2048 || lr_total / 4 > pv.maxj * NR) continue;
+            if (max_rank > 32 * pv.hub || max_rank_wav > 32 * pv.hub2 || lr_total > 64 * pv.nl1 || lr_total > 2048 || lr_total / 4 > pv.maxj * NR) continue;
         }
         return (int) v;
     }
