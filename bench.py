@@ -120,6 +120,8 @@ def parse_args():
     ap.add_argument("--abi-tokens", type=int, default=24, help="tokens timed through the unmodified rwkv_eval ABI (host state in/out every call; 0 disables)")
     ap.add_argument("--chain", action="store_true",
                     help="with --gpus N in ONE process (no torch.distributed.run): the layer chain of RWKV_MI_DEVICES over N devices, decode loop in C++")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other_configs block of the default line (BASELINE C2 / C4 / C3-decode measured beside the headline)")
     ap.add_argument("--chain-devices", default=None, help="device list of --chain (default 0-(N-1); e.g. 0,0 runs two stages on one GPU)")
     return ap.parse_args()
 
@@ -246,6 +248,35 @@ KERNEL_NAMES = {2: "k6_ring (persistent decode kernel: all layers of the stage i
                 0: "k_mvq_t1 (quantised single-token projection)"}
 
 
+OTHER_CONFIGS = [("C2", "rwkv4-169m", "Q5_1"), ("C4", "rwkv7-2b9", "Q5_1"), ("C3-decode", "rwkv6-1b6", "Q4_0")]
+
+
+def other_configs(args, pkg, lib, synth, torch):
+    """The other single-GPU decode configurations of BASELINE.json beside the headline, in the driver's own run: tokens/s, the fraction of
+    8 TB/s of the dominant kernel and of the whole token, in-run parity against the CPU oracle (tokens, last logits, whole state). Every leg
+    is wrapped: a failure there is reported in its entry and cannot lose the headline line."""
+    import argparse
+    out = {}
+    for tag, cfg, dtype in OTHER_CONFIGS:
+        t0 = time.time()
+        try:
+            sub = argparse.Namespace(**vars(args))
+            sub.config, sub.dtype, sub.steps, sub.warmup, sub.abi_tokens, sub.cpu_seconds, sub.parity_tokens, sub.quiet_fail = cfg, dtype, 128, 8, 0, 4.0, 32, True
+            os.environ["RWKV_BENCH_NO_COLD"] = "1"
+            path, spec = ensure_model_file(sub, synth, 0, lambda: None)
+            r = bench_decode(sub, pkg, lib, path, spec, torch)
+            roof = r.get("roofline", {})
+            out[tag] = {"workload": r["config"]["workload"], "tokens_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": sub.steps,
+                        "decode_path": r["config"]["decode_path"], "persist_kind": r["config"]["persist_kind"],
+                        "kernel": roof.get("kernel"), "kernel_frac_of_8TBps": roof.get("frac"), "kernel_avg_launch_us": roof.get("avg_launch_us"),
+                        "token_frac_of_8TBps": r["hbm"]["frac_of_8TBps"], "algorithmic_bytes_per_token": r["hbm"]["algorithmic_bytes_per_token"],
+                        "parity": {k: r.get("parity", {}).get(k) for k in ("tokens_checked", "equal", "tokens_equal", "logits_equal", "state_equal", "crosses_tag_wrap")},
+                        "cpu_tokens_per_s": r.get("cpu_baseline", {}).get("value"), "seconds": round(time.time() - t0, 1)}
+        except (Exception, SystemExit) as e:   # noqa: BLE001
+            out[tag] = {"error": repr(e), "seconds": round(time.time() - t0, 1)}
+    return out
+
+
 def bench_decode(args, pkg, lib, path, spec, torch):
     """One step = one decoded token (embedding row, every layer, ln_out, head, on-device argmax), state resident in HBM."""
     import numpy as np
@@ -324,7 +355,8 @@ def bench_decode(args, pkg, lib, path, spec, torch):
                                 "what": "n greedy tokens of rwkv_mi_decode_greedy on this file from a fresh state vs the CPU oracle's: token ids, the last "
                                         "token's logits and the whole state, np.array_equal"}
             if not equal:
-                print(json.dumps(result))
+                if not getattr(args, "quiet_fail", False):
+                    print(json.dumps(result))
                 raise SystemExit(f"[bench] PARITY FAILURE: GPU != CPU oracle after {n} greedy tokens (tokens {eq_t}, logits {eq_l}, state {eq_s}, healthy {healthy})")
     model.free()
     return result
@@ -571,6 +603,8 @@ def main():
         result = bench_prefill(args, pkg, lib, path, spec, torch)
     else:
         result = bench_decode(args, pkg, lib, path, spec, torch)
+        if args.config == "rwkv6-7b" and args.dtype == "Q4_0" and not args.no_other_configs:
+            result["other_configs"] = other_configs(args, pkg, lib, synth, torch)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -440,6 +440,9 @@ struct K47 {
                 T47(1);
                 ln_stats(l, lane, xs);
             }
+            T47(2);
+            __syncthreads();   // B1: x - mean and the scale are in LDS
+            // (the first low-rank stages' rows go in flight behind B1: issuing eighty loads in front of it cost the workers a microsecond of x)
             Job jb[V7 ? MAXJ : 1];
             int jm[MAXJ], jrow[MAXJ]; bool jhas[MAXJ];
             if constexpr (V7) {
@@ -457,8 +460,6 @@ struct K47 {
                     job_issue(jb[k], p.arena + L.lr1[jm[k]], jrow[k], lane);
                 }
             }
-            T47(2);
-            __syncthreads();   // B1: x - mean and the scale are in LDS
             __syncthreads();   // B2: the workers' images
             if constexpr (V7) {
                 const int lane = opq(lane0);
