@@ -41,13 +41,13 @@ p47trace)
   ;;
 default)
   # the driver's own command: headline + other_configs, timed
-  /usr/bin/time -v timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -1 $O/bench_default.json | line default
+  SECONDS=0; timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench.py (no flags) wall: ${SECONDS}s"; tail -1 $O/bench_default.json | line default
   python - <<PY
 import json
 d=json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
 for k,v in d.get("other_configs",{}).items(): print(k, {a:(round(b,3) if isinstance(b,float) else b) for a,b in v.items() if a in ("tokens_per_s","kernel_frac_of_8TBps","token_frac_of_8TBps","parity","error","seconds","persist_kind")})
 PY
-  grep -E "Elapsed|Maximum resident" $O/bench_default.err
+  tail -3 $O/bench_default.err
   ;;
 suite)
   ( timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15 ) > $O/pytest.txt; cat $O/pytest.txt
