@@ -35,22 +35,23 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // the completion event of the previous persistent launch of the process. Other processes cannot be seen from here: a poll
 // time-out is recovered from by dropping to the per-layer launches (recover_from_abort).
 // ---------------------------------------------------------------------------------------------------------------
-static std::mutex g_mega_mu;
 static constexpr int k_max_devices = 64;
+static std::mutex g_mega_mu[k_max_devices + 1];   // per device: a streamed rwkv_eval holds it across its host-blocking slice uploads, other devices go on
 static hipEvent_t g_mega_last[k_max_devices] = {};
 static rwkv_context * g_mega_last_owner[k_max_devices] = {};
 static int g_mega_contexts[k_max_devices] = {};   // contexts of this process holding a persistent kernel, per device
 
+static std::mutex & mega_mu(int dev) { return g_mega_mu[(dev >= 0 && dev < k_max_devices) ? dev : k_max_devices]; }
 static int mega_chain_count(rwkv_context * ctx, int delta) {
-    std::lock_guard<std::mutex> lk(g_mega_mu);
     const int dev = ctx->model->device;
+    std::lock_guard<std::mutex> lk(mega_mu(dev));
     if (dev < 0 || dev >= k_max_devices) return 0;
     return g_mega_contexts[dev] += delta;
 }
 
 static void mega_chain_begin(rwkv_context * ctx) {
-    g_mega_mu.lock();
     const int dev = ctx->model->device;
+    mega_mu(dev).lock();
     if (dev >= 0 && dev < k_max_devices && g_mega_last[dev] && g_mega_last_owner[dev] != ctx) (void) hipStreamWaitEvent(ctx->stream, g_mega_last[dev], 0);
 }
 static void mega_chain_end(rwkv_context * ctx) {
@@ -59,11 +60,11 @@ static void mega_chain_end(rwkv_context * ctx) {
     if (dev >= 0 && dev < k_max_devices && g_mega_contexts[dev] > 1 && ctx->mega_done && hipEventRecord(ctx->mega_done, ctx->stream) == hipSuccess) {
         g_mega_last[dev] = ctx->mega_done; g_mega_last_owner[dev] = ctx;
     }
-    g_mega_mu.unlock();
+    mega_mu(dev).unlock();
 }
 static void mega_chain_forget(rwkv_context * ctx) {
-    std::lock_guard<std::mutex> lk(g_mega_mu);
     const int dev = ctx->model->device;
+    std::lock_guard<std::mutex> lk(mega_mu(dev));
     if (dev >= 0 && dev < k_max_devices && g_mega_last_owner[dev] == ctx) {
         if (g_mega_last[dev]) (void) hipEventSynchronize(g_mega_last[dev]);
         g_mega_last[dev] = nullptr; g_mega_last_owner[dev] = nullptr;
@@ -91,7 +92,10 @@ static void calibrate_decode_path(rwkv_context * ctx) {
     // candidates: [0] the handle create_context made, [1] the other persistent kernel (when the environment names none), fused = nullptr
     void * cand[2] = {ctx->mega, nullptr};
     const char * pk = getenv("RWKV_MI_PERSIST");
-    if (!(pk && pk[0]) && mega_v6_kind(cand[0]) == 2) cand[1] = mega_v6_create_kind(m, 1);
+    // (the register-prefetch kernel only where it has been seen within 2 % of the ring: D = 2048 -- profiles/r04y_prefill_1b6_q4_0_kernel_stats.csv
+    //  calibration rows, 710 vs 726 us; at D = 4096 / 2560 the ring wins by 10 % and more and timing a third path cost every context
+    //  creation ~15 ms. RWKV_MI_PERSIST=regs still names it.)
+    if (!(pk && pk[0]) && mega_v6_kind(cand[0]) == 2 && m.n_embed() == 2048) cand[1] = mega_v6_create_kind(m, 1);
     // (with logits: the ring kernel runs ln_out + head inside its launch, the other paths as launches of their own -- part of what is compared)
     auto run = [&](void * h, int n) { ctx->mega = h; for (int i = 0; i < n && ok; i++) ok = forward(ctx, 1, m.has_head); };
     auto timed = [&](void * h) -> float {
@@ -268,7 +272,7 @@ void destroy_context(rwkv_context * ctx) {
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->prof.events) (void) hipEventDestroy(e);
-    if (ctx->stream && ctx->owns_stream) (void) hipStreamDestroy(ctx->stream);
+    if (ctx->stream && ctx->owns_stream) { matvec_f_release_stream(ctx->stream); (void) hipStreamDestroy(ctx->stream); }
     release_model(ctx->model);
     delete ctx;
 }
@@ -318,8 +322,12 @@ bool ensure_scratch(rwkv_context * ctx, int64_t T) {
     return true;
 }
 
+std::atomic<int> g_test_fail_state_init{0};   // (tests: librwkv_testhooks.so arms it; the next state initialisation fails once)
+
 bool state_from_host(rwkv_context * ctx, const float * state_in) {
     Model & m = *ctx->model;
+    if (g_test_fail_state_init.load(std::memory_order_relaxed) > 0 && g_test_fail_state_init.fetch_sub(1) > 0)
+        RW_CTX_CHECK(ctx, RWKV_ERROR_GRAPH, false, false, "state initialisation failed (injected by the test hook)");
     float * dst = ctx->state[ctx->cur];
     if (state_in) {
         HIP_CTX_OK(ctx, hipMemcpyAsync(dst, state_in, (size_t) m.state_len() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -763,6 +771,10 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
     const int64_t per = m.state_per_layer();
     float * sin = ctx->state[ctx->cur];
     float * sout = ctx->state[ctx->cur ^ 1];
+    // every fallible step of the set-up comes BEFORE the download job is published: a return between arming the worker and the final wait
+    // would leave it inside a stale job holding the caller's pointer (it then finished the NEXT call's groups twice, the second time after
+    // that call had returned)
+    if (!h_in) { if (!state_from_host(ctx, nullptr)) return false; }
     std::vector<std::pair<uint32_t, uint32_t>> ranges;
     {
         std::lock_guard<std::mutex> lk(a->mu);
@@ -778,7 +790,6 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
     }
     a->cv.notify_all();
     Runner r{ctx, m, ctx->stream, 1, m.n_embed(), m.head_count, m.head_size, ctx->b};
-    if (!h_in) { if (!state_from_host(ctx, nullptr)) return false; }
     r.run_embed();
     const bool chained = ctx->mega != nullptr;
     if (chained) mega_chain_begin(ctx);

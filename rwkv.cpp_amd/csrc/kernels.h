@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "common.h"
 
 namespace rwkvmi {
@@ -40,6 +41,9 @@ struct Epi {
 void launch_matvec_q(const DevTensor & W, const QAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st);
 // Same for F32 / F16 weights with f32 activations x[t*ldx + k] (F16 weights: activations rounded to fp16 on load).
 void launch_matvec_f(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st);
+
+extern std::atomic<unsigned long long> g_mmf16_launches;   // launches of the F16 matrix-core sequence kernel so far (test hook reads it)
+void matvec_f_release_stream(hipStream_t st);   // frees the split-K workspace kept for this stream (a context's own stream, at its destruction)
 
 // x[T][K] f32 -> QAct
 void launch_quantize_act(const float * x, int64_t T, int64_t K, const QAct & out, hipStream_t st);
@@ -114,9 +118,6 @@ void launch_fill_state_v4(float * state, int64_t n_layer, int64_t D, hipStream_t
 
 // argmax over logits[n] -> *out (first index of the maximum), used by the on-device greedy decode loop
 void launch_argmax(const float * logits, int64_t n, uint32_t * out, hipStream_t st);
-
-// test hook: deterministic scalar functions (0 exp, 1 tanh, 2 sigmoid, 3 silu, 4 exp(-exp), 5 v7 decay, 6 1/sqrt(x+1e-5))
-void launch_test_unary(int op, const float * x, float * y, int64_t n, hipStream_t st);
 
 // load-time transpose of att.time_maa_w2: [5][D][R] -> [5][R][D]
 void launch_transpose_w2(const float * src, float * dst, int64_t D, int64_t R, hipStream_t st);

@@ -17,6 +17,8 @@
 //    which the tests assert with array_equal.
 #include "kdev.h"
 
+#include <atomic>
+
 #include <mutex>
 #include <vector>
 
@@ -403,6 +405,8 @@ __global__ __launch_bounds__(256) void k_mmf16_combine(MfArgs p) {
     if (n < p.N && t < p.T) p.y[t * p.ldy + n] = apply_epi(p.epi, sum, t, n, p.ldy);
 }
 
+std::atomic<unsigned long long> g_mmf16_launches{0};   // launches of k_mmf16_seq by this process (tests assert that the arm they mean to test ran)
+
 static bool seq_f16_on_mfma() {   // (read per call: the test suite runs both arms in one process)
     const char * e = getenv("RWKV_MI_SEQ_F16");
     return !(e && e[0] == 'v');
@@ -423,11 +427,22 @@ static float * mf_workspace(int dev, hipStream_t st) {
     return part;
 }
 
+// a context that owns its stream drops the stream's workspace when it goes (destroy_context): processes that create and destroy many
+// contexts do not accumulate 16 MB per stream handle
+void matvec_f_release_stream(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mf_mu);
+    for (size_t i = 0; i < g_mf_ws.size();) {
+        if (g_mf_ws[i].st == st) { (void) hipFree(g_mf_ws[i].part); g_mf_ws.erase(g_mf_ws.begin() + (long) i); }
+        else i++;
+    }
+}
+
 void launch_matvec_f(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
     if (W.type == T_F16 && T >= 32 && W.cols() % 8 == 0 && ldx % 4 == 0 && seq_f16_on_mfma()) {
         const int64_t N = W.rows(), K = W.cols();
         MfArgs a{};
         a.W = (const uint16_t *) W.data; a.x = x; a.y = y; a.N = N; a.K = K; a.ldx = ldx; a.T = T; a.ldy = ldy; a.epi = epi; a.ksplit = 1;
+        g_mmf16_launches.fetch_add(1, std::memory_order_relaxed);
         const int64_t tiles = ((N + 63) / 64) * ((T + 63) / 64), chunks = (K + MF_KC - 1) / MF_KC;
         int dev = 0;
         (void) hipGetDevice(&dev);
@@ -984,34 +999,6 @@ __global__ __launch_bounds__(1024) void k_argmax(const float * __restrict__ logi
 }
 void launch_argmax(const float * logits, int64_t n, uint32_t * out, hipStream_t st) {
     hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, n, out);
-}
-
-// Test hook: the deterministic scalar functions applied elementwise (compared against the oracle's on the CPU).
-__global__ __launch_bounds__(256) void k_test_unary(int op, const float * __restrict__ x, float * __restrict__ y, int64_t n) {
-    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) {
-        const float v = x[i];
-        float r;
-        switch (op) {
-            case 0: r = det_expf(v); break;
-            case 1: r = det_tanhf(v); break;
-            case 2: r = sigmoid_f(v); break;
-            case 3: r = v / (1.0f + det_expf(-v)); break;
-            case 4: r = det_expf(-det_expf(v)); break;
-            case 5: r = det_expf(sigmoid_f(v) * -0.606531f); break;
-            case 6: r = 1.0f / sqrtf(v + 1e-5f); break;
-            case 7: { const float a = wave_sum_f(v), b = wave_sum_f_ref(v); r = (__float_as_uint(a) == __float_as_uint(b)) ? 1.0f : 0.0f; break; }
-            case 8: { const double xd = (double) v * (1.0 + 1e-9 * (double) (threadIdx.x & 63));
-                      const double a = wave_sum_d(xd), b = wave_sum_d_ref(xd); r = (a == b) ? 1.0f : 0.0f; break; }
-            case 9: { float m = fabsf(v); for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
-                      int q = (int) v, sref = q; for (int o = 16; o > 0; o >>= 1) sref += __shfl_xor(sref, o, WAVE);
-                      r = (half_max_f(fabsf(v)) == m && half_sum_i(q) == sref) ? 1.0f : 0.0f; break; }
-            default: r = v; break;
-        }
-        y[i] = r;
-    }
-}
-void launch_test_unary(int op, const float * x, float * y, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(k_test_unary, dim3(1024), dim3(256), 0, st, op, x, y, n);
 }
 
 // load-time transpose of the v6 mix matrix: [5][D][R] (file) -> [5][R][D], so that lanes read consecutive d

@@ -192,6 +192,7 @@ namespace rwkvmi {
 rwkv_context * create_context(Model * m, uint32_t n_threads);
 void destroy_context(rwkv_context * ctx);
 
+extern std::atomic<int> g_test_fail_state_init;   // test hook (rwkv_mi_test_fail_state_init): the next n state initialisations fail
 // state upload / download / init on the device-resident state
 bool state_from_host(rwkv_context * ctx, const float * state_in /* NULL = fresh */);
 bool state_to_host(rwkv_context * ctx, float * state_out);

@@ -2,12 +2,44 @@
 // lib/librwkv_testhooks.so (every product object + this file), which the kernel-level parity tests load (tests/gpu_lib.py). The product
 // library exports the rwkv.h / rwkv_mi355x.h symbols and nothing else (csrc/rwkv.map).
 #include "model.h"
+#include "kdev.h"
 #include "rwkv_mi355x.h"
 #include "rwkv_testhooks.h"
 
 #include <cstdlib>
 
 using namespace rwkvmi;
+
+namespace rwkvmi {
+// Test hook: the deterministic scalar functions applied elementwise (compared against the oracle's on the CPU).
+__global__ __launch_bounds__(256) void k_test_unary(int op, const float * __restrict__ x, float * __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) {
+        const float v = x[i];
+        float r;
+        switch (op) {
+            case 0: r = det_expf(v); break;
+            case 1: r = det_tanhf(v); break;
+            case 2: r = sigmoid_f(v); break;
+            case 3: r = v / (1.0f + det_expf(-v)); break;
+            case 4: r = det_expf(-det_expf(v)); break;
+            case 5: r = det_expf(sigmoid_f(v) * -0.606531f); break;
+            case 6: r = 1.0f / sqrtf(v + 1e-5f); break;
+            case 7: { const float a = wave_sum_f(v), b = wave_sum_f_ref(v); r = (__float_as_uint(a) == __float_as_uint(b)) ? 1.0f : 0.0f; break; }
+            case 8: { const double xd = (double) v * (1.0 + 1e-9 * (double) (threadIdx.x & 63));
+                      const double a = wave_sum_d(xd), b = wave_sum_d_ref(xd); r = (a == b) ? 1.0f : 0.0f; break; }
+            case 9: { float m = fabsf(v); for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+                      int q = (int) v, sref = q; for (int o = 16; o > 0; o >>= 1) sref += __shfl_xor(sref, o, WAVE);
+                      r = (half_max_f(fabsf(v)) == m && half_sum_i(q) == sref) ? 1.0f : 0.0f; break; }
+            default: r = v; break;
+        }
+        y[i] = r;
+    }
+}
+static void launch_test_unary(int op, const float * x, float * y, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_test_unary, dim3(1024), dim3(256), 0, st, op, x, y, n);
+}
+
+}  // namespace rwkvmi
 
 extern "C" {
 
@@ -17,6 +49,12 @@ RWKV_API bool rwkv_mi_test_set_tag(struct rwkv_context * ctx, uint32_t base) {
     if (hipSetDevice(ctx->model->device) != hipSuccess) return false;
     return mega_v6_set_tag(ctx->mega, base, ctx->stream);
 }
+
+// Test hook: the next n state initialisations (state_from_host) of this process fail -- the error paths of rwkv_eval.
+RWKV_API void rwkv_mi_test_fail_state_init(int n) { g_test_fail_state_init.store(n); }
+
+// Test hook: launches of the F16 matrix-core sequence kernel (k_mmf16_seq) by this process so far.
+RWKV_API uint64_t rwkv_mi_test_mmf16_launches(void) { return (uint64_t) g_mmf16_launches.load(); }
 
 // Test hook: the activation quantiser (f32 -> Q8_0/Q8_1 blocks) on standalone buffers.
 RWKV_API bool rwkv_mi_test_quantize_act(const float * x, int64_t n, int8_t * q, float * d, float * s, int32_t * isum) {

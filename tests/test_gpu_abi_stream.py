@@ -101,3 +101,38 @@ def test_streamed_eval_without_logits_or_without_state_out(tmp_path):
     assert np.array_equal(m.state_store(), ost2)                                                   # ... but it is on the device
     m.free()
     om.free()
+
+
+def test_streamed_eval_error_before_the_download_job_is_armed(tmp_path):
+    """forward_streamed used to publish the download job (caller's state_out pointer included) BEFORE a fallible set-up step and return
+    early on its failure: the download thread then finished the NEXT call's groups inside the stale job and ran the new job a second time
+    after that call had returned -- a late write into caller memory. Inject the failure (test hook), then: the failed call leaves the
+    caller's buffers untouched, the next call is right, and a buffer handed to the failed call is never written afterwards."""
+    import ctypes
+    import time
+    from gpu_lib import hooks_library
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS["mega-v6-2048"]
+    synth.write_model(p, spec, "Q4_0", seed=87)
+    om = O.OracleModel(p)
+    m = model(p, hooks=True)
+    H = hooks_library().library
+    H.rwkv_mi_test_fail_state_init.argtypes = [ctypes.c_int]
+    H.rwkv_mi_test_fail_state_init.restype = None
+    sentinel = np.float32(-12345.5)
+    victim = np.full(m.state_len, sentinel, dtype=np.float32)
+    logits = np.full(m.n_vocab, sentinel, dtype=np.float32)
+    H.rwkv_mi_test_fail_state_init(1)
+    with pytest.raises(ValueError):
+        m.eval(5, None, victim, logits)           # state_in NULL: the fresh state is initialised on the device -> injected failure
+    assert (victim == sentinel).all() and (logits == sentinel).all()
+    ost = om.init_state()
+    st = None
+    for t in TOKENS[:3]:
+        ol, ost = om.eval(t, ost)
+        lg, st = m.eval(t, st)                    # other output buffers
+        assert np.array_equal(lg, ol) and np.array_equal(st, ost)
+    time.sleep(0.2)                               # (a stale download job would have fired by now)
+    assert (victim == sentinel).all(), "late write into the buffer of the failed call"
+    assert m.healthy()
+    m.free(); om.free()

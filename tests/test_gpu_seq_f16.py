@@ -23,7 +23,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from gpu_lib import gpu_mul_mat, library, model, synth
+from gpu_lib import gpu_mul_mat, hooks_library, library, model, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -106,5 +106,46 @@ def test_sequence_pass_on_the_matrix_cores(tmp_path, name, fmt, T):
         lg, st = m.eval(t, st)
         olg, ost2 = om.eval(t, ost2)
     assert np.array_equal(lg, olg) and np.array_equal(st, ost2)
+    m.free()
+    om.free()
+
+
+def _mmf16_launches():
+    import ctypes
+    L = hooks_library().library
+    L.rwkv_mi_test_mmf16_launches.restype = ctypes.c_uint64
+    return int(L.rwkv_mi_test_mmf16_launches())
+
+
+@pytest.mark.parametrize("name,fmt", [("slice-v7-2560", "Q5_1"), ("test-v7", "Q5_1"), ("test-v6", "FP16"), ("test-v4", "FP16")])
+@pytest.mark.parametrize("T", [32, 33, 64, 97, 130])
+def test_one_layer_slices_on_the_matrix_cores_tight(tmp_path, name, fmt, T):
+    """The product's DEFAULT sequence arm for F16 matrices at ragged lengths, held two orders tighter than the multi-layer cases above:
+    ONE layer (no depth to amplify a last-bit difference through further recurrences), logits and state within 1e-4 * (1 + max |oracle|).
+    A tile-edge or split-K wiring error is worth >= 1e-3 here. The launch counter -- not err > 0 -- proves the matrix-core kernel ran."""
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS[name]
+    synth.write_model(p, spec, fmt, seed=61, limit_layers=1)
+    toks = [int((1103515245 * i + 12345) % spec.n_vocab) for i in range(T)]
+    om = O.OracleModel(p)
+    ol, ost = om.eval_sequence(toks, om.init_state())
+    m = model(p, hooks=True)
+    before = _mmf16_launches()
+    gl, gst = m.eval_sequence(toks, None)
+    assert _mmf16_launches() > before, "the F16 matrix-core kernel did not run"
+    for a, b, what in ((gl, ol, "logits"), (gst, ost, "state")):
+        tol = 1e-4 * (1.0 + float(np.abs(b).max()))
+        err = float(np.abs(a - b).max())
+        assert err <= tol, (name, fmt, T, what, err, tol)
+    # chunked: passes of 40 tokens take the kernel again at other tile shapes (ragged last pass below 32 tokens: the exact kernels)
+    cl, cst = m.eval_sequence_in_chunks(toks, None, chunk_size=40)
+    for a, b, what in ((cl, ol, "chunked logits"), (cst, ost, "chunked state")):
+        tol = 1e-4 * (1.0 + float(np.abs(b).max()))
+        assert float(np.abs(a - b).max()) <= tol, (name, fmt, T, what)
+    os.environ["RWKV_MI_SEQ_F16"] = "valu"
+    before = _mmf16_launches()
+    el, est = m.eval_sequence(toks, None)
+    assert _mmf16_launches() == before and np.array_equal(el, ol) and np.array_equal(est, ost)
+    os.environ["RWKV_MI_SEQ_F16"] = "mfma"
     m.free()
     om.free()

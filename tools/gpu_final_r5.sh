@@ -1,0 +1,14 @@
+#!/bin/bash
+# Evidence run of round 5: the WHOLE -m gpu suite first; evidence is recorded only when it finished green (round 4 ended with its last
+# suite run killed by its own timeout behind the experiments). usage: tools/gpu_final_r5.sh <tag>
+set -u
+cd "$(dirname "$0")/.."
+T=${1:-r05z}; O=gpurun_out/$T; mkdir -p $O
+export TMPDIR=/tmp RWKV_BENCH_DIR=/tmp
+git rev-parse HEAD > $O/head.txt 2>/dev/null || true
+SECONDS=0
+( timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -15 ) > $O/pytest.txt; cat $O/pytest.txt; echo "suite wall: ${SECONDS}s" >> $O/pytest.txt
+if ! grep -q " passed" $O/pytest.txt || grep -q "failed\|error" $O/pytest.txt; then echo "SUITE NOT GREEN: no evidence recorded"; exit 1; fi
+RWKV_FINAL_SKIP_SUITE=1 bash tools/gpu_final.sh $T
+timeout 200 python tools/trace_p47.py rwkv4-169m Q5_1 11 > $O/p47_phase_trace_v4_169m.txt 2>&1
+timeout 300 python tools/trace_p47.py rwkv7-2b9 Q5_1 9 > $O/p47_phase_trace_v7_2b9.txt 2>&1
