@@ -20,6 +20,9 @@ RWKV_API void rwkv_mi_test_fail_state_init(int n);
 /* Test hook (used by tests/ only): how often the F16 matrix-core sequence kernel has been launched by this process. */
 RWKV_API uint64_t rwkv_mi_test_mmf16_launches(void);
 
+/* Test hook (used by tests/ only): how often the plain-order quantised sequence GEMM has been launched by this process. */
+RWKV_API uint64_t rwkv_mi_test_mmq_fast_launches(void);
+
 /* Test hook (used by tests/ only): the activation quantiser; n multiple of 32; d, s, isum have n/32 entries. */
 RWKV_API bool rwkv_mi_test_quantize_act(const float * x, int64_t n, int8_t * q, float * d, float * s, int32_t * isum);
 

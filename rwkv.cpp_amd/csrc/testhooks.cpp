@@ -3,6 +3,7 @@
 // library exports the rwkv.h / rwkv_mi355x.h symbols and nothing else (csrc/rwkv.map).
 #include "model.h"
 #include "kdev.h"
+#include "prefill_mm.h"
 #include "rwkv_mi355x.h"
 #include "rwkv_testhooks.h"
 
@@ -55,6 +56,9 @@ RWKV_API void rwkv_mi_test_fail_state_init(int n) { g_test_fail_state_init.store
 
 // Test hook: launches of the F16 matrix-core sequence kernel (k_mmf16_seq) by this process so far.
 RWKV_API uint64_t rwkv_mi_test_mmf16_launches(void) { return (uint64_t) g_mmf16_launches.load(); }
+
+// Test hook: launches of the plain-order quantised GEMM (k_mmq_fast) by this process so far.
+RWKV_API uint64_t rwkv_mi_test_mmq_fast_launches(void) { return (uint64_t) g_mmq_fast_launches.load(); }
 
 // Test hook: the activation quantiser (f32 -> Q8_0/Q8_1 blocks) on standalone buffers.
 RWKV_API bool rwkv_mi_test_quantize_act(const float * x, int64_t n, int8_t * q, float * d, float * s, int32_t * isum) {

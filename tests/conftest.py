@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # order (bit-identical to the oracle). The suite's np.array_equal checks run on the exact arm; tests/test_gpu_seq_f16.py switches to
 # the matrix-core arm and checks it against the oracle within a stated tolerance.
 os.environ.setdefault("RWKV_MI_SEQ_F16", "valu")
+# The same for quantised matrices (csrc/prefill_fast.hip, launch_mmq_fast): the default accumulates the block sums in plain K order
+# (k_mmq_fast), the exact arm (k_mmq_mfma) walks K in the single-token kernel's order. tests/test_gpu_prefill_fast.py runs the default arm.
+os.environ.setdefault("RWKV_MI_SEQ_Q", "exact")
 
 
 def pytest_configure(config):

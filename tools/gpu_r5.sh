@@ -39,6 +39,17 @@ p47trace)
     f=$(find /tmp/prof_$n -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f $O/decode_${n}_kernel_stats.csv; head -8 $f | cut -c1-160; fi
   done
   ;;
+prefill)
+  timeout 900 python -m pytest tests/test_gpu_prefill_fast.py -m gpu -q -x -p no:cacheprovider "$@" > $O/pytest_fast_full.txt 2>&1; tail -15 $O/pytest_fast_full.txt | grep -v "^$" > $O/pytest_fast.txt; cat $O/pytest_fast.txt
+  pline() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline',{}); p=d.get('parity',{})
+print('$1', round(d['value'],1), d['unit'], round(d['ms_per_step'],3), 'ms/pass', 'gemm TOP/s', round(r.get('achieved',0),1), 'avg_us', round(r.get('avg_launch_us',0),2), 'launches', r.get('launches'), 'parity', p.get('equal'), p.get('exact_arm_bit_identical'), json.dumps(p.get('timed_arm',{}))[:400], flush=True)
+"; }
+  timeout 400 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 25 --parity-tokens 1024 > $O/prefill_1b6_q4_0.json 2> $O/prefill_1b6.err; tail -1 $O/prefill_1b6_q4_0.json | pline 1b6
+  RWKV_MI_SEQ_Q=exact timeout 400 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 0 --parity-tokens 0 > $O/prefill_1b6_q4_0_exact.json 2>> $O/prefill_1b6.err; tail -1 $O/prefill_1b6_q4_0_exact.json | pline 1b6-exact
+  timeout 400 python bench.py --config rwkv7-2b9 --dtype Q5_1 --mode prefill --steps 3 --warmup 1 --cpu-seconds 8 --parity-tokens 128 > $O/prefill_7v_2b9_q5_1.json 2> $O/prefill_2b9.err; tail -1 $O/prefill_7v_2b9_q5_1.json | pline 2b9
+  ;;
 default)
   # the driver's own command: headline + other_configs, timed
   SECONDS=0; timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench.py (no flags) wall: ${SECONDS}s"; tail -1 $O/bench_default.json | line default
