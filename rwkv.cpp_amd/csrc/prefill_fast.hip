@@ -167,40 +167,45 @@ __global__ __launch_bounds__(256, 2) void k_mmq_fast(FastArgs A) {
         return bop;
     };
 
-    // Software pipeline over the blocks: while the fold of block s runs on the VALU (32 packed FMAs), the two MFMAs of block s + 1 run on
-    // the matrix pipe. A block in flight = its integer sums (two 32 x 32 tiles) and the two weight scales; its token scales are read from
-    // LDS right before its fold.
+    // Software pipeline over the blocks of a chunk, three stages deep: while the fold of block s runs on the VALU (32 packed FMAs), the two
+    // MFMAs of block s + 1 run on the matrix pipe and the LDS reads of block s + 2 (operands) and s + 1 (token scales) are in flight -- every
+    // LDS read is issued a stage before its use (with one wave per SIMD a read that is waited for right away costs its whole latency: the
+    // first version of this kernel spent 1100 cycles per block on 50 instructions). A block in flight = its integer sums (two 32 x 32 tiles)
+    // and the two weight scales.
+    struct Ops { v4i aop; int4 braw[2]; unsigned scw[2], qhw[2]; };
     struct Blk { v16i acc[2]; float dw[2], mw[2]; };
-    auto start = [&](Blk & q, unsigned off) {                         // operands of the block at LDS offset `off` -> MFMAs under way
+    struct Sc { v2f dd[8], aux[8]; };
+    auto ld_ops = [&](Ops & o, unsigned off) {
         const unsigned char * S = lds + off;
-        const v4i aop = *reinterpret_cast<const v4i *>(S + a_aop);
-        int4 braw[2]; unsigned scw[2], qhw[2] = {0u, 0u};
+        o.aop = *reinterpret_cast<const v4i *>(S + a_aop);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            braw[i] = *reinterpret_cast<const int4 *>(S + a_b[i]);
-            scw[i] = *reinterpret_cast<const unsigned *>(S + a_sc[i]);
-            if constexpr (M::QH) qhw[i] = *reinterpret_cast<const unsigned *>(S + a_sc[i] + (M::OFF_WQH - M::OFF_WSC));
-        }
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            q.dw[i] = h2f_bits((uint16_t) (scw[i] & 0xFFFFu));
-            q.mw[i] = M::HM ? h2f_bits((uint16_t) (scw[i] >> 16)) : 0.0f;
-            q.acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop, unpack(braw[i], qhw[i]), magic, 0, 0, 0);
+            o.braw[i] = *reinterpret_cast<const int4 *>(S + a_b[i]);
+            o.scw[i] = *reinterpret_cast<const unsigned *>(S + a_sc[i]);
+            if constexpr (M::QH) o.qhw[i] = *reinterpret_cast<const unsigned *>(S + a_sc[i] + (M::OFF_WQH - M::OFF_WSC)); else o.qhw[i] = 0u;
         }
     };
-    auto read_scales = [&](v2f (&dd)[8], v2f (&aux)[8], unsigned off) {
+    auto ld_sc = [&](Sc & c, unsigned off) {
         const unsigned char * S = lds + off;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const float4 dx4 = *reinterpret_cast<const float4 *>(S + a_xd + 32 * g);
-            dd[2 * g] = (v2f){dx4.x, dx4.y}; dd[2 * g + 1] = (v2f){dx4.z, dx4.w};
+            c.dd[2 * g] = (v2f){dx4.x, dx4.y}; c.dd[2 * g + 1] = (v2f){dx4.z, dx4.w};
             if constexpr (M::HM || M::XO) {
                 const float4 a4 = *reinterpret_cast<const float4 *>(S + a_xd + ((M::HM ? M::OFF_XS : M::OFF_XO) - M::OFF_XD) + 32 * g);
-                aux[2 * g] = (v2f){a4.x, a4.y}; aux[2 * g + 1] = (v2f){a4.z, a4.w};
+                c.aux[2 * g] = (v2f){a4.x, a4.y}; c.aux[2 * g + 1] = (v2f){a4.z, a4.w};
             }
         }
     };
-    auto fold = [&](const Blk & q, const v2f (&dd)[8], const v2f (&aux)[8]) {
+    auto launch = [&](Blk & q, const Ops & o) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            q.dw[i] = h2f_bits((uint16_t) (o.scw[i] & 0xFFFFu));
+            q.mw[i] = M::HM ? h2f_bits((uint16_t) (o.scw[i] >> 16)) : 0.0f;
+            q.acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.aop, unpack(o.braw[i], o.qhw[i]), magic, 0, 0, 0);
+        }
+    };
+    auto fold = [&](const Blk & q, const Sc & c) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const v2f dw2 = {q.dw[i], q.dw[i]};
@@ -210,10 +215,10 @@ __global__ __launch_bounds__(256, 2) void k_mmq_fast(FastArgs A) {
             for (int j = 0; j < 8; j++) {
                 const v2f raw = {__int_as_float(q.acc[i][2 * j]), __int_as_float(q.acc[i][2 * j + 1])};
                 v2f g;
-                if constexpr (M::XO) { const v2f sf = (raw - (v2f){MAGIC_F, MAGIC_F}) - aux[j]; g = sf * dw2; }      // (exact integers below 2^24, then one rounding)
+                if constexpr (M::XO) { const v2f sf = (raw - (v2f){MAGIC_F, MAGIC_F}) - c.aux[j]; g = sf * dw2; }    // (exact integers below 2^24, then one rounding)
                 else g = __builtin_elementwise_fma(raw, dw2, cdw2);                                                  // = d_w * isum', one rounding
-                cur[i][j] = __builtin_elementwise_fma(g, dd[j], cur[i][j]);
-                if constexpr (M::HM) cur[i][j] = __builtin_elementwise_fma((v2f){q.mw[i], q.mw[i]}, aux[j], cur[i][j]);
+                cur[i][j] = __builtin_elementwise_fma(g, c.dd[j], cur[i][j]);
+                if constexpr (M::HM) cur[i][j] = __builtin_elementwise_fma((v2f){q.mw[i], q.mw[i]}, c.aux[j], cur[i][j]);
             }
         }
     };
@@ -221,32 +226,40 @@ __global__ __launch_bounds__(256, 2) void k_mmq_fast(FastArgs A) {
     const int n_chunks = nb / G::CH;
     issue(0);
     Blk qa, qb;
+    Ops oa, ob;
+    Sc sa, sb;
+#define PF_PIN() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll 1
     for (int k = 0; k < n_chunks; k++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's share of chunk k has landed ...
         __syncthreads();                                             // ... everybody's has, and nobody still reads the buffer chunk k + 1 goes into
         if (k + 1 < n_chunks) issue(k + 1);
         const unsigned cb = (unsigned) (G::CH * (k & 1)) * M::SLOT;
-        start(qa, cb);
+        ld_ops(oa, cb); ld_sc(sa, cb); ld_ops(ob, cb + M::SLOT);
+        PF_PIN();
+        launch(qa, oa);
+        PF_PIN();
 #pragma unroll
         for (int s = 0; s < G::CH; s += 2) {
-            v2f dd[8], aux[8];
-            // block s in qa: start s + 1 into qb, fold s
-            read_scales(dd, aux, cb + (unsigned) s * M::SLOT);
-            __builtin_amdgcn_sched_barrier(0);
-            start(qb, cb + (unsigned) (s + 1) * M::SLOT);
-            __builtin_amdgcn_sched_barrier(0);
-            fold(qa, dd, aux);
-            __builtin_amdgcn_sched_barrier(0);
-            // block s + 1 in qb: start s + 2 into qa (not behind the chunk's last block: the next chunk starts behind its barrier), fold s + 1
-            read_scales(dd, aux, cb + (unsigned) (s + 1) * M::SLOT);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < G::CH) start(qa, cb + (unsigned) (s + 2) * M::SLOT);
-            __builtin_amdgcn_sched_barrier(0);
-            fold(qb, dd, aux);
-            __builtin_amdgcn_sched_barrier(0);
+            // block s: sums in qa, scales in sa; block s + 1: operands in ob
+            launch(qb, ob);
+            PF_PIN();
+            if (s + 2 < G::CH) ld_ops(oa, cb + (unsigned) (s + 2) * M::SLOT);
+            ld_sc(sb, cb + (unsigned) (s + 1) * M::SLOT);
+            PF_PIN();
+            fold(qa, sa);
+            PF_PIN();
+            // block s + 1: sums in qb, scales in sb; block s + 2: operands in oa
+            if (s + 2 < G::CH) launch(qa, oa);
+            PF_PIN();
+            if (s + 3 < G::CH) ld_ops(ob, cb + (unsigned) (s + 3) * M::SLOT);
+            if (s + 2 < G::CH) ld_sc(sa, cb + (unsigned) (s + 2) * M::SLOT);
+            PF_PIN();
+            fold(qb, sb);
+            PF_PIN();
         }
     }
+#undef PF_PIN
 
     // ---- epilogue: row n = column of the tile (lane), tokens along the registers ----
 #pragma unroll
@@ -268,9 +281,12 @@ __global__ __launch_bounds__(256, 2) void k_mmq_fast(FastArgs A) {
 
 std::atomic<unsigned long long> g_mmq_fast_launches{0};   // launches of k_mmq_fast by this process (tests assert the arm they mean ran)
 
-static bool seq_q_fast() {   // (read per call: the test suite runs both arms in one process)
+// RWKV_MI_SEQ_Q = fast (default) | exact | force (tests: the plain-order kernel also on shapes with too few tiles to be worth it). Read per
+// call: the test suite runs the arms in one process.
+static int seq_q_arm() {
     const char * e = getenv("RWKV_MI_SEQ_Q");
-    return !(e && e[0] == 'e');
+    if (e && e[0] == 'e') return 0;
+    return (e && e[0] == 'f' && e[1] == 'o') ? 2 : 1;
 }
 
 static std::mutex g_fast_mu;
@@ -315,10 +331,11 @@ static bool launch_fast_t(int n, const DevTensor * const * Ws, const TileAct * x
 // false: not this kernel's shape (rows of fewer than 8 blocks or not a multiple of 8; too few output tiles to fill the chip without
 // cutting K -- the exact kernel cuts its walk for those) or the exact arm is asked for
 bool launch_mmq_fast(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy, hipStream_t st) {
-    if (!seq_q_fast() || n < 1 || n > MMQ_BATCH) return false;
+    const int arm = seq_q_arm();
+    if (arm == 0 || n < 1 || n > MMQ_BATCH) return false;
     const int64_t N = Ws[0]->rows(), K = Ws[0]->cols();
     const int64_t nb = K / 32, tiles = (int64_t) n * ((N + 127) / 128) * ((T + 63) / 64);
-    if (K % 256 != 0 || nb < 16 || N < 128 || tiles < 128) return false;
+    if (K % 256 != 0 || nb < 16 || N < 128 || (tiles < 128 && arm != 2)) return false;
     switch (Ws[0]->type) {
         case T_Q4_0: return launch_fast_t<T_Q4_0>(n, Ws, xs, ys, epis, T, ldy, st);
         case T_Q4_1: return launch_fast_t<T_Q4_1>(n, Ws, xs, ys, epis, T, ldy, st);

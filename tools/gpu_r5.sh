@@ -46,7 +46,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline',{}); p=d.get('parity',{})
 print('$1', round(d['value'],1), d['unit'], round(d['ms_per_step'],3), 'ms/pass', 'gemm TOP/s', round(r.get('achieved',0),1), 'avg_us', round(r.get('avg_launch_us',0),2), 'launches', r.get('launches'), 'parity', p.get('equal'), p.get('exact_arm_bit_identical'), json.dumps(p.get('timed_arm',{}))[:400], flush=True)
 "; }
-  timeout 400 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 25 --parity-tokens 1024 > $O/prefill_1b6_q4_0.json 2> $O/prefill_1b6.err; tail -1 $O/prefill_1b6_q4_0.json | pline 1b6
+  timeout 400 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 25 --parity-tokens ${PARITY:-128} > $O/prefill_1b6_q4_0.json 2> $O/prefill_1b6.err; tail -1 $O/prefill_1b6_q4_0.json | pline 1b6
   RWKV_MI_SEQ_Q=exact timeout 400 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 0 --parity-tokens 0 > $O/prefill_1b6_q4_0_exact.json 2>> $O/prefill_1b6.err; tail -1 $O/prefill_1b6_q4_0_exact.json | pline 1b6-exact
   timeout 400 python bench.py --config rwkv7-2b9 --dtype Q5_1 --mode prefill --steps 3 --warmup 1 --cpu-seconds 8 --parity-tokens 128 > $O/prefill_7v_2b9_q5_1.json 2> $O/prefill_2b9.err; tail -1 $O/prefill_7v_2b9_q5_1.json | pline 2b9
   ;;
