@@ -26,7 +26,14 @@ namespace rwkvmi {
 
 template <int FMT> struct MG {
     typedef MF<FMT> M;                       // the per-step slot layout (128 rows, two token tiles) is the exact kernel's
-    static constexpr int NT = 256, CH = 8, NBUF = 2;
+// (measured, 1.6B Q4_0, 1024-token pass, same box: two buffers of 8 blocks = 78 KB, two workgroups per CU: 86.1 k tokens/s; three buffers,
+//  one workgroup per CU: 76.0 k -- the second workgroup hides more than the deeper prefetch; the exact kernel: 73.2 k)
+#ifndef PFF_NBUF
+#define PFF_NBUF 2
+#endif
+    static constexpr int NT = 256, CH = 8;
+    static constexpr int NBUF = PFF_NBUF * CH * M::SLOT <= 160 * 1024 ? PFF_NBUF : 2;   // chunk buffers: chunk k + NBUF - 1 is issued when chunk k starts (Q8_0: two fit)
+    static constexpr int DMA_PER_CHUNK = 2 * M::n_dma(0);                   // DMA instructions of one wave per chunk (its two steps): the vmcnt share
     static constexpr int LDS_BYTES = NBUF * CH * M::SLOT;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");   // (Q4_0 / Q4_1: 78 - 82 KB, two workgroups per CU; Q5 / Q8_0: one)
 };
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq_fast(FastArgs A) {
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
         const int64_t b = (int64_t) k * G::CH + st;       // (nb is a multiple of CH: every step of every chunk is a block of the row)
-        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned) ((G::CH * (k & 1) + st) * M::SLOT));
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned) ((G::CH * (k % G::NBUF) + st) * M::SLOT));
 #pragma unroll
         for (int r = 0; r < M::NR; r++) {
             const unsigned dst = dst0 + r * 1024;
@@ -224,17 +231,20 @@ __global__ __launch_bounds__(256, 2) void k_mmq_fast(FastArgs A) {
     };
 
     const int n_chunks = nb / G::CH;
-    issue(0);
+#pragma unroll
+    for (int k0 = 0; k0 < G::NBUF - 1; k0++) if (k0 < n_chunks) issue(k0);
     Blk qa, qb;
     Ops oa, ob;
     Sc sa, sb;
 #define PF_PIN() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll 1
     for (int k = 0; k < n_chunks; k++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's share of chunk k has landed ...
-        __syncthreads();                                             // ... everybody's has, and nobody still reads the buffer chunk k + 1 goes into
-        if (k + 1 < n_chunks) issue(k + 1);
-        const unsigned cb = (unsigned) (G::CH * (k & 1)) * M::SLOT;
+        // this wave's share of chunk k has landed when only the younger chunks' DMAs are outstanding (vmcnt counts this wave's, in order) ...
+        if (G::NBUF > 2 && k + G::NBUF - 2 < n_chunks) wait_vm<G::DMA_PER_CHUNK * (G::NBUF - 2)>();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                             // ... everybody's has, and nobody still reads the buffer the next issue goes into
+        if (k + G::NBUF - 1 < n_chunks) issue(k + G::NBUF - 1);
+        const unsigned cb = (unsigned) (G::CH * (k % G::NBUF)) * M::SLOT;
         ld_ops(oa, cb); ld_sc(sa, cb); ld_ops(ob, cb + M::SLOT);
         PF_PIN();
         launch(qa, oa);

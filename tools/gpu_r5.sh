@@ -39,8 +39,13 @@ p47trace)
     f=$(find /tmp/prof_$n -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f $O/decode_${n}_kernel_stats.csv; head -8 $f | cut -c1-160; fi
   done
   ;;
+prefillbench)
+  for a in fast exact; do RWKV_MI_SEQ_Q=$a timeout 300 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 0 --parity-tokens 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$a', round(d['value'],1), 'tok/s', round(d['ms_per_step'],3), 'ms', 'gemm avg us', round(r['avg_launch_us'],2), 'TOP/s', round(r['achieved'],1), flush=True)"; done
+  ;;
 prefill)
-  timeout 900 python -m pytest tests/test_gpu_prefill_fast.py -m gpu -q -x -p no:cacheprovider "$@" > $O/pytest_fast_full.txt 2>&1; tail -15 $O/pytest_fast_full.txt | grep -v "^$" > $O/pytest_fast.txt; cat $O/pytest_fast.txt
+  timeout ${PYT:-240} python -m pytest tests/test_gpu_prefill_fast.py -m gpu -q -x -p no:cacheprovider --durations=5 "$@" > $O/pytest_fast_full.txt 2>&1; tail -15 $O/pytest_fast_full.txt | grep -v "^$" > $O/pytest_fast.txt; cat $O/pytest_fast.txt
   pline() { python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline',{}); p=d.get('parity',{})
