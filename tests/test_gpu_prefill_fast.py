@@ -6,7 +6,7 @@ memcmp is promised and tested for FP32 files; quantised formats are validated ag
 operands and exact integer block sums and changes only the order (and one association) of the f32 additions, so it is compared with the
 oracle within bounds that are stated here:
 
-  kernel level   |y - oracle| <= 1.5 * (2 nb + 8) * 2^-24 * A,  A = sum_k |x_q[k]| |w_deq[k]|: the rounding-error bound of two f32 sums of nb
+  kernel level   |y - oracle| <= 1.5 * (2 nb + 8) * 2^-24 * A,  A = |x_q|_2 |w_deq|_2 >= sum_k |x_q[k]| |w_deq[k]|: the rounding-error bound of two f32 sums of nb
                  block terms (the oracle's tree and this kernel's chain) around the same real number. A wrong tile edge, a swapped nibble
                  or a missing block is worth >= 1e-2 A.
   model level    ONE-layer slices of the BASELINE geometries at full and ragged lengths: logits and state within 1e-4 * (1 + max |oracle|).
@@ -29,6 +29,10 @@ QFORMATS = ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0"]
 
 @pytest.fixture(autouse=True)
 def fast_arm():
+    # the oracle on its AVX row kernels (bit-identical to its scalar form) and on a bounded thread count: with one OpenMP thread per hardware
+    # thread of the GPU box a 512 x 256 x 128 product took 16 s inside orc_mul_mat
+    O.lib().orc_set_fast(1)
+    O.lib().orc_set_threads(min(16, os.cpu_count() or 1))
     old = os.environ.get("RWKV_MI_SEQ_Q")
     os.environ["RWKV_MI_SEQ_Q"] = "fast"
     yield
@@ -75,7 +79,9 @@ def test_plain_order_gemm_against_the_oracle(fmt, K, N, T, arm):
     for i in range(T):
         q, d, _ = O.quantize_act(x[i])
         xq[i] = q.astype(np.float64) * np.repeat(d.astype(np.float64), 32)
-    A = np.abs(xq) @ np.abs(wd).T
+    # A = sum_k |x_q[k]| |w_deq[k]| is bounded by the product of the two 2-norms (Cauchy-Schwarz; 1.6 x looser on these operands): an outer
+    # product of norms instead of a float64 GEMM
+    A = np.sqrt((xq * xq).sum(axis=1))[:, None] * np.sqrt((wd * wd).sum(axis=1))[None, :]
     nb = K // 32
     bound = 1.5 * (2 * nb + 8) * 2.0 ** -24 * A + 1e-30
     ratio = float((np.abs(y.astype(np.float64) - ref.astype(np.float64)) / bound).max())
