@@ -828,6 +828,9 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
 // that the ~100 short launches of a decode step cost one graph launch on the host.
 bool forward_decode(rwkv_context * ctx, bool want_logits) {
     if (!ctx->use_graph) return forward(ctx, 1, want_logits);
+    // one launch per token (persist_v47.hip with embedding, head and argmax inside it): a direct launch from a busy stream costs the host
+    // 3 - 5 us, the replay of a one-node graph 10 - 16 (guide row graph-replay-floor) -- at 250 us per token of the 169M that is the gap
+    if (ctx->mega && ctx->model->has_embed && ctx->model->has_head && mega_v6_folds_embed(ctx->mega) && mega_v6_folds_argmax(ctx->mega)) return forward(ctx, 1, want_logits);
     if (!ensure_scratch(ctx, 1)) return false;
     hipGraphExec_t & ge = ctx->graph_exec[ctx->cur][want_logits ? 1 : 0];
     if (!ge) {

@@ -425,6 +425,7 @@ struct K47 {
         const M6Arena ar{p.arena};
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         unsigned keys_done = 0;
+        __builtin_amdgcn_s_setprio(2);   // every hand-over of the workgroup goes through this wave: it issues ahead of the two workers on its SIMD
         for (int li = p.l0; li < p.l1; li++) {
             const P47Layer & L = p.layers[li];
             const unsigned tagL = base + (unsigned) (li - p.l0) * 8u;
