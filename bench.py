@@ -66,25 +66,15 @@ def pmc_traffic(path_id, args, kind=0):
 
 
 def prefill_source_stamp():
-    """sha256 over the sources of the sequence-mode GEMM: a matrix-pipe PMC quote is only valid for the build it was taken on.
-    Covers kdev.h and prefill.hip WITHOUT the section of the WKV-7 sequence kernel (from its header comment to its launcher): that kernel
-    shares the file but no code with k_mmq_mfma, and the end of round 4 changed it after the quote was taken -- the rest of the file is
-    byte-identical to the build the counters ran on (full-file hash of that build: e5ff39fc245bd9bc, commit bc46ba6)."""
+    """sha256 over the COMPLETE sources of the sequence-mode GEMMs (prefill_fast.hip: the timed default; prefill.hip: the exact arm; their shared
+    header; kdev.h): a matrix-pipe PMC quote is only valid for the build it was taken on."""
     import hashlib
     h = hashlib.sha256()
-    try:
-        lines = open(os.path.join(ROOT, "rwkv.cpp_amd/csrc/prefill.hip"), "rb").read().split(b"\n")
-        a = next((i for i, l in enumerate(lines) if l.startswith(b"// WKV-7 over a sequence")), None)
-        b = next((i for i, l in enumerate(lines) if l.startswith(b"bool launch_wkv7_seq")), None)
-        if a is not None and b is not None and a < b:
-            lines = lines[:a] + lines[b:]
-        h.update(b"\n".join(lines))
-    except OSError:
-        h.update(b"missing:prefill.hip")
-    try:
-        h.update(open(os.path.join(ROOT, "rwkv.cpp_amd/csrc/kdev.h"), "rb").read())
-    except OSError:
-        h.update(b"missing:kdev.h")
+    for f in ("rwkv.cpp_amd/csrc/prefill_fast.hip", "rwkv.cpp_amd/csrc/prefill.hip", "rwkv.cpp_amd/csrc/prefill_mm.h", "rwkv.cpp_amd/csrc/kdev.h"):
+        try:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        except OSError:
+            h.update(b"missing:" + f.encode())
     return h.hexdigest()[:16]
 
 
