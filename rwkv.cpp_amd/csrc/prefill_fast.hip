@@ -42,6 +42,7 @@ struct FastArgs {
     PfW w[MMQ_BATCH]; PfX x[MMQ_BATCH]; float * y[MMQ_BATCH]; Epi epi[MMQ_BATCH];
     int64_t N, T, ldy;
     int nb, RT, C;
+    int dbg;   // RWKV_MI_PFF_DBG (timing-only experiments, results INVALID): 1 no MFMAs / folds, 2 no staging behind the first chunks, 4 no chunk barrier
 };
 
 template <int FMT>
@@ -242,8 +243,9 @@ __global__ __launch_bounds__(256, 2) void k_mmq_fast(FastArgs A) {
         // this wave's share of chunk k has landed when only the younger chunks' DMAs are outstanding (vmcnt counts this wave's, in order) ...
         if (G::NBUF > 2 && k + G::NBUF - 2 < n_chunks) wait_vm<G::DMA_PER_CHUNK * (G::NBUF - 2)>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                             // ... everybody's has, and nobody still reads the buffer the next issue goes into
-        if (k + G::NBUF - 1 < n_chunks) issue(k + G::NBUF - 1);
+        if (!(A.dbg & 4)) __syncthreads();                           // ... everybody's has, and nobody still reads the buffer the next issue goes into
+        if (k + G::NBUF - 1 < n_chunks && !((A.dbg & 2) && k >= 1)) issue(k + G::NBUF - 1);
+        if (A.dbg & 1) continue;
         const unsigned cb = (unsigned) (G::CH * (k % G::NBUF)) * M::SLOT;
         ld_ops(oa, cb); ld_sc(sa, cb); ld_ops(ob, cb + M::SLOT);
         PF_PIN();
@@ -331,6 +333,7 @@ static bool launch_fast_t(int n, const DevTensor * const * Ws, const TileAct * x
     }
     const int RT = (int) ((N + 31) / 32), RP = (RT + 3) / 4, C = (int) ((T + 63) / 64);
     A.N = N; A.T = T; A.ldy = ldy; A.nb = nb; A.RT = RT; A.C = C;
+    { const char * e = getenv("RWKV_MI_PFF_DBG"); A.dbg = e ? atoi(e) : 0; }
     mmq_fast_prepare_current_device();
     const dim3 grid((unsigned) (RP < 8 ? RP * C : ((RP + 7) / 8) * 8 * C), (unsigned) n, 1);
     hipLaunchKernelGGL((k_mmq_fast<FMT>), grid, dim3(MG<FMT>::NT), (size_t) MG<FMT>::LDS_BYTES, st, A);

@@ -39,6 +39,11 @@ p47trace)
     f=$(find /tmp/prof_$n -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f $O/decode_${n}_kernel_stats.csv; head -8 $f | cut -c1-160; fi
   done
   ;;
+pffdbg)
+  for d in 0 1 2 3 4 7; do RWKV_MI_PFF_DBG=$d timeout 200 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 4 --warmup 1 --cpu-seconds 0 --parity-tokens 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('dbg $d', round(d['value'],1), 'tok/s', round(d['ms_per_step'],3), 'ms', 'gemm avg us', round(r['avg_launch_us'],2), flush=True)"; done
+  ;;
 prefillbench)
   for a in fast exact; do RWKV_MI_SEQ_Q=$a timeout 300 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 0 --parity-tokens 0 2>/dev/null | python -c "
 import json,sys
