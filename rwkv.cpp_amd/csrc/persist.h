@@ -61,6 +61,75 @@ __device__ __forceinline__ bool poll_backoff(Poll & pl, unsigned spin) {
     return pl.dead;
 }
 
+// A long wait (tens of microseconds: a workgroup that has nothing to do until a far-away phase) on ONE unit, every lane of the wave reading the
+// same address (one request per attempt) with SL x 64 clocks of sleep between attempts -- the full poll that follows it finds the data
+// there or nearly there. A full-width poll spinning for that long is N x 1 KiB per attempt and wave against the very lines the running
+// phases hand over through.
+template <int SL>
+__device__ __forceinline__ void calm_wait(Poll & pl, xrsrc xr, int unit, unsigned tag) {
+    for (unsigned spin = 0;; spin++) {
+        asm volatile("" ::: "memory");
+        const v4u v = tg_load(xr, unit);   // (the lanes may watch different units: all of them)
+        if (__all(tg_ok(v, tag)) || pl.dead) break;
+        if ((spin & 63u) == 63u) {
+            if (__hip_atomic_load(pl.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) pl.dead = true;
+            else if (spin > 3000000u) { __hip_atomic_store(pl.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pl.dead = true; }
+        }
+        __builtin_amdgcn_s_sleep(SL);
+    }
+}
+
+// The watch in front of a hand-over's sweep, where the wait is on the layer's critical path: FOUR reads of the unit's tag word in flight,
+// issued SL x 64 clocks apart and checked as the oldest lands (reads of a wave return in order) -- the unit is sampled every SL x 64
+// clocks instead of once per memory round trip (~0.6 us), at 64 bytes per read. All four land in ONE register: a younger read that
+// overtakes the check only shows a fresher tag. The loop is one block of assembly: written with the builtins the compiler waits for ALL
+// reads (vmcnt(0)) in front of every check -- the one-deep watch again -- and a tied operand around a loop gets copied while in flight.
+// The register must stay reserved until the reads still in flight when the watch ends have landed: the caller keeps the Watch4 alive
+// across its sweep (whose own reads are younger and waited for) and hands it to watch_done() behind it; tools/check_watch_regs.py reads
+// the build's assembly and fails when anything writes the register between the two markers.
+typedef unsigned v4s __attribute__((ext_vector_type(4)));
+struct Watch4 { unsigned v; };
+template <int SL>
+__device__ __forceinline__ void watch4(Watch4 & w, Poll & pl, void * base, unsigned bytes, int unit, unsigned tag) {
+    const unsigned long long ba = (unsigned long long) base;
+    v4s rs;
+    rs.x = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) ba);
+    rs.y = (unsigned) __builtin_amdgcn_readfirstlane((int) ((unsigned) (ba >> 32) & 0xFFFFu));
+    rs.z = (unsigned) __builtin_amdgcn_readfirstlane((int) bytes);
+    rs.w = 0x00020000u;
+    const int off = unit * 16 + 12;
+    const unsigned want = (unsigned) __builtin_amdgcn_readfirstlane((int) (tag & 0xFFFFu));
+    unsigned v = 0u, t, left;
+    for (unsigned round = 0;; round++) {
+        asm volatile("s_waitcnt vmcnt(0)\n\t"
+                     "buffer_load_dword %0, %3, %4, 0 offen sc1\n\ts_sleep %6\n\t"
+                     "buffer_load_dword %0, %3, %4, 0 offen sc1\n\ts_sleep %6\n\t"
+                     "buffer_load_dword %0, %3, %4, 0 offen sc1\n\ts_sleep %6\n\t"
+                     "buffer_load_dword %0, %3, %4, 0 offen sc1\n\ts_sleep %6\n\t"
+                     "s_movk_i32 %2, 0x100\n"
+                     "1:\n\t"
+                     "s_waitcnt vmcnt(3)\n\t"
+                     "v_and_b32 %1, 0xffff, %0\n\t"
+                     "v_cmp_eq_u32 vcc, %5, %1\n\t"
+                     "s_cmp_eq_u64 vcc, exec\n\t"            // (every lane: the lanes may watch different units)
+                     "s_cbranch_scc1 2f\n\t"
+                     "buffer_load_dword %0, %3, %4, 0 offen sc1\n\t"
+                     "s_sleep %6\n\t"
+                     "s_sub_u32 %2, %2, 1\n\t"
+                     "s_cmp_lg_u32 %2, 0\n\t"
+                     "s_cbranch_scc1 1b\n"
+                     "2:\n\t"
+                     "; WATCH4_BEGIN %0"
+                     : "=&v"(v), "=&v"(t), "=&s"(left) : "v"(off), "s"(rs), "s"(want), "n"(SL) : "vcc", "scc", "memory");
+        if (left != 0u || pl.dead) break;
+        if (__hip_atomic_load(pl.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) pl.dead = true;
+        else if (round > 30000u) { __hip_atomic_store(pl.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pl.dead = true; }
+        if (pl.dead) break;
+    }
+    w.v = v;
+}
+__device__ __forceinline__ void watch_done(Watch4 & w) { asm volatile("; WATCH4_END %0" : : "v"(w.v) : "memory"); }
+
 // Core: N units per lane given by address; all loads of an attempt are issued together; an attempt succeeds for the wave
 // when every lane saw the expected tag on all of its valid units (invalid slots carry a harmless duplicate address).
 template <int N>

@@ -45,6 +45,24 @@ struct P47Layer {
     int pad_;
 };
 
+// A layer's table entry read through the scalar cache (constant address space: the table is written before the launch and a uniform address
+// then makes s_load instructions). As plain global reads the fields are VECTOR reads -- the kernel writes memory, so nothing proves the
+// table invariant -- and a field read between two batches of weights waits, in order, for every weight issued before it.
+struct KLayer {
+    unsigned long long a;
+    __device__ __forceinline__ long long q(size_t off) const { return *(const __attribute__((address_space(4))) long long *) (a + off); }
+    __device__ __forceinline__ M6Off o(size_t off) const { return M6Off{q(off), q(off + 8), q(off + 16)}; }
+    __device__ __forceinline__ int i(size_t off) const { return *(const __attribute__((address_space(4))) int *) (a + off); }
+    template <int N> __device__ __forceinline__ void qs(size_t off, long long (&out)[N]) const {
+#pragma unroll
+        for (int i = 0; i < N; i++) out[i] = q(off + 8 * (size_t) i);
+    }
+};
+#define KQ(L, f) (L).q(offsetof(P47Layer, f))
+#define KO(L, f) (L).o(offsetof(P47Layer, f))
+#define KI(L, f) (L).i(offsetof(P47Layer, f))
+#define KLAYER(p, li) KLayer{(unsigned long long) ((p).layers + __builtin_amdgcn_readfirstlane(li))}
+
 struct P47 {
     const P47Layer * layers; int l0, l1;
     const unsigned char * arena;
@@ -58,7 +76,25 @@ struct P47 {
     const uint32_t * tok; const void * emb; int emb_f16; long long ln0_w, ln0_b;
     // ln_out + head + argmax inside the launch (last stage, rwkv_graph.inc:704-708): logits != nullptr; every workgroup of the grid takes rows
     float * logits; uint32_t * next_tok; const void * head; long long lnout_w, lnout_b; int V; int u_am; int n_spare;
+    int calm;                                        // long waits watch ONE unit before the full-width poll -- bit 0: spare / head workgroups for the last layer
+                                                     // (the polling waves of the layers: P47_WATCH, compile time)
 };
+
+#ifndef P47_WATCH_SL
+#define P47_WATCH_SL 5
+#endif
+#ifndef P47_WATCH_SPREAD
+#define P47_WATCH_SPREAD 8
+#endif
+#ifndef P47_EARLY
+#define P47_EARLY 0
+#endif
+#ifndef P47_PARK
+#define P47_PARK 1
+#endif
+#ifndef P47_WATCH
+#define P47_WATCH 2
+#endif
 
 enum { S47_A = 0, S47_Y = 1, S47_XATT = 2, S47_KQ = 3, S47_XFFN = 4, S47_AM = 5, S47_IN = 6 };
 
@@ -132,7 +168,10 @@ __device__ __forceinline__ void rows_sum(const Batch<FMT, R, U> & bt, int nbk, i
     for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
 }
 
-struct L47 { size_t x, sc, q, lr, yq, kq, out, fl, hx, am, lr1, ch, hv, st, total; };
+struct L47 { size_t x, sc, q, lr, yq, kq, out, fl, hx, am, lr1, ch, hv, st, park, total; };
+// rows of the head parked in LDS by the workgroups the layers do not use (K47::PARK): one pass (8 rows) per wave, lane-major like the register buffers
+__host__ __device__ constexpr int l47_ch(int D) { return D / 32 <= 24 ? 24 : 16; }
+__host__ __device__ constexpr size_t l47_park_bytes(int D) { return D <= 768 ? (size_t) 9 * l47_ch(D) * 64 * 8 : 0; }
 __host__ __device__ inline L47 l47_lds(int D, bool v7) {
     L47 o; size_t p = 0;
     auto take = [&](size_t n) { const size_t r = p; p += m6_round16(n); return r; };
@@ -145,7 +184,8 @@ __host__ __device__ inline L47 l47_lds(int D, bool v7) {
     size_t h = 0;
     auto takeh = [&](size_t n) { const size_t r = h; h += m6_round16(n); return r; };
     o.lr1 = takeh(2048 * 4); o.ch = takeh(4 * 64 * 4); o.hv = takeh(5 * 64 * 4); o.st = takeh(64 * 68 * 4);
-    o.total = p > h ? p : h;
+    o.park = p > h ? p : h;
+    o.total = o.park + l47_park_bytes(D);
     return o;
 }
 
@@ -168,11 +208,16 @@ struct K47 {
     static constexpr int DU = (3 * nb + 63) / 64, KQU = (3 * nbF + 63) / 64;
     static constexpr int STEPS = D / 32;
     static constexpr int NIA = V7 ? 6 : 3, NIF = V7 ? 1 : 2;
+    // Short rows (D <= 768: a layer's weights are 66 registers per lane at Q5_1): every batch of weights is issued a whole phase earlier than it
+    // is needed -- behind B1 what the phases after the y hand-over read, behind B4 the value rows and the next layer's r / k / v rows -- so no
+    // read of the workers is in flight in front of a hand-over's sweep on the same CU (the sweeps behind a batch took 1.7 - 2.0 us after the
+    // last store, the one with nothing in front of it 1.06). Long rows keep the late issue: 168 registers hold one phase's batch, not two.
+    static constexpr bool EARLY = P47_EARLY && D <= 768;
     static_assert(D % 256 == 0 && GK % GPB == 0 && NR * 8 * GPB == D && NBLK <= 256 && NU <= 32 && KQU <= 32, "geometry");
 
     struct Lds {
         float * x; float * sc; unsigned char * q[3]; float * lr[4]; unsigned char * yq; unsigned char * kq; float * out; unsigned * fl;
-        float * lr1; float * ch; float * hv; float * st; float * hx; int * am;
+        float * lr1; float * ch; float * hv; float * st; float * hx; int * am; unsigned char * park;
     };
     static __device__ __forceinline__ Lds carve(unsigned char * smem) {
         const L47 lo = l47_lds(D, V7);
@@ -182,12 +227,39 @@ struct K47 {
         for (int i = 0; i < 4; i++) l.lr[i] = reinterpret_cast<float *>(smem + lo.lr) + (V7 ? i * D : 0);
         l.yq = smem + lo.yq; l.kq = smem + lo.kq; l.out = reinterpret_cast<float *>(smem + lo.out); l.fl = reinterpret_cast<unsigned *>(smem + lo.fl);
         l.lr1 = reinterpret_cast<float *>(smem + lo.lr1); l.ch = reinterpret_cast<float *>(smem + lo.ch); l.hv = reinterpret_cast<float *>(smem + lo.hv); l.st = reinterpret_cast<float *>(smem + lo.st);
-        l.hx = reinterpret_cast<float *>(smem + lo.hx); l.am = reinterpret_cast<int *>(smem + lo.am);
+        l.hx = reinterpret_cast<float *>(smem + lo.hx); l.am = reinterpret_cast<int *>(smem + lo.am); l.park = smem + lo.park;
         return l;
     }
 
     // rows of the D-row matrices owned by worker `own` of row workgroup `blk`: unit u = 8 blk + own is polled by lane u % 64 in slot u / 64
     static __device__ __forceinline__ int unit_of(int blk, int own) { return blk * 8 + own; }
+    // the unit a long wait watches: one of the row workgroup half the grid away (any unit does; not one of this workgroup's own)
+    // P47_WATCH_SPREAD = n (a power of two, 1 .. 64): the watch reads n units of n row workgroups spread over the grid, one per group of 64 / n
+    // lanes (n requests per read), and turns when ALL of them have -- the sweep behind it rarely comes back incomplete (an incomplete sweep
+    // costs a memory round trip). 1 -> 8: +6.4 % at 169M, +5.1 % at 2.9B.
+    static __device__ __forceinline__ int far_unit() {
+        constexpr int NSP = P47_WATCH_SPREAD < 1 ? 1 : P47_WATCH_SPREAD;
+        const int k = (int) (threadIdx.x & 63) / (64 / NSP);
+        return (((int) blockIdx.x + (2 * k + 1) * NR / (2 * NSP)) % NR) * 8 + (k & 7);
+    }
+    static __device__ __forceinline__ int far_head() {
+        constexpr int NSP = P47_WATCH_SPREAD < 1 ? 1 : P47_WATCH_SPREAD;
+        const int k = (int) (threadIdx.x & 63) / (64 / NSP);
+        return ((int) blockIdx.x + k * H / NSP) % H;
+    }
+    // in front of a hand-over's sweep on a row workgroup's polling wave (P47_WATCH: 0 none, 1 one read at a time, 2 four reads deep);
+    // watch_done(w) behind the sweep
+    static __device__ __forceinline__ void watch(Watch4 & w, const P47 & p, Poll & pl, xrsrc xr, int unit, unsigned tag) {
+#if P47_WATCH == 2
+        // (four deep where the layer is short: +1.4 % at 169M; at 2.9B, where the weight stream runs through two of the five waits, -0.6 %)
+        if constexpr (D <= 768) watch4<P47_WATCH_SL>(w, pl, p.xch, p.xch_bytes, unit, tag);
+        else { calm_wait<1>(pl, xr, unit, tag); w.v = 0u; }
+#elif P47_WATCH == 1
+        calm_wait<1>(pl, xr, unit, tag); w.v = 0u;
+#else
+        w.v = 0u;
+#endif
+    }
     static __device__ __forceinline__ int row0_of(int u) { return GPB == 1 ? u : (u & 63) + 128 * (u >> 6); }
 
     // -----------------------------------------------------------------------------------------------------------
@@ -427,7 +499,7 @@ struct K47 {
         unsigned keys_done = 0;
         __builtin_amdgcn_s_setprio(2);   // every hand-over of the workgroup goes through this wave: it issues ahead of the two workers on its SIMD
         for (int li = p.l0; li < p.l1; li++) {
-            const P47Layer & L = p.layers[li];
+            const KLayer L = KLAYER(p, li);
             const unsigned tagL = base + (unsigned) (li - p.l0) * 8u;
             T47(0);
             // (per-phase opaque copies of the lane id: poll and LDS addresses derived from it are recomputed where they are used instead of
@@ -437,7 +509,12 @@ struct K47 {
                 const int lane = opq(lane0);
                 float xs[NU][GPB];
                 if (li == p.l0 && p.tok) embed_ln0(p, l, lane, xs);
-                else poll_x(pl, xr, p.u_xffn, tagL - 8u + (li == p.l0 ? S47_IN : S47_XFFN), lane, xs);
+                else {
+                    Watch4 wt;
+                    watch(wt, p, pl, xr, p.u_xffn + far_unit(), tagL - 8u + (li == p.l0 ? S47_IN : S47_XFFN));
+                    poll_x(pl, xr, p.u_xffn, tagL - 8u + (li == p.l0 ? S47_IN : S47_XFFN), lane, xs);
+                    watch_done(wt);
+                }
                 T47(1);
                 ln_stats(l, lane, xs);
             }
@@ -452,13 +529,13 @@ struct K47 {
 #pragma unroll
                 for (int k = 0; k < MAXJ; k++) {
                     const int r0 = 4 * (blk + NR * k);                       // first row of the job in the concatenated lr1 vector
-                    jhas[k] = r0 < L.lr_n;
-                    int m = 0;
+                    jhas[k] = r0 < KI(L, lr_n);
+                    int m = 0, mb = 0;
 #pragma unroll
-                    for (int t = 1; t < 4; t++) if (r0 >= L.lbase[t]) m = t;
+                    for (int t = 1; t < 4; t++) { const int lb = L.i(offsetof(P47Layer, lbase) + 4 * t); if (r0 >= lb) { m = t; mb = lb; } }
                     jm[k] = jhas[k] ? m : 0;
-                    jrow[k] = jhas[k] ? r0 - L.lbase[m] + (lane >> 4) : 0;
-                    job_issue(jb[k], p.arena + L.lr1[jm[k]], jrow[k], lane);
+                    jrow[k] = jhas[k] ? r0 - mb + (lane >> 4) : 0;
+                    job_issue(jb[k], p.arena + L.q(offsetof(P47Layer, lr1) + 8 * (size_t) __builtin_amdgcn_readfirstlane(jm[k])), jrow[k], lane);
                 }
             }
             __syncthreads();   // B2: the workers' images
@@ -470,18 +547,24 @@ struct K47 {
                     float v = job_row(jb[k], l.lr[0] + jm[k] * D, lane);   // (one base + offset: an indexed pointer array would live in scratch as generic pointers)
                     if (jm[k] == 0) v = det_tanhf(v);
                     else if (jm[k] == 2) v = sigmoid_f(v);
-                    if (jhas[k] && (lane & 15) == 0) tg_store(xr, p.u_lr1 + L.lbase[jm[k]] + jrow[k], __float_as_uint(v), 0u, 0u, 0u, tagL + S47_A);
+                    if (jhas[k] && (lane & 15) == 0) tg_store(xr, p.u_lr1 + L.i(offsetof(P47Layer, lbase) + 4 * (size_t) __builtin_amdgcn_readfirstlane(jm[k])) + jrow[k], __float_as_uint(v), 0u, 0u, 0u, tagL + S47_A);
                 }
                 __builtin_amdgcn_s_setprio(0);
             }
             T47(3);
             // ---- C: y ----
             if constexpr (V7) {
+                Watch4 wt;
+                watch(wt, p, pl, xr, p.u_y + 6 * far_head(), tagL + S47_Y);   // (a head = two 32-blocks = six units)
                 stage_qvec<DU, 64>(pl, xr, p.u_y, D, tagL + S47_Y, l.yq, opq(lane0));
+                watch_done(wt);
             } else {
                 const int lane = opq(lane0);
                 float ys[NU][GPB];
+                Watch4 wt;
+                watch(wt, p, pl, xr, p.u_y + far_unit(), tagL + S47_Y);
                 poll_x(pl, xr, p.u_y, tagL + S47_Y, lane, ys);
+                watch_done(wt);
                 // Polled layout: lane l of slot s holds element l + 64 s. Quantising in that layout (one 32-block per half-wave and slot) costs
                 // two f32 divisions + a rounding per element on this one wave (2.3 us of the y hand-over at D = 768); through LDS (l.x is free
                 // between the time-mixing prologue and the next statistics) the vector comes back four consecutive elements per lane, eight
@@ -509,7 +592,10 @@ struct K47 {
             {
                 const int lane = opq(lane0);
                 float xs[NU][GPB];
+                Watch4 wt;
+                watch(wt, p, pl, xr, p.u_xatt + far_unit(), tagL + S47_XATT);
                 poll_x(pl, xr, p.u_xatt, tagL + S47_XATT, lane, xs);
+                watch_done(wt);
                 T47(5);
                 ln_stats(l, lane, xs);
             }
@@ -532,7 +618,10 @@ struct K47 {
             }
             T47(9);
             // ---- E: kq ----
+            Watch4 wt;
+            watch(wt, p, pl, xr, p.u_kq + 3 * GPB * (far_unit() >> 3), tagL + S47_KQ);
             stage_qvec<KQU, 64>(pl, xr, p.u_kq, F, tagL + S47_KQ, l.kq, opq(lane0));
+            watch_done(wt);
             T47(8);
             __syncthreads();   // B6
         }
@@ -576,17 +665,50 @@ struct K47 {
         auto issue_A = [&](int li, bool has) {
             __builtin_amdgcn_sched_barrier(0);
             const int tid = opq(tid0), lane = has ? (tid & 63) : 0, myrow = myrow_of(tid & 63);
-            const P47Layer & L = p.layers[li];
+            const KLayer L{(unsigned long long) (p.layers + __builtin_amdgcn_readfirstlane(li))};
             const float * sin_l = p.sin + (long long) (li - p.l0) * p.state_stride;
-            sa = pro_src<NIA>(ar, L.ln1_w, L.ln1_b, L.mix_a, sin_l + D);
+            long long mix[NIA];
+            L.qs<NIA>(offsetof(P47Layer, mix_a), mix);
+            sa = pro_src<NIA>(ar, KQ(L, ln1_w), KQ(L, ln1_b), mix, sin_l + D);
             pro_load<NIA>(pa, sa, (has && tid < NG4) ? tid : 0);
             if constexpr (!V7) {
                 st4[0] = sin_l[2 * D + myrow]; st4[1] = sin_l[3 * D + myrow]; st4[2] = sin_l[4 * D + myrow];
-                st4[3] = ar.f(L.tf)[myrow]; st4[4] = ar.f(L.td)[myrow];
+                st4[3] = ar.f(KQ(L, tf))[myrow]; st4[4] = ar.f(KQ(L, td))[myrow];
             }
-            rows_issue<FMT, GPB, UD>(wA[0], ar.w(L.wr), has ? e0 : 0, has ? 64 : 0, has ? nb : 1, lane);
-            rows_issue<FMT, GPB, UD>(wA[1], ar.w(L.wk), has ? e0 : 0, has ? 64 : 0, has ? nb : 1, lane);
-            rows_issue<FMT, GPB, UD>(wA[2], ar.w(L.wv), has ? e0 : 0, has ? 64 : 0, has ? nb : 1, lane);
+            rows_issue<FMT, GPB, UD>(wA[0], ar.w(KO(L, wr)), has ? e0 : 0, has ? 64 : 0, has ? nb : 1, lane);
+            rows_issue<FMT, GPB, UD>(wA[1], ar.w(KO(L, wk)), has ? e0 : 0, has ? 64 : 0, has ? nb : 1, lane);
+            rows_issue<FMT, GPB, UD>(wA[2], ar.w(KO(L, wv)), has ? e0 : 0, has ? 64 : 0, has ? nb : 1, lane);
+        };
+        // EARLY: the youngest read of the previous batch as an operand of an (empty) instruction HERE. The compiler counts reads and writes of
+        // vector memory in one counter and, with a write outstanding (a hand-over store, a state row), waits for the counter to reach zero
+        // whatever it needs: a prologue that finds a fresh batch in flight then waits for the whole batch (measured: 1.05 -> 2.7 us). With the
+        // wait taken before the new batch is issued, the phases that follow find their operands landed and wait for nothing.
+        auto landed = [&](auto & bt) {
+            constexpr int UU = (int) (sizeof(bt.raw) / sizeof(bt.raw[0])), RR = (int) (sizeof(bt.raw[0]) / sizeof(bt.raw[0][0]));
+            if constexpr (QF<FMT>::QS == 32) asm volatile("" : : "v"(bt.raw[UU - 1][RR - 1].q[1].w) : "memory");
+            else asm volatile("" : : "v"(bt.raw[UU - 1][RR - 1].q[0].w) : "memory");
+        };
+        // the channel-mixing prologue's parameters, the output rows and the key (+ receptance) rows
+        auto issue_C = [&](int li) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int tid = opq(tid0), lane = tid & 63;
+            const KLayer L{(unsigned long long) (p.layers + __builtin_amdgcn_readfirstlane(li))};
+            const float * sin_l = p.sin + (long long) (li - p.l0) * p.state_stride;
+            long long mix[NIF];
+            L.qs<NIF>(offsetof(P47Layer, mix_f), mix);
+            sf = pro_src<NIF>(ar, KQ(L, ln2_w), KQ(L, ln2_b), mix, sin_l);
+            pro_load<NIF>(pf, sf, tid < NG4 ? tid : 0);
+            rows_issue<FMT, GPB, UD>(wC, ar.w(KO(L, wo)), e0, 64, nb, lane);
+            const WPl fkp = ar.w(KO(L, fk));
+#pragma unroll
+            for (int g = 0; g < GPB; g++) rows_issue<FMT, 4, UD>(wK[g], fkp, 32 * (blk * GPB + g) + 4 * own, 1, nb, lane);
+            if constexpr (!V7) rows_issue<FMT, GPB, UD>(wFr, ar.w(KO(L, fr)), e0, 64, nb, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto issue_E = [&](int li) {
+            __builtin_amdgcn_sched_barrier(0);
+            const KLayer L{(unsigned long long) (p.layers + __builtin_amdgcn_readfirstlane(li))};
+            rows_issue<FMT, GPB, UF>(wE, ar.w(KO(L, fv)), e0, 64, nbF, opq(tid0) & 63);
         };
         issue_A(p.l0, true);
 
@@ -602,6 +724,7 @@ struct K47 {
 #pragma unroll
                 for (int r = 0; r < GPB; r++) xown[r] = l.hx[e0 + 64 * r];
             }
+            if constexpr (EARLY) { landed(wA[2]); issue_C(li); }
             pro_run<NIA, 3, V7>(l, pa, sa, sout_l + D, blk == 0, opq(tid0));
             T47(2);
             __syncthreads();   // B2
@@ -644,18 +767,7 @@ struct K47 {
                 }
             }
             T47(3);
-            // the channel-mixing prologue's parameters, then the output rows and the key (+ receptance) rows: they stream through the y hand-over
-            {
-                __builtin_amdgcn_sched_barrier(0);
-                const int tid = opq(tid0), lane = tid & 63;
-                const P47Layer & L = p.layers[li];
-                sf = pro_src<NIF>(ar, L.ln2_w, L.ln2_b, L.mix_f, sin_l);
-                pro_load<NIF>(pf, sf, tid < NG4 ? tid : 0);
-                rows_issue<FMT, GPB, UD>(wC, ar.w(L.wo), e0, 64, nb, lane);
-#pragma unroll
-                for (int g = 0; g < GPB; g++) rows_issue<FMT, 4, UD>(wK[g], ar.w(L.fk), 32 * (blk * GPB + g) + 4 * own, 1, nb, lane);
-                if constexpr (!V7) rows_issue<FMT, GPB, UD>(wFr, ar.w(L.fr), e0, 64, nb, lane);
-            }
+            if constexpr (!EARLY) issue_C(li);   // (they stream through the y hand-over)
             __syncthreads();   // B3: yq
             T47(4);
             {
@@ -669,6 +781,7 @@ struct K47 {
             T47(5);
             __syncthreads();   // B4
             T47(6);
+            if constexpr (EARLY) { if constexpr (V7) landed(wK[GPB - 1]); else landed(wFr); issue_E(li); issue_A(last ? li : li + 1, !last); }
             pro_run<NIF, NIF, false>(l, pf, sf, sout_l, blk == 0, opq(tid0));
             __syncthreads();   // B5
             T47(7);
@@ -693,8 +806,7 @@ struct K47 {
                 kq_seen += 1u;
                 lf_wait(plw, l.fl + 1, kq_seen);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            { const P47Layer & L = p.layers[li]; rows_issue<FMT, GPB, UF>(wE, ar.w(L.fv), e0, 64, nbF, opq(tid0) & 63); }
+            if constexpr (!EARLY) issue_E(li);
             __syncthreads();   // B6: kq
             T47(9);
             {
@@ -710,7 +822,7 @@ struct K47 {
                 else x_store(p.u_xffn, tagL + S47_XFFN);        // (the last layer's x goes to every workgroup's ln_out when the head follows in this launch)
             }
             T47(10);
-            issue_A(last ? li : li + 1, !last);
+            if constexpr (!EARLY) issue_A(last ? li : li + 1, !last);
         }
     }
 
@@ -824,13 +936,13 @@ struct K47 {
         Poll pl{p.ctl, false};
         const M6Arena ar{p.arena};
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
-        float vf = p.layers[p.l0].layer0 ? 0.0f : p.v_first[hb * S + lane0];
+        float vf = KI(KLAYER(p, p.l0), layer0) ? 0.0f : p.v_first[hb * S + lane0];
         float s[S], cp[5];
         // per-channel parameters a layer ahead; the state row (64 registers) only after the poll -- it lands under the workers' second stages
         auto issue_cp = [&](int li) {
             const int lane = opq(lane0), c = hb * S + lane;
-            const P47Layer & L = p.layers[li];
-            cp[0] = ar.f(L.k_k)[c]; cp[1] = ar.f(L.k_a)[c]; cp[2] = ar.f(L.r_k)[c]; cp[3] = ar.f(L.lnx_w)[c]; cp[4] = ar.f(L.lnx_b)[c];
+            const KLayer L = KLAYER(p, li);
+            cp[0] = ar.f(KQ(L, k_k))[c]; cp[1] = ar.f(KQ(L, k_a))[c]; cp[2] = ar.f(KQ(L, r_k))[c]; cp[3] = ar.f(KQ(L, lnx_w))[c]; cp[4] = ar.f(KQ(L, lnx_b))[c];
             __builtin_amdgcn_sched_barrier(0);
         };
         // The head's state (64 x 64 floats, contiguous) goes HBM -> LDS at the layer top, long before r / k / v arrive: sixteen coalesced
@@ -854,7 +966,7 @@ struct K47 {
         };
         issue_cp(p.l0);
         for (int li = p.l0; li < p.l1; li++) {
-            const P47Layer & L = p.layers[li];
+            const KLayer L = KLAYER(p, li);
             float * sout_l = p.sout + (long long) (li - p.l0) * p.state_stride;
             const unsigned tagL = base + (unsigned) (li - p.l0) * 8u;
             T47(0);
@@ -866,8 +978,11 @@ struct K47 {
                 int ptr[NL1 + 1]; bool valid[NL1 + 1]; v4u dv[NL1 + 1];
                 ptr[0] = p.u_a + c; valid[0] = true;
 #pragma unroll
-                for (int k = 0; k < NL1; k++) { ptr[k + 1] = p.u_lr1 + lane + 64 * k; valid[k + 1] = lane + 64 * k < L.lr_n; }
+                for (int k = 0; k < NL1; k++) { ptr[k + 1] = p.u_lr1 + lane + 64 * k; valid[k + 1] = lane + 64 * k < KI(L, lr_n); }
+                Watch4 wt;
+                watch(wt, p, pl, xr, p.u_a + hb * S + 32, tagL + S47_A);   // (~30 us per layer: r / k / v of one of the head's channels first, then the sweep)
                 poll_ptrs<NL1 + 1>(pl, xr, ptr, valid, tagL + S47_A, dv);
+                watch_done(wt);
                 rv = __uint_as_float(dv[0].x); kv0 = __uint_as_float(dv[0].y); vv = __uint_as_float(dv[0].z);
 #pragma unroll
                 for (int k = 0; k < NL1; k++) l.lr1[lane + 64 * k] = round_f16(__uint_as_float(dv[k + 1].x));
@@ -889,7 +1004,7 @@ struct K47 {
             const float ka = kv0 * c_ka;
             const float aka = av * ka;
             const float kn = kv0 + (aka - ka);
-            if (L.layer0) { p.v_first[c] = vv; vf = vv; }
+            if (KI(L, layer0)) { p.v_first[c] = vv; vf = vv; }
             else { const float dv = (vf - vv) * l.ch[192 + lane]; vv = vv + dv; }
             // {k, w, b, r}_j as one 16-byte broadcast read per step, l_a as sixteen; eight reads in flight at a time
             float4 * bc = reinterpret_cast<float4 *>(l.hv);
@@ -966,36 +1081,42 @@ struct K47 {
         auto prow = [&](int j) { const int pp = 3 * (wave - 4) + j; return 16 * (pp & 3); };
         auto issue = [&](int li) {
             const int lane = opq(tid0) & 63;
-            const P47Layer & L = p.layers[li];
+            const KLayer L = KLAYER(p, li);
+            const int has_v = KI(L, has_v);
+            auto lr2_of = [&](int m) { return L.q(offsetof(P47Layer, lr2) + 8 * (size_t) __builtin_amdgcn_readfirstlane(m)); };
+            auto rank_of = [&](int m) { return L.i(offsetof(P47Layer, rank) + 4 * (size_t) __builtin_amdgcn_readfirstlane(m)); };
             {   // g2 rows (every wave issues: the absent kind loads row 0 of w2 -- one request -- so the issue stays straight-line)
                 const long long row = gw ? (long long) hb * S + 16 * wave + (lane >> 2) : 0;
-                hb_issue<HUB>(bg, p.arena + L.lr2[gw ? 2 : 0], row, gw ? L.rank[2] : 32, gw ? lane : 0);
+                hb_issue<HUB>(bg, p.arena + lr2_of(gw ? 2 : 0), row, gw ? rank_of(2) : 32, gw ? lane : 0);
             }
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 const int m = gw ? 0 : pmtx(j);
-                const bool has = !gw && (m != 3 || L.has_v);
+                const bool has = !gw && (m != 3 || has_v);
                 const long long row = has ? (long long) hb * S + prow(j) + (lane >> 2) : 0;
-                hb_issue<HUB2>(bs[j], p.arena + L.lr2[has ? m : 0], row, has ? L.rank[m] : 32, has ? lane : 0);
+                hb_issue<HUB2>(bs[j], p.arena + lr2_of(has ? m : 0), row, has ? rank_of(m) : 32, has ? lane : 0);
                 const long long ci = (long long) hb * S + (gw ? 0 : prow(j)) + (lane >> 2);
-                const long long off = (has && m == 1) ? L.a0 : ((has && m == 3) ? L.v0 : L.w0);
+                const long long off = (has && m == 1) ? KQ(L, a0) : ((has && m == 3) ? KQ(L, v0) : KQ(L, w0));
                 e0[j] = ar.f(off)[ci];
             }
         };
         issue(p.l0);
         for (int li = p.l0; li < p.l1; li++) {
-            const P47Layer & L = p.layers[li];
+            const KLayer L = KLAYER(p, li);
+            const int has_v = KI(L, has_v);
+            auto rank_of = [&](int m) { return L.i(offsetof(P47Layer, rank) + 4 * (size_t) __builtin_amdgcn_readfirstlane(m)); };
+            auto lbase_of = [&](int m) { return L.i(offsetof(P47Layer, lbase) + 4 * (size_t) __builtin_amdgcn_readfirstlane(m)); };
             __syncthreads();   // H1: lr1 staged
             const int lane = opq(tid0) & 63;
             if (gw) {
-                const float v = hb_row<HUB>(bg, L.rank[2], l.lr1 + L.lbase[2], lane);
+                const float v = hb_row<HUB>(bg, rank_of(2), l.lr1 + lbase_of(2), lane);
                 if ((lane & 3) == 0) l.ch[2 * 64 + 16 * wave + (lane >> 2)] = v;
             } else {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const int m = pmtx(j);
-                    if (m != 3 || L.has_v) {
-                        float v = hb_row<HUB2>(bs[j], L.rank[m], l.lr1 + L.lbase[m], lane);
+                    if (m != 3 || has_v) {
+                        float v = hb_row<HUB2>(bs[j], rank_of(m), l.lr1 + lbase_of(m), lane);
                         if (m == 0) v = det_expf(sigmoid_f(v + e0[j]) * -0.606531f);
                         else v = sigmoid_f(v + e0[j]);
                         if ((lane & 3) == 0) l.ch[m * 64 + prow(j) + (lane >> 2)] = v;
@@ -1016,20 +1137,31 @@ struct K47 {
     // -----------------------------------------------------------------------------------------------------------
     static constexpr int CH = STEPS <= 24 ? 24 : 16, CPP = (STEPS + CH - 1) / CH, NHB = 2;
     static constexpr int ESP = CPP >= NHB ? 1 : NHB / CPP;
+    // Short rows (a pass is one chunk, 12 KB at D = 768): a spare wave also parks LPW passes in LDS at the start of the launch -- the head of
+    // the 169M model is 77 MB, the registers of 256 workgroups hold 55 MB of it and the row workgroups can only fill theirs when their last
+    // layer is done (measured: their 2 x 12 KB per wave took 8.8 us to ISSUE, 96 CUs pulling 18.8 MB at the pace of their outstanding
+    // requests). With 3 passes per spare wave settled before the token is known, a row wave is left with one pass and the tail with ~3 MB.
+    static constexpr bool PARK = P47_PARK && CPP == 1 && NHB == 2 && D <= 768;
+    static constexpr int LPW = PARK ? 1 : 0;
+    static_assert(CH == (STEPS <= 24 ? 24 : 16) && (!PARK || l47_park_bytes(D) == (size_t) 9 * LPW * CH * 512), "park area");
     static constexpr int HXB = NHB > 2 ? 4 : 8;   // activation reads per pinned batch
     struct HJ {
         int2 buf[NHB][CH];
-        int c1, c2, sw, gw, ns, nwt, p1;      // passes of the spare region / the regular region owned by this wave, and where they start
+        int c1, c2, sw, gw, ns, nwt, p1;      // passes of the spare region (register ones) / the regular region owned by this wave, and where they start
         int nitems;
+        int cp;                               // passes of the spare region this wave parked in LDS (they follow its register ones: sw + (ESP + j) ns)
     };
     static __device__ __forceinline__ int hj_pass(const HJ & h, int k) { return k < h.c1 ? h.sw + k * h.ns : h.p1 + h.gw + (k - h.c1) * h.nwt; }
+    static __device__ __forceinline__ int hj_parked(const HJ & h, int j) { return h.sw + (ESP + j) * h.ns; }
     static __device__ __forceinline__ void hj_init(HJ & h, const P47 & p, int wave) {
         const int np = (p.V + 7) / 8, blk = blockIdx.x;
         h.ns = p.n_spare * 9; h.nwt = (int) gridDim.x * 9;
         h.gw = blk * 9 + wave;
         h.sw = blk >= NBLK ? (blk - NBLK) * 9 + wave : -1;
-        h.p1 = np < ESP * h.ns ? np : ESP * h.ns;
-        h.c1 = (h.sw >= 0 && h.sw < h.p1) ? (h.p1 - h.sw + h.ns - 1) / h.ns : 0;
+        h.p1 = np < (ESP + LPW) * h.ns ? np : (ESP + LPW) * h.ns;
+        const int call = (h.sw >= 0 && h.sw < h.p1) ? (h.p1 - h.sw + h.ns - 1) / h.ns : 0;   // this wave's passes of the spare region: the first ESP in registers
+        h.c1 = call < ESP ? call : ESP;
+        h.cp = call - h.c1;
         h.c2 = h.p1 + h.gw < np ? (np - h.p1 - h.gw + h.nwt - 1) / h.nwt : 0;
         h.nitems = (h.c1 + h.c2) * CPP;
     }
@@ -1050,8 +1182,13 @@ struct K47 {
     }
     template <int B>
     static __device__ __forceinline__ void hj_consume(HJ & h, const P47 & p, const Lds & l, int it, int lane, float (&acc)[4], float & best, int & bi) {
-        const bool has = it < h.nitems;
-        const int k = it / CPP, c = it - k * CPP, q = lane & 7;
+        const int k = it / CPP;
+        hj_consume_pass<B>(h, p, l, it < h.nitems, hj_pass(h, k), it - k * CPP, lane, acc, best, bi);
+    }
+    // chunk c of pass `pass` from register buffer B
+    template <int B>
+    static __device__ __forceinline__ void hj_consume_pass(HJ & h, const P47 & p, const Lds & l, bool has, int pass, int c, int lane, float (&acc)[4], float & best, int & bi) {
+        const int q = lane & 7;
         if (c == 0) { acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f; }
 #pragma unroll
         for (int u0 = 0; u0 < CH; u0 += HXB) {
@@ -1080,7 +1217,7 @@ struct K47 {
                 ps[e] = v;
             }
             const float sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            const long long row = has ? (long long) hj_pass(h, k) * 8 + (lane >> 3) : p.V;
+            const long long row = has ? (long long) pass * 8 + (lane >> 3) : p.V;
             if (q == 0 && row < p.V) {
                 p.logits[row] = sum;
                 if (sum > best || (sum == best && (int) row < bi)) { best = sum; bi = (int) row; }
@@ -1091,6 +1228,35 @@ struct K47 {
         hj_issue<0>(h, p, 0, lane);
         if constexpr (NHB > 1) hj_issue<1>(h, p, 1, lane);
         if constexpr (NHB > 2) hj_issue<2>(h, p, 2, lane);
+    }
+    // spare waves, start of the launch: pass j of the parked ones through register buffer 0 into the wave's slice of the park area
+    static __device__ __forceinline__ void hj_park(HJ & h, const P47 & p, const Lds & l, int wave, int lane) {
+        if constexpr (PARK) {
+#pragma unroll
+            for (int j = 0; j < LPW; j++) {
+                const bool has = j < h.cp;
+                long long row = has ? (long long) hj_parked(h, j) * 8 + (lane >> 3) : 0;
+                if (row >= p.V) row = p.V - 1;
+                const uint16_t * base = reinterpret_cast<const uint16_t *>(p.head) + row * D + 4 * (lane & 7);
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    int st = u; if (st >= STEPS) st = STEPS - 1;
+                    { typedef int wv2i __attribute__((ext_vector_type(2))); const wv2i t = __builtin_nontemporal_load(reinterpret_cast<const wv2i *>(base + 32 * st)); h.buf[0][u] = make_int2(t.x, t.y); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                int2 * dst = reinterpret_cast<int2 *>(l.park) + ((wave * LPW + j) * CH) * 64 + lane;
+#pragma unroll
+                for (int u = 0; u < CH; u++) dst[u * 64] = h.buf[0][u];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    template <int B>
+    static __device__ __forceinline__ void hj_unpark(HJ & h, const Lds & l, int wave, int j, int lane) {
+        const int2 * src = reinterpret_cast<const int2 *>(l.park) + ((wave * LPW + j) * CH) * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < CH; u++) h.buf[B][u] = src[u * 64];
+        __builtin_amdgcn_sched_barrier(0);
     }
     static __device__ __forceinline__ void am_merge(float & best, int & bi, float ov, int oi) { if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } }
     static __device__ __forceinline__ void am_wave(float & best, int & bi) {
@@ -1108,10 +1274,10 @@ struct K47 {
         if (wave == 8) {   // ln_out statistics on what the last layer published
             const int lane = opq(tid0) & 63;
             float xs[NU][GPB];
+            if ((p.calm & 1) && (int) blockIdx.x >= NR) calm_wait<8>(pl, xr, p.u_xffn + (int) (blockIdx.x % (unsigned) (NR * 8)), tagT + S47_XFFN);
             poll_x(pl, xr, p.u_xffn, tagT + S47_XFFN, lane, xs);
             ln_stats(l, lane, xs);
-            hj_init(h, p, wave);
-            hj_prefetch(h, p, lane);
+            if (!PARK || (int) blockIdx.x < NBLK) { hj_init(h, p, wave); hj_prefetch(h, p, lane); }   // (PARK: a spare workgroup's polling wave filled its buffers when the launch started)
         }
         __syncthreads();   // T1
         TT47(12);
@@ -1134,6 +1300,27 @@ struct K47 {
         {
             const int lane = opq(tid0) & 63;
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (PARK) {
+                // register passes first (the streamed pass goes in flight behind the first), then the parked ones out of LDS through the
+                // buffer the second left free, then whatever was streamed
+                hj_consume<0>(h, p, l, 0, lane, acc, best, bi);
+                hj_issue<0>(h, p, 2, lane);
+                hj_consume<1>(h, p, l, 1, lane, acc, best, bi);
+#pragma unroll
+                for (int j = 0; j < LPW; j++) {
+                    if (j < h.cp) {   // (wave-uniform; the buffer is refilled whole by the issue below)
+                        hj_unpark<1>(h, l, wave, j, lane);
+                        hj_consume_pass<1>(h, p, l, true, hj_parked(h, j), 0, lane, acc, best, bi);
+                    }
+                }
+                hj_issue<1>(h, p, 3, lane);
+                for (int it = 2; it < h.nitems; it += 2) {
+                    hj_consume<0>(h, p, l, it, lane, acc, best, bi);
+                    hj_issue<0>(h, p, it + 2, lane);
+                    hj_consume<1>(h, p, l, it + 1, lane, acc, best, bi);
+                    hj_issue<1>(h, p, it + 3, lane);
+                }
+            } else
             for (int it = 0; it < h.nitems; it += NHB) {
                 hj_consume<0>(h, p, l, it, lane, acc, best, bi);
                 hj_issue<0>(h, p, it + NHB, lane);
@@ -1216,7 +1403,7 @@ __global__ __launch_bounds__(576) void k47_persist(P47 p) {
         }
     } else {
         // spare workgroup: only rows of the head; its waves that do not poll start their stream now
-        if (fold_head && wave != 8) { K::hj_init(hj, p, wave); K::hj_prefetch(hj, p, tid & 63); }
+        if (fold_head && (K::PARK || wave != 8)) { K::hj_init(hj, p, wave); K::hj_park(hj, p, l, wave, tid & 63); K::hj_prefetch(hj, p, tid & 63); }
     }
 #ifndef P47_X_NO_TAIL
     if (fold_head) {
@@ -1230,6 +1417,10 @@ __global__ __launch_bounds__(576) void k47_persist(P47 p) {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
+
+#ifndef P47_CALM_DEFAULT
+#define P47_CALM_DEFAULT 1
+#endif
 
 struct P47Handle {
     int kind = 3;                 // (mega_v6.hip dispatches on the first member: 1 register prefetch v6, 2 ring v6, 3 this file)
@@ -1410,6 +1601,9 @@ void * p47_create(const Model & m) {
         q.n_spare = g->n_cu - g->n_blocks;
         g->head_bytes = m.head->nbytes + m.ln_out_w->nbytes + m.ln_out_b->nbytes + (uint64_t) m.n_vocab() * 4;
     }
+    // long waits (spare and head workgroups) on one unit instead of the full-width poll; RWKV_MI_P47_CALM=0..3 selects which (measurement aid)
+    const char * calm = getenv("RWKV_MI_P47_CALM");
+    q.calm = calm && calm[0] >= '0' && calm[0] <= '9' ? atoi(calm) : P47_CALM_DEFAULT;
     if (!in_arena) { p47_destroy(g); return nullptr; }
     return g;
 }

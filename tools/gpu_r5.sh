@@ -39,6 +39,33 @@ p47trace)
     f=$(find /tmp/prof_$n -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f $O/decode_${n}_kernel_stats.csv; head -8 $f | cut -c1-160; fi
   done
   ;;
+calm)   # long waits on one unit (RWKV_MI_P47_CALM bit 0: tail, bit 1: head workgroups, bit 2: row polling waves): A/B on one box, raw stamps
+  for c in ${CALMS:-1 5 7 1 5}; do
+    export RWKV_MI_P47_CALM=$c
+    bench_one v4_calm$c rwkv4-169m Q5_1 --abi-tokens 0 --parity-tokens 16
+    bench_one v7_calm$c rwkv7-2b9 Q5_1 --abi-tokens 0 --parity-tokens 16
+  done
+  for c in ${TCALMS:-1 5}; do
+    export RWKV_MI_P47_CALM=$c
+    for ly in 3 11; do TRACE_DUMP=$O/raw_v4_calm${c}_l$ly.npy timeout 200 python tools/trace_p47.py rwkv4-169m Q5_1 $ly > $O/trace_v4_calm${c}_l$ly.txt 2>&1; done
+    for ly in 9 20; do TRACE_DUMP=$O/raw_v7_calm${c}_l$ly.npy timeout 300 python tools/trace_p47.py rwkv7-2b9 Q5_1 $ly > $O/trace_v7_calm${c}_l$ly.txt 2>&1; done
+  done
+  grep -h "layer wall" $O/trace_*_l*.txt
+  ;;
+ab)     # A/B/A/B of lib/ against a variant build of persist_v47.hip in lib_b/ (tools/build_variant.sh lib_b -D...): parity first
+  timeout 900 python -X faulthandler -m pytest ${ABTESTS:-tests/test_gpu_persist_v47.py} -m gpu -x -q -p no:cacheprovider > $O/pytest_p47.txt 2>&1; tail -3 $O/pytest_p47.txt
+  L=rwkv.cpp_amd/lib/librwkv.so; cp $L /tmp/lib_main.so
+  for v in main b main b; do
+    if [ $v = b ]; then cp rwkv.cpp_amd/lib_b/librwkv.so $L; else cp /tmp/lib_main.so $L; fi
+    for c in ${CONFIGS:-v4:rwkv4-169m:Q5_1 v7:rwkv7-2b9:Q5_1}; do IFS=: read n cfg dt <<< "$c"; bench_one ${n}_$v $cfg ${dt:-Q5_1} --abi-tokens 0; done
+  done
+  cp /tmp/lib_main.so $L
+  if [ -z "${NO_TRACE:-}" ]; then
+  for ly in 3 11; do timeout 200 python tools/trace_p47.py rwkv4-169m Q5_1 $ly > $O/trace_v4_l$ly.txt 2>&1; done
+  grep -h "layer wall" $O/trace_*_l*.txt; sed -n 2,26p $O/trace_v4_l11.txt
+  fi
+  if [ -n "${TRACE_V7:-}" ]; then timeout 300 python tools/trace_p47.py rwkv7-2b9 Q5_1 9 > $O/trace_v7_l9.txt 2>&1; sed -n 2,31p $O/trace_v7_l9.txt; fi
+  ;;
 pffdbg)
   for d in 0 1 2 3 4 7; do RWKV_MI_PFF_DBG=$d timeout 200 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 4 --warmup 1 --cpu-seconds 0 --parity-tokens 0 2>/dev/null | python -c "
 import json,sys

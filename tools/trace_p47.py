@@ -31,6 +31,8 @@ L.rwkv_mi_trace_phases.restype = ctypes.c_bool
 out = np.zeros(256 * 8 * 32, dtype=np.int64)
 assert L.rwkv_mi_trace_phases(m._ctx.ptr, 5, layer, 3, out.ctypes.data)
 t = out[:256 * 9 * 16].reshape(256, 9, 16).astype(float) / 100.0      # microseconds
+if os.environ.get('TRACE_DUMP'):   # raw stamps for offline analysis (tools/late_p47.py)
+    np.save(os.environ['TRACE_DUMP'], out[:256 * 9 * 16].reshape(256, 9, 16))
 D = spec.n_embed
 v7 = spec.arch == '7'
 GK = D // 8
@@ -62,6 +64,20 @@ if H:
     for k, n in enumerate(['0 layer top', '1 r k v lr1 gathered', '2 H1 H2 passed (second stages done)', '3 WKV-7 .. yq stored']):
         show(n, hd[:, 8, k])
 print('layer wall (first worker in -> last worker out): %.2f us' % (rows[:, :8, 10].max() - t0))
+# who is late: the stores that feed a hand-over (worker stamps 3, 5, 8, 10), latest wave per workgroup -- by XCD (workgroup id mod 8) and the six latest
+for k in (0, 3, 5, 8, 10):
+    w = rows[:, :8, k].max(axis=1) - t0
+    by = ' '.join('%6.2f' % w[x::8].mean() for x in range(8))
+    late = np.argsort(-w)[:6]
+    print('  late @%-2d  mean by XCD: %s | latest: %s' % (k, by, ', '.join('wg %d (%+.2f)' % (b, w[b] - w.mean()) for b in late)))
+for k in (1, 4, 5, 8):
+    w = rows[:, 8, k] - t0
+    by = ' '.join('%6.2f' % w[x::8].mean() for x in range(8))
+    late = np.argsort(-w)[:4]
+    print('  comm @%-2d  mean by XCD: %s | latest: %s' % (k, by, ', '.join('wg %d (%+.2f)' % (b, w[b] - w.mean()) for b in late)))
+# the waves of the latest workgroup at stamp 10
+b = int(np.argmax(rows[:, :8, 10].max(axis=1)))
+print('  waves of wg %d @10: %s ; @8: %s' % (b, ' '.join('%.2f' % (v - t0) for v in rows[b, :8, 10]), ' '.join('%.2f' % (v - t0) for v in rows[b, :8, 8])))
 # the tail (ln_out + head + argmax inside the launch): stamps 11..15 of every wave of the whole grid, relative to the first wave entering it
 ta = t[:, :, 11:16]
 if ta[:NR].max() > 0:
