@@ -129,6 +129,8 @@ __device__ __forceinline__ void watch4(Watch4 & w, Poll & pl, void * base, unsig
     w.v = v;
 }
 __device__ __forceinline__ void watch_done(Watch4 & w) { asm volatile("; WATCH4_END %0" : : "v"(w.v) : "memory"); }
+// ... and where no sweep of this wave follows the watch: wait for the reads still in flight before the register is released
+__device__ __forceinline__ void watch_drain(Watch4 & w) { asm volatile("s_waitcnt vmcnt(0)\n\t; WATCH4_END %0" : : "v"(w.v) : "memory"); }
 
 // Core: N units per lane given by address; all loads of an attempt are issued together; an attempt succeeds for the wave
 // when every lane saw the expected tag on all of its valid units (invalid slots carry a harmless duplicate address).

@@ -86,6 +86,12 @@ struct P47 {
 #ifndef P47_WATCH_SPREAD
 #define P47_WATCH_SPREAD 8
 #endif
+#ifndef P47_HEAD_SPREAD
+#define P47_HEAD_SPREAD 0
+#endif
+#ifndef P47_YPAR
+#define P47_YPAR 1
+#endif
 #ifndef P47_EARLY
 #define P47_EARLY 0
 #endif
@@ -213,6 +219,7 @@ struct K47 {
     // read of the workers is in flight in front of a hand-over's sweep on the same CU (the sweeps behind a batch took 1.7 - 2.0 us after the
     // last store, the one with nothing in front of it 1.06). Long rows keep the late issue: 168 registers hold one phase's batch, not two.
     static constexpr bool EARLY = P47_EARLY && D <= 768;
+    static constexpr bool YPAR = P47_YPAR && !V7 && GPB == 1 && (D / 8) % 32 == 0;   // RWKV-4's y hand-over swept and quantised by the eight workers
     static_assert(D % 256 == 0 && GK % GPB == 0 && NR * 8 * GPB == D && NBLK <= 256 && NU <= 32 && KQU <= 32, "geometry");
 
     struct Lds {
@@ -558,6 +565,14 @@ struct K47 {
                 watch(wt, p, pl, xr, p.u_y + 6 * far_head(), tagL + S47_Y);   // (a head = two 32-blocks = six units)
                 stage_qvec<DU, 64>(pl, xr, p.u_y, D, tagL + S47_Y, l.yq, opq(lane0));
                 watch_done(wt);
+            } else if constexpr (YPAR) {
+                // RWKV-4: y arrives as floats and every workgroup quantises all of it. This wave only watches; the eight workers -- idle at B3
+                // otherwise -- sweep an eighth of the units each and quantise their blocks (one wave doing all of it: 12 reads per lane, an LDS
+                // transposition and three quantiser passes, ~1.4 us behind the watch)
+                Watch4 wt;
+                watch(wt, p, pl, xr, p.u_y + far_unit(), tagL + S47_Y);
+                lf_add(l.fl + 2, 1u);
+                watch_drain(wt);   // (no sweep of this wave behind the watch: its last reads land here, off the critical path)
             } else {
                 const int lane = opq(lane0);
                 float ys[NU][GPB];
@@ -658,7 +673,7 @@ struct K47 {
         Batch<FMT, GPB, UF> wE;
         float st4[5];                                                         // v4: aa, bb, pp, time_first, time_decay of this lane's channel
         Poll plw{p.ctl, false};
-        unsigned kq_seen = 0;
+        unsigned kq_seen = 0, y_seen = 0;
 
         // has = false (behind the last layer): every lane loads block 0 of row 0 / group 0 -- one request per instruction, and the issue stays
         // straight-line code (a branch around it leaves the buffers conditionally defined: they would live, and spill, around the whole loop)
@@ -768,6 +783,37 @@ struct K47 {
             }
             T47(3);
             if constexpr (!EARLY) issue_C(li);   // (they stream through the y hand-over)
+            if constexpr (YPAR) {
+                // this wave's eighth of y: elements EPW own .. EPW own + EPW - 1 (units of the same index), a 32-block per half-wave and pass
+                constexpr int EPW = D / 8, NPASS = (EPW + 63) / 64;
+                y_seen += 1u;
+                lf_wait(plw, l.fl + 2, y_seen);
+                const int lane = opq(tid0) & 63;
+                int idx[NPASS]; bool val[NPASS]; v4u yv[NPASS];
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ps++) { const int i = 64 * ps + lane; val[ps] = i < EPW; idx[ps] = EPW * own + (val[ps] ? i : i - 32); }
+                for (unsigned spin = 0;; spin++) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int ps = 0; ps < NPASS; ps++) yv[ps] = tg_load(xr, p.u_y + idx[ps]);
+                    bool ok = true;
+#pragma unroll
+                    for (int ps = 0; ps < NPASS; ps++) ok = ok && tg_ok(yv[ps], tagL + S47_Y);
+                    if (__all(ok) || plw.dead) break;
+                    if (poll_backoff(plw, spin)) break;
+                }
+                const QVec lq = qvec_at(l.yq, D);
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ps++) {
+                    int qi, isum; float d16, s16;
+                    quant_block32(__uint_as_float(yv[ps].x), qi, d16, s16, isum);
+                    const int bk = idx[ps] >> 5, e = idx[ps] & 31;
+                    if (val[ps]) {
+                        lq.q[(e < 16 ? 0 : nb * 16) + bk * 16 + (e & 15)] = (int8_t) qi;
+                        if (e == 0) { lq.d[bk] = d16; lq.s[bk] = s16; lq.isum[bk] = isum; }
+                    }
+                }
+            }
             __syncthreads();   // B3: yq
             T47(4);
             {
@@ -980,7 +1026,11 @@ struct K47 {
 #pragma unroll
                 for (int k = 0; k < NL1; k++) { ptr[k + 1] = p.u_lr1 + lane + 64 * k; valid[k + 1] = lane + 64 * k < KI(L, lr_n); }
                 Watch4 wt;
+#if P47_HEAD_SPREAD
+                watch(wt, p, pl, xr, p.u_a + hb * S + (lane & ~7) + 3, tagL + S47_A);   // (~30 us per layer: r / k / v of eight of the head's channels -- eight row workgroups' -- first, then the sweep)
+#else
                 watch(wt, p, pl, xr, p.u_a + hb * S + 32, tagL + S47_A);   // (~30 us per layer: r / k / v of one of the head's channels first, then the sweep)
+#endif
                 poll_ptrs<NL1 + 1>(pl, xr, ptr, valid, tagL + S47_A, dv);
                 watch_done(wt);
                 rv = __uint_as_float(dv[0].x); kv0 = __uint_as_float(dv[0].y); vv = __uint_as_float(dv[0].z);
@@ -1381,7 +1431,7 @@ __global__ __launch_bounds__(576) void k47_persist(P47 p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const typename K::Lds l = K::carve(smem);
     const unsigned base = p.ctl[0];
-    if (tid == 0) { l.fl[0] = 0u; l.fl[1] = 0u; }
+    if (tid == 0) { l.fl[0] = 0u; l.fl[1] = 0u; l.fl[2] = 0u; }
     __syncthreads();
     typename K::HJ hj;
     const bool fold_head = p.logits != nullptr;

@@ -1,6 +1,7 @@
 """Static check of the four-deep watch (persist.h watch4): between '; WATCH4_BEGIN vN' and the matching '; WATCH4_END vN' of a build's
 assembly nothing may write vN (reads of the watch are still in flight into it) and vN may not be spilled; the END must name the same
-register as the BEGIN. usage: python tools/check_watch_regs.py rwkv.cpp_amd/build/persist_v47-hip-amdgcn-amd-amdhsa-gfx950.s"""
+register as the BEGIN, and a full wait (s_waitcnt vmcnt(0): the sweep's, or watch_drain's own) must lie between the two -- an END straight
+behind the watch releases the register while reads are in flight. usage: python tools/check_watch_regs.py rwkv.cpp_amd/build/persist_v47-hip-amdgcn-amd-amdhsa-gfx950.s"""
 import re
 import sys
 
@@ -26,12 +27,15 @@ def dests(line):
 
 def check(path):
     bad, sites, kernel = [], 0, None
-    open_reg, open_line = None, 0
+    open_reg, open_line, waited = None, 0, False
     for n, line in enumerate(open(path), 1):
         if re.match(r"^_Z\w+:", line):
             kernel = line.strip().rstrip(":")
+        if open_reg is not None and re.search(r"s_waitcnt vmcnt\(0\)", line):
+            waited = True
         m = re.search(r"; WATCH4_BEGIN v(\d+)", line)
         if m:
+            waited = False
             # (a BEGIN while one is open: the abort path's re-entry of the loop, same register expected)
             if open_reg is not None and open_reg != int(m.group(1)):
                 bad.append((kernel, n, "nested BEGIN with another register"))
@@ -40,6 +44,8 @@ def check(path):
             continue
         m = re.search(r"; WATCH4_END v(\d+)", line)
         if m:
+            if open_reg is not None and not waited:
+                bad.append((kernel, n, "END without a full wait behind the BEGIN at line %d" % open_line))
             if open_reg is not None and int(m.group(1)) != open_reg:
                 bad.append((kernel, n, "END names v%s, BEGIN (line %d) v%d: the value was copied while reads were in flight" % (m.group(1), open_line, open_reg)))
             open_reg = None
