@@ -86,8 +86,14 @@ struct P47 {
 #ifndef P47_WATCH_SPREAD
 #define P47_WATCH_SPREAD 8
 #endif
-#ifndef P47_HEAD_SPREAD
-#define P47_HEAD_SPREAD 0
+#ifndef P47_HEAD_SPLIT
+#define P47_HEAD_SPLIT 1
+#endif
+#ifndef P47_E_NOWAIT
+#define P47_E_NOWAIT 1
+#endif
+#ifndef P47_ESTAGE
+#define P47_ESTAGE 1
 #endif
 #ifndef P47_YPAR
 #define P47_YPAR 1
@@ -143,10 +149,10 @@ __device__ __forceinline__ float fma_h_hi(unsigned wpair, float x, float acc) {
 
 // R rows row0, row0 + rstride, ... of a quantised matrix with nbk blocks per row: every load of the batch in flight (fused_blocks.h's
 // batch_issue with a row stride; rows are always valid here)
-template <int FMT, int R, int U>
+template <int FMT, int R, int U, int U0 = 0>
 __device__ __forceinline__ void rows_issue(Batch<FMT, R, U> & bt, const WPl & w, int row0, int rstride, int nbk, int lane) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
+    for (int u = U0; u < U; u++) {
         const int bb = u * WAVE + lane;
         unsigned b = (unsigned) (bb < nbk ? bb : nbk - 1);
         asm volatile("" : "+v"(b));
@@ -174,10 +180,14 @@ __device__ __forceinline__ void rows_sum(const Batch<FMT, R, U> & bt, int nbk, i
     for (int r = 0; r < R; r++) res[r] = wave_sum_f(acc[r]);
 }
 
-struct L47 { size_t x, sc, q, lr, yq, kq, out, fl, hx, am, lr1, ch, hv, st, park, total; };
+struct L47 { size_t x, sc, q, lr, yq, kq, out, fl, hx, am, lr1, ch, hv, st, park, stage, total; };
 // rows of the head parked in LDS by the workgroups the layers do not use (K47::PARK): one pass (8 rows) per wave, lane-major like the register buffers
 __host__ __device__ constexpr int l47_ch(int D) { return D / 32 <= 24 ? 24 : 16; }
 __host__ __device__ constexpr size_t l47_park_bytes(int D) { return D <= 768 ? (size_t) 9 * l47_ch(D) * 64 * 8 : 0; }
+// RWKV-7 with long rows (K47::ESTAGE): three of the five 64-block steps of every worker's value rows (two rows: 16 + 4 + 4 bytes per block)
+// wait in LDS from the end of the time mixing on -- 8 waves x 3 x 2 x 1.5 KiB = 72 KiB, which is exactly what D = 2560 leaves of 160 KiB
+__host__ __device__ constexpr int l47_nst(int D, bool v7) { return (v7 && D > 768) ? 3 : 0; }
+__host__ __device__ constexpr size_t l47_stage_bytes(int D, bool v7) { return (size_t) 8 * l47_nst(D, v7) * 2 * 1536; }
 __host__ __device__ inline L47 l47_lds(int D, bool v7) {
     L47 o; size_t p = 0;
     auto take = [&](size_t n) { const size_t r = p; p += m6_round16(n); return r; };
@@ -191,7 +201,8 @@ __host__ __device__ inline L47 l47_lds(int D, bool v7) {
     auto takeh = [&](size_t n) { const size_t r = h; h += m6_round16(n); return r; };
     o.lr1 = takeh(2048 * 4); o.ch = takeh(4 * 64 * 4); o.hv = takeh(5 * 64 * 4); o.st = takeh(64 * 68 * 4);
     o.park = p > h ? p : h;
-    o.total = o.park + l47_park_bytes(D);
+    o.stage = o.park + l47_park_bytes(D);
+    o.total = o.stage + l47_stage_bytes(D, v7);
     return o;
 }
 
@@ -219,12 +230,18 @@ struct K47 {
     // read of the workers is in flight in front of a hand-over's sweep on the same CU (the sweeps behind a batch took 1.7 - 2.0 us after the
     // last store, the one with nothing in front of it 1.06). Long rows keep the late issue: 168 registers hold one phase's batch, not two.
     static constexpr bool EARLY = P47_EARLY && D <= 768;
+    // The value rows' weights (F = 4 D long: 123 KB per workgroup at D = 2560) cannot be issued before the key rows are done -- the registers
+    // hold the key rows' -- so the layer's last phase was its weight stream: 19.7 MB behind the kq hand-over, 5.4 us. ESTAGE: NST of a
+    // wave's UF steps go global -> LDS (LDS-DMA, no registers) when the time mixing's rows are done, and wait there through the head's phase;
+    // behind the key rows only UF - NST steps are left to stream. (Formats with a 4-byte scale pair and 16 code bytes per block.)
+    static constexpr bool ESTAGE = P47_ESTAGE && V7 && GPB == 2 && UF >= 4 && QF<FMT>::HM && QF<FMT>::QS == 16 && nbF % 64 == 0 && l47_nst(D, V7) > 0;
+    static constexpr int NST = ESTAGE ? l47_nst(D, V7) : 0, ST_Q = 0, ST_H = NST * GPB * 1024, ST_S = ST_H + NST * GPB * 256, ST_W = NST * GPB * 1536;
     static constexpr bool YPAR = P47_YPAR && !V7 && GPB == 1 && (D / 8) % 32 == 0;   // RWKV-4's y hand-over swept and quantised by the eight workers
     static_assert(D % 256 == 0 && GK % GPB == 0 && NR * 8 * GPB == D && NBLK <= 256 && NU <= 32 && KQU <= 32, "geometry");
 
     struct Lds {
         float * x; float * sc; unsigned char * q[3]; float * lr[4]; unsigned char * yq; unsigned char * kq; float * out; unsigned * fl;
-        float * lr1; float * ch; float * hv; float * st; float * hx; int * am; unsigned char * park;
+        float * lr1; float * ch; float * hv; float * st; float * hx; int * am; unsigned char * park; unsigned char * stage;
     };
     static __device__ __forceinline__ Lds carve(unsigned char * smem) {
         const L47 lo = l47_lds(D, V7);
@@ -234,7 +251,7 @@ struct K47 {
         for (int i = 0; i < 4; i++) l.lr[i] = reinterpret_cast<float *>(smem + lo.lr) + (V7 ? i * D : 0);
         l.yq = smem + lo.yq; l.kq = smem + lo.kq; l.out = reinterpret_cast<float *>(smem + lo.out); l.fl = reinterpret_cast<unsigned *>(smem + lo.fl);
         l.lr1 = reinterpret_cast<float *>(smem + lo.lr1); l.ch = reinterpret_cast<float *>(smem + lo.ch); l.hv = reinterpret_cast<float *>(smem + lo.hv); l.st = reinterpret_cast<float *>(smem + lo.st);
-        l.hx = reinterpret_cast<float *>(smem + lo.hx); l.am = reinterpret_cast<int *>(smem + lo.am); l.park = smem + lo.park;
+        l.hx = reinterpret_cast<float *>(smem + lo.hx); l.am = reinterpret_cast<int *>(smem + lo.am); l.park = smem + lo.park; l.stage = smem + lo.stage;
         return l;
     }
 
@@ -723,7 +740,51 @@ struct K47 {
         auto issue_E = [&](int li) {
             __builtin_amdgcn_sched_barrier(0);
             const KLayer L{(unsigned long long) (p.layers + __builtin_amdgcn_readfirstlane(li))};
-            rows_issue<FMT, GPB, UF>(wE, ar.w(KO(L, fv)), e0, 64, nbF, opq(tid0) & 63);
+            rows_issue<FMT, GPB, UF, NST>(wE, ar.w(KO(L, fv)), e0, 64, nbF, opq(tid0) & 63);
+        };
+        // ESTAGE: steps 0 .. NST - 1 of this wave's value rows, global -> LDS: per (step, row) 1 KiB of codes, 256 B of fifth bits, 256 B of
+        // scale pairs, lane-major (lane l's block lands at l x 16 / l x 4 of its slice). M0 carries the LDS address of an LDS-DMA
+        // instruction and is not preserved around a statement: saved and restored inside it.
+        auto stage_E = [&](int li) {
+            if constexpr (ESTAGE) {
+                __builtin_amdgcn_sched_barrier(0);
+                const KLayer L{(unsigned long long) (p.layers + __builtin_amdgcn_readfirstlane(li))};
+                const WPl fv = ar.w(KO(L, fv));
+                const unsigned lane = (unsigned) (opq(tid0) & 63);
+                const unsigned m0 = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) (l.stage + own * ST_W));
+                const unsigned long long bq = (unsigned long long) fv.qs, bh = (unsigned long long) fv.qh, bs = (unsigned long long) fv.sc;
+#pragma unroll
+                for (int u = 0; u < NST; u++)
+#pragma unroll
+                    for (int r = 0; r < GPB; r++) {
+                        const unsigned bi = (unsigned) (e0 + 64 * r) * (unsigned) nbF + (unsigned) u * 64u + lane;
+                        const unsigned vq = bi * 16u, vh = bi * 4u;
+                        const unsigned dq = m0 + ST_Q + (u * GPB + r) * 1024, dh = m0 + ST_H + (u * GPB + r) * 256, ds = m0 + ST_S + (u * GPB + r) * 256;
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(vq), "s"(bq), "s"(dq) : "memory");
+                        if constexpr (QF<FMT>::QH) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(vh), "s"(bh), "s"(dh) : "memory");
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(vh), "s"(bs), "s"(ds) : "memory");
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // ... and back into the batch's registers in front of the value rows (every read of this wave has landed: one full wait)
+        auto unstage_E = [&]() {
+            if constexpr (ESTAGE) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int lane = opq(tid0) & 63;
+                const unsigned char * sb = l.stage + own * ST_W;
+#pragma unroll
+                for (int u = 0; u < NST; u++)
+#pragma unroll
+                    for (int r = 0; r < GPB; r++) {
+                        RawBlk<FMT> & o = wE.raw[u][r];
+                        o.q[0] = *reinterpret_cast<const int4 *>(sb + ST_Q + (u * GPB + r) * 1024 + lane * 16);
+                        if constexpr (QF<FMT>::QH) o.qh = *reinterpret_cast<const unsigned *>(sb + ST_H + (u * GPB + r) * 256 + lane * 4);
+                        o.sc = *reinterpret_cast<const unsigned *>(sb + ST_S + (u * GPB + r) * 256 + lane * 4);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         issue_A(p.l0, true);
 
@@ -782,7 +843,7 @@ struct K47 {
                 }
             }
             T47(3);
-            if constexpr (!EARLY) issue_C(li);   // (they stream through the y hand-over)
+            if constexpr (!EARLY) { issue_C(li); stage_E(li); }   // (they stream through the y hand-over)
             if constexpr (YPAR) {
                 // this wave's eighth of y: elements EPW own .. EPW own + EPW - 1 (units of the same index), a 32-block per half-wave and pass
                 constexpr int EPW = D / 8, NPASS = (EPW + 63) / 64;
@@ -846,7 +907,7 @@ struct K47 {
                 if constexpr (!V7) rows_sum<FMT, GPB, UD>(wFr, nb, lane, qvec_at(l.q[1], D), rgate);
             }
             T47(8);
-            if constexpr (UF >= 4) {
+            if constexpr (UF >= 4 && !(ESTAGE && P47_E_NOWAIT)) {
                 // (long rows: 77 KB per workgroup at 2.9B. Issued before the comm wave has stored this workgroup's key groups they sit in the
                 //  CU's memory pipe in front of that store -- and 159 other workgroups wait for it: measured 1.6 us on the slowest)
                 kq_seen += 1u;
@@ -855,6 +916,7 @@ struct K47 {
             if constexpr (!EARLY) issue_E(li);
             __syncthreads();   // B6: kq
             T47(9);
+            unstage_E();
             {
                 const int lane = opq(tid0) & 63, myrow = myrow_of(lane);
                 float res[GPB];
@@ -1017,8 +1079,37 @@ struct K47 {
             const unsigned tagL = base + (unsigned) (li - p.l0) * 8u;
             T47(0);
             stage_state(li);
-            // r, k, v of this lane's channel (one unit) and the lr1 vector (fp16-rounded into LDS: what ggml feeds an F16 matrix)
             float rv, kv0, vv;
+#if P47_HEAD_SPLIT
+            // The lr1 vector first (fp16-rounded into LDS: what ggml feeds an F16 matrix): the polling waves of the row workgroups publish it a
+            // row phase before r / k / v (their jobs run beside the workers' R / K / V rows), and the second low-rank stages need nothing else
+            // -- they run on the eight workers while this wave waits for r, k, v of its channels (one unit per lane). Gathered together the
+            // second stages started behind the LAST r / k / v row: 2.2 us on the layer's longest chain.
+            {
+                const int lane = opq(lane0);
+                int ptr[NL1]; bool valid[NL1]; v4u dv[NL1];
+#pragma unroll
+                for (int k = 0; k < NL1; k++) { ptr[k] = p.u_lr1 + lane + 64 * k; valid[k] = lane + 64 * k < KI(L, lr_n); }
+                Watch4 wt;
+                watch(wt, p, pl, xr, p.u_lr1 + 72 * (lane >> 3) + 5 < p.u_lr1 + KI(L, lr_n) ? p.u_lr1 + 72 * (lane >> 3) + 5 : p.u_lr1, tagL + S47_A);   // (~25 us per layer: eight units of eight jobs first, then the sweep)
+                poll_ptrs<NL1>(pl, xr, ptr, valid, tagL + S47_A, dv);
+                watch_done(wt);
+#pragma unroll
+                for (int k = 0; k < NL1; k++) l.lr1[lane + 64 * k] = round_f16(__uint_as_float(dv[k].x));
+            }
+            T47(1);
+            __syncthreads();   // H1
+            {
+                const int lane = opq(lane0), c = hb * S + lane;
+                int ptr[1] = {p.u_a + c}; bool valid[1] = {true}; v4u dv[1];
+                Watch4 wt;
+                watch(wt, p, pl, xr, p.u_a + hb * S + (lane & ~7) + 3, tagL + S47_A);
+                poll_ptrs<1>(pl, xr, ptr, valid, tagL + S47_A, dv);
+                watch_done(wt);
+                rv = __uint_as_float(dv[0].x); kv0 = __uint_as_float(dv[0].y); vv = __uint_as_float(dv[0].z);
+            }
+#else
+            // r, k, v of this lane's channel (one unit) and the lr1 vector (fp16-rounded into LDS: what ggml feeds an F16 matrix)
             {
                 const int lane = opq(lane0), c = hb * S + lane;
                 int ptr[NL1 + 1]; bool valid[NL1 + 1]; v4u dv[NL1 + 1];
@@ -1026,11 +1117,7 @@ struct K47 {
 #pragma unroll
                 for (int k = 0; k < NL1; k++) { ptr[k + 1] = p.u_lr1 + lane + 64 * k; valid[k + 1] = lane + 64 * k < KI(L, lr_n); }
                 Watch4 wt;
-#if P47_HEAD_SPREAD
-                watch(wt, p, pl, xr, p.u_a + hb * S + (lane & ~7) + 3, tagL + S47_A);   // (~30 us per layer: r / k / v of eight of the head's channels -- eight row workgroups' -- first, then the sweep)
-#else
                 watch(wt, p, pl, xr, p.u_a + hb * S + 32, tagL + S47_A);   // (~30 us per layer: r / k / v of one of the head's channels first, then the sweep)
-#endif
                 poll_ptrs<NL1 + 1>(pl, xr, ptr, valid, tagL + S47_A, dv);
                 watch_done(wt);
                 rv = __uint_as_float(dv[0].x); kv0 = __uint_as_float(dv[0].y); vv = __uint_as_float(dv[0].z);
@@ -1039,6 +1126,7 @@ struct K47 {
             }
             T47(1);
             __syncthreads();   // H1
+#endif
             __syncthreads();   // H2: the second stages' results are in l.ch
             T47(2);
             const int lane = opq(lane0), c = hb * S + lane;

@@ -61,7 +61,7 @@ for k, n in ((0, cn[0]), (1, cn[1]), (2, cn[2]), (3, cn[3]), (4, cn[4]), (5, cn[
 if H:
     hd = t[NR:NR + H]
     print('head workgroups, COMM wave')
-    for k, n in enumerate(['0 layer top', '1 r k v lr1 gathered', '2 H1 H2 passed (second stages done)', '3 WKV-7 .. yq stored']):
+    for k, n in enumerate(['0 layer top', '1 lr1 gathered (r k v: under the second stages)', '2 H1 H2 passed (second stages done)', '3 WKV-7 .. yq stored']):
         show(n, hd[:, 8, k])
 print('layer wall (first worker in -> last worker out): %.2f us' % (rows[:, :8, 10].max() - t0))
 # who is late: the stores that feed a hand-over (worker stamps 3, 5, 8, 10), latest wave per workgroup -- by XCD (workgroup id mod 8) and the six latest
