@@ -89,6 +89,12 @@ struct P47 {
 #ifndef P47_HEAD_SPLIT
 #define P47_HEAD_SPLIT 1
 #endif
+#ifndef P47_PRO2_FIRST
+#define P47_PRO2_FIRST 0
+#endif
+#ifndef P47_E_MID
+#define P47_E_MID 0
+#endif
 #ifndef P47_E_NOWAIT
 #define P47_E_NOWAIT 1
 #endif
@@ -449,6 +455,22 @@ struct K47 {
     template <int NI, int NQ, bool LR>
     static __device__ __forceinline__ void pro_run(const Lds & l, const Pro<NI> & pr, const ProSrc<NI> & src, float * carry_out, bool write_state, int tid) {
         const float scale = l.sc[0];
+        if constexpr (SL == 2 && P47_PRO2_FIRST) {
+            // (the second slot's parameters go in flight BEFORE the first slot's arithmetic: loaded behind it, waves 0 and 1 finished the
+            //  time-mixing prologue 1.45 us after the others -- a memory round trip -- and B2 waited for them)
+            const int wave0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
+            if (wave0 + 512 < NG4) {           // whole waves (NG4 % 64 == 0)
+                Pro<NI> p2;
+                asm volatile("" : : "v"(pr.cf[NI - 1].w) : "memory");   // (the first slot's parameters have landed HERE: with p2 in flight the compiler's wait for them would be a wait for p2 as well)
+                pro_load<NI>(p2, src, tid + 512);
+                __builtin_amdgcn_sched_barrier(0);
+                pro_group<NI, NQ, LR>(l, pr, scale, carry_out, write_state, tid, true);
+                pro_group<NI, NQ, LR>(l, p2, scale, carry_out, write_state, tid + 512, true);
+            } else {
+                pro_group<NI, NQ, LR>(l, pr, scale, carry_out, write_state, tid < NG4 ? tid : 0, tid < NG4);
+            }
+            return;
+        }
         pro_group<NI, NQ, LR>(l, pr, scale, carry_out, write_state, tid < NG4 ? tid : 0, tid < NG4);
 #pragma unroll
         for (int u = 1; u < SL; u++) {
@@ -902,6 +924,7 @@ struct K47 {
                     const float v = pick_lane<4>(res, lane);
                     const float t = v > 0.0f ? v : 0.0f;
                     if (lane < 4) l.out[32 * g + 4 * own + lane] = t * t;
+                    if constexpr (ESTAGE && P47_E_MID && GPB == 2) { if (g == 0) issue_E(li); }   // (the first key group's registers are free: the value rows' last steps go in flight under the second)
                 }
                 lf_add(l.fl, 1u);
                 if constexpr (!V7) rows_sum<FMT, GPB, UD>(wFr, nb, lane, qvec_at(l.q[1], D), rgate);
@@ -913,7 +936,7 @@ struct K47 {
                 kq_seen += 1u;
                 lf_wait(plw, l.fl + 1, kq_seen);
             }
-            if constexpr (!EARLY) issue_E(li);
+            if constexpr (!EARLY && !(ESTAGE && P47_E_MID && GPB == 2)) issue_E(li);
             __syncthreads();   // B6: kq
             T47(9);
             unstage_E();
