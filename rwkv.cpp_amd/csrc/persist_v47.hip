@@ -92,6 +92,9 @@ struct P47 {
 #ifndef P47_PRO2_FIRST
 #define P47_PRO2_FIRST 0
 #endif
+#ifndef P47_E_WITH_C
+#define P47_E_WITH_C 0
+#endif
 #ifndef P47_E_MID
 #define P47_E_MID 0
 #endif
@@ -242,6 +245,9 @@ struct K47 {
     // behind the key rows only UF - NST steps are left to stream. (Formats with a 4-byte scale pair and 16 code bytes per block.)
     static constexpr bool ESTAGE = P47_ESTAGE && V7 && GPB == 2 && UF >= 4 && QF<FMT>::HM && QF<FMT>::QS == 16 && nbF % 64 == 0 && l47_nst(D, V7) > 0;
     static constexpr int NST = ESTAGE ? l47_nst(D, V7) : 0, ST_Q = 0, ST_H = NST * GPB * 1024, ST_S = ST_H + NST * GPB * 256, ST_W = NST * GPB * 1536;
+    // short rows: the value rows' weights (12 registers per lane at D = 768) go in flight with the output and key rows', a hand-over earlier --
+    // nothing of the workers is then in front of the kq sweep on the CU
+    static constexpr bool E_WITH_C = P47_E_WITH_C && !EARLY && UF <= 2;
     static constexpr bool YPAR = P47_YPAR && !V7 && GPB == 1 && (D / 8) % 32 == 0;   // RWKV-4's y hand-over swept and quantised by the eight workers
     static_assert(D % 256 == 0 && GK % GPB == 0 && NR * 8 * GPB == D && NBLK <= 256 && NU <= 32 && KQU <= 32, "geometry");
 
@@ -865,7 +871,7 @@ struct K47 {
                 }
             }
             T47(3);
-            if constexpr (!EARLY) { issue_C(li); stage_E(li); }   // (they stream through the y hand-over)
+            if constexpr (!EARLY) { issue_C(li); stage_E(li); if constexpr (E_WITH_C) issue_E(li); }   // (they stream through the y hand-over)
             if constexpr (YPAR) {
                 // this wave's eighth of y: elements EPW own .. EPW own + EPW - 1 (units of the same index), a 32-block per half-wave and pass
                 constexpr int EPW = D / 8, NPASS = (EPW + 63) / 64;
@@ -936,7 +942,7 @@ struct K47 {
                 kq_seen += 1u;
                 lf_wait(plw, l.fl + 1, kq_seen);
             }
-            if constexpr (!EARLY && !(ESTAGE && P47_E_MID && GPB == 2)) issue_E(li);
+            if constexpr (!EARLY && !E_WITH_C && !(ESTAGE && P47_E_MID && GPB == 2)) issue_E(li);
             __syncthreads();   // B6: kq
             T47(9);
             unstage_E();
