@@ -13,8 +13,8 @@ if ! grep -q " passed" $O/pytest.txt || grep -q "failed\|error" $O/pytest.txt; t
 # this build's sources: the bench lines below then quote counters of the build they run on
 R=$PWD
 ( cd /tmp
-  RWKV_MI_NO_AUTOTUNE=1 RWKV_MI_PERSIST=ring RWKV_BENCH_NO_COLD=1 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -o p -- python $R/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --abi-tokens 0 --no-profile --parity-tokens 0 > /dev/null 2> $R/$O/pmc_fetch.err
-  RWKV_MI_NO_AUTOTUNE=1 RWKV_MI_PERSIST=ring RWKV_BENCH_NO_COLD=1 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -o p -- python $R/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --abi-tokens 0 --no-profile --parity-tokens 0 > /dev/null 2> $R/$O/pmc_write.err )
+  RWKV_MI_NO_AUTOTUNE=1 RWKV_MI_PERSIST=ring RWKV_BENCH_NO_COLD=1 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -o p -- python $R/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --abi-tokens 0 --no-profile --parity-tokens 0 --no-other-configs > /dev/null 2> $R/$O/pmc_fetch.err
+  RWKV_MI_NO_AUTOTUNE=1 RWKV_MI_PERSIST=ring RWKV_BENCH_NO_COLD=1 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -o p -- python $R/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --abi-tokens 0 --no-profile --parity-tokens 0 --no-other-configs > /dev/null 2> $R/$O/pmc_write.err )
 KS=$(python -c "import bench; print(bench.kernel_source_stamp(2))")
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write k6_ring rwkv6-7b:Q4_0:path2:kind2 profiles/pmc_traffic.json $KS > $O/pmc_traffic_summary.txt 2>&1; cat $O/pmc_traffic_summary.txt; cp profiles/pmc_traffic.json $O/pmc_traffic.json
 RWKV_FINAL_SKIP_SUITE=1 RWKV_FINAL_SKIP_PMC=1 bash tools/gpu_final.sh $T
