@@ -18,11 +18,23 @@
 // owns rows {e0, e0 + 64 (GPB = 2)} of EVERY D-row matrix (so the residual of those rows lives in its registers for the whole token and
 // RWKV-4's per-channel recurrence is wave-local) and four rows of each of its key groups; one more wave ("comm", wave 8) polls every
 // hand-over into LDS, runs the LayerNorm statistics on what it polled (the x units are laid out so that lane l receives the elements
-// l mod 64: exactly the partials of the specified reduction tree), quantises y (RWKV-4) and the key groups, and on
-// RWKV-7 runs the workgroup's share of the first low-rank stages. RWKV-7's heads run on H further workgroups that own no rows: their
-// comm wave polls r / k / v / lr1 and runs the recurrence of kdev's k7_head statement for statement, their eight workers the second stages.
+// l mod 64: exactly the partials of the specified reduction tree), quantises the key groups, and on RWKV-7 runs the
+// workgroup's share of the first low-rank stages. RWKV-7's heads run on H further workgroups that own no rows: their comm wave polls
+// lr1, then r / k / v, and runs the recurrence of kdev's k7_head statement for statement, their eight workers the second stages.
 // Weights go global -> registers one phase ahead (no ring: a workgroup's share of a 169M layer is 55 KB, of a 2.9B layer 412 KB in four
 // phases). Arithmetic and reduction orders are those of fused_v7.hip / kernels.hip and of the CPU oracle: bit-identical.
+//
+// Embedding + ln0 (first stage) and ln_out + head + argmax (last stage; every workgroup of the grid, the CUs the layers do not use
+// included) run inside the launch: a token is one graph node. Layer ranges serve pipeline stages and the streamed rwkv_eval.
+//
+// Hand-overs (DESIGN.md 6.3c has the measurements behind each): a wave that waits WATCHES before it sweeps -- one tag word per group of
+// eight lanes, eight producers' units, four reads in flight on short rows (persist.h watch4) -- and sweeps when all eight have turned;
+// RWKV-4's y is swept and quantised by the eight workers (YPAR); RWKV-7's head workgroups gather lr1 first and r / k / v under their
+// second low-rank stages (P47_HEAD_SPLIT); three of five steps of RWKV-7's value rows wait in LDS from the end of the time mixing
+// (ESTAGE, LDS-DMA); the layer table is read through the scalar cache (KLayer); spare workgroups park a third pass of the head in LDS
+// (PARK). Compile-time switches for same-box A/B builds (tools/build_variant.sh): P47_WATCH (0 none / 1 one read / 2 four deep),
+// P47_WATCH_SPREAD (units watched: 8), P47_HEAD_SPLIT, P47_ESTAGE, P47_E_NOWAIT, P47_YPAR, P47_PARK -- on; P47_EARLY, P47_E_MID,
+// P47_E_WITH_C, P47_PRO2_FIRST -- measured, off. Run time: RWKV_MI_P47_NOFOLD, RWKV_MI_P47_CALM.
 //
 // Residency and safety as mega_v6.hip: NR (+ H) <= CUs, polls are bounded by the abort word.
 #include "persist.h"
@@ -546,7 +558,6 @@ struct K47 {
     static __device__ __forceinline__ void row_comm(const P47 & p, const Lds & l, int lane0, unsigned base) {
         const int blk = blockIdx.x;
         Poll pl{p.ctl, false};
-        const M6Arena ar{p.arena};
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         unsigned keys_done = 0;
         __builtin_amdgcn_s_setprio(2);   // every hand-over of the workgroup goes through this wave: it issues ahead of the two workers on its SIMD
@@ -817,7 +828,6 @@ struct K47 {
         issue_A(p.l0, true);
 
         for (int li = p.l0; li < p.l1; li++) {
-            const float * sin_l = p.sin + (long long) (li - p.l0) * p.state_stride;
             float * sout_l = p.sout + (long long) (li - p.l0) * p.state_stride;
             const unsigned tagL = base + (unsigned) (li - p.l0) * 8u;
             const bool last = li + 1 == p.l1;
@@ -1300,7 +1310,8 @@ struct K47 {
     // increasing k on fp16-rounded activations, ggml's fold). Every wave of the grid takes "passes" of eight rows (eight lanes per row,
     // lane q keeps partials 4q .. 4q + 3) in chunks of CH 32-column steps through NHB register buffers. The head does not depend on the
     // token: spare workgroups (CUs the layers do not use: 160 of 256 at D = 768) put their first chunks in flight when the launch starts,
-    // the others when their last layer is done -- E passes per spare wave are reserved for that, the rest is dealt evenly.
+    // the others when their last layer is done -- ESP (+ LPW parked) passes per spare wave are reserved for that (the "spare region" of the
+    // pass numbers), the rest is dealt evenly over every wave of the grid.
     // -----------------------------------------------------------------------------------------------------------
     static constexpr int CH = STEPS <= 24 ? 24 : 16, CPP = (STEPS + CH - 1) / CH, NHB = 2;
     static constexpr int ESP = CPP >= NHB ? 1 : NHB / CPP;
