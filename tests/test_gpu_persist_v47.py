@@ -208,3 +208,37 @@ def test_persistent_v47_trace_and_clones(tmp_path):
     assert (np.diff(t[:96, 8, :9], axis=1) >= 0).all()                                                    # their polling waves
     assert a.healthy() and b.healthy()
     a.free(); b.free(); om.free()
+
+
+@pytest.mark.parametrize("name,env", [("test-v4", "RWKV_MI_P47_NOFOLD"), ("test-v7", "RWKV_MI_P47_NOFOLD"), ("slice-v4-768", "RWKV_MI_P47_CALM0"), ("test-v7", "RWKV_MI_P47_CALM0")])
+def test_persistent_v47_measurement_switches_keep_the_result(tmp_path, name, env):
+    """RWKV_MI_P47_NOFOLD=1 (embedding + ln0 and ln_out + head + argmax as separate launches) and RWKV_MI_P47_CALM=0 (spare / head workgroups
+    poll the last layer's x at full width) are A/B aids of DESIGN.md 6.3c: other schedules of the same arithmetic -- logits, state and the
+    greedy continuation stay the oracle's."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS[name]
+    synth.write_model(p, spec, "Q5_1", seed=47)
+    om = O.OracleModel(p)
+    var, val = (env, "1") if env.endswith("NOFOLD") else ("RWKV_MI_P47_CALM", "0")
+    os.environ[var] = val
+    try:
+        m = model(p)
+    finally:
+        del os.environ[var]
+    assert m.decode_path() == 2 and m.persist_kind() == 3
+    ost, st = om.init_state(), None
+    for i, t in enumerate(TOKENS[:6]):
+        ol, ost = om.eval(t, ost)
+        lg, st = m.eval(t, st)
+        assert np.array_equal(lg, ol) and np.array_equal(st, ost), (name, env, i)
+    m.state_load(None)
+    toks, _ = m.decode_greedy(5, 8)
+    os2, tok, ref = om.init_state(), 5, []
+    for _ in range(8):
+        ol, os2 = om.eval(tok, os2)
+        tok = int(np.argmax(ol))
+        ref.append(tok)
+    assert list(toks) == ref and np.array_equal(m.state_store(), os2)
+    assert m.healthy()
+    m.free(); om.free()
