@@ -259,6 +259,7 @@ def other_configs(args, pkg, lib, synth, torch):
             out[tag] = {"workload": r["config"]["workload"], "tokens_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": sub.steps,
                         "decode_path": r["config"]["decode_path"], "persist_kind": r["config"]["persist_kind"],
                         "kernel": roof.get("kernel"), "kernel_frac_of_8TBps": roof.get("frac"), "kernel_avg_launch_us": roof.get("avg_launch_us"),
+                        "kernel_traffic_bytes_per_launch": roof.get("traffic"), "kernel_bytes_per_launch": roof.get("avg_bytes_per_launch"),
                         "token_frac_of_8TBps": r["hbm"]["frac_of_8TBps"], "algorithmic_bytes_per_token": r["hbm"]["algorithmic_bytes_per_token"],
                         "parity": {k: r.get("parity", {}).get(k) for k in ("tokens_checked", "equal", "tokens_equal", "logits_equal", "state_equal", "crosses_tag_wrap")},
                         "cpu_tokens_per_s": r.get("cpu_baseline", {}).get("value"), "seconds": round(time.time() - t0, 1)}
