@@ -291,7 +291,9 @@ RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_to
     uint32_t * d_hist = hist.p;
     HIP_CTX_OK(ctx, hipStreamSynchronize(ctx->stream));
     // persist_v47.hip: the launch itself picks the token, leaves it where its own embedding lookup reads it and appends it to the history
-    const bool in_launch = folded_argmax_target(ctx) == ctx->d_tokens && mega_v6_set_history(ctx->mega, d_hist, ctx->stream);
+    const bool in_launch = folded_argmax_target(ctx) == ctx->d_tokens && mega_v6_set_history(ctx->mega, d_hist, n_tokens, ctx->stream);
+    // (every exit from here on takes the history pointer out of the kernel's control words again: d_hist is freed when this function returns)
+    struct HistGuard { rwkv_context * c; bool on; ~HistGuard() { if (on && c->mega) (void) mega_v6_set_history(c->mega, nullptr, 0, c->stream); } } hist_guard{ctx, in_launch};
     HIP_CTX_OK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     bool ok = true;
     for (size_t i = 0; i < n_tokens && ok; i++) {
@@ -304,7 +306,8 @@ RWKV_API bool rwkv_mi_decode_greedy(struct rwkv_context * ctx, uint32_t first_to
     }
     if (in_launch && ctx->mega) {
         const bool drained = hipEventRecord(ctx->ev1, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-        ok = mega_v6_set_history(ctx->mega, nullptr, ctx->stream) && drained && ok;
+        ok = mega_v6_set_history(ctx->mega, nullptr, 0, ctx->stream) && drained && ok;
+        hist_guard.on = false;
         if (ok && elapsed_ms) ok = hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1) == hipSuccess;
         if (ok && tokens_out) ok = hipMemcpyAsync(tokens_out, d_hist, n_tokens * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
     } else if (ok) {

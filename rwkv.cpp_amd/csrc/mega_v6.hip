@@ -940,18 +940,21 @@ uint64_t mega_v6_bytes(void * h) { if (is_ring(h)) return ring_v6_bytes(h); if (
 bool mega_v6_folds_head(void * h) { return (is_ring(h) && ring_v6_folds_head(h)) || (is_p47(h) && p47_folds_head(h)); }
 
 bool mega_v6_has_range(void * h) { return is_ring(h) || is_p47(h); }
-bool mega_v6_folds_embed(void * h) { return is_p47(h) && p47_folds_embed(h); }
-bool mega_v6_folds_argmax(void * h) { return is_p47(h) && p47_folds_head(h); }
-bool mega_v6_set_history(void * h, uint32_t * hist, hipStream_t st) { return is_p47(h) && p47_set_history(h, hist, st); }
+bool mega_v6_folds_embed(void * h) { return (is_p47(h) && p47_folds_embed(h)) || (is_ring(h) && ring_v6_folds_embed(h)); }
+bool mega_v6_folds_argmax(void * h) { return (is_p47(h) && p47_folds_head(h)) || (is_ring(h) && ring_v6_folds_argmax(h)); }
+bool mega_v6_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st) {
+    if (is_p47(h)) return p47_set_history(h, hist, n, st);
+    return is_ring(h) && ring_v6_set_history(h, hist, n, st);
+}
 void mega_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1, float * v_first,
                            const uint32_t * tok, uint32_t * next_tok) {
     if (is_p47(h)) { p47_forward_range(h, x, v_first, sin, sout, st, pf, l0, l1, logits, tok, next_tok); return; }
-    ring_v6_forward_range(h, x, sin, sout, st, pf, logits, l0, l1);
+    ring_v6_forward_range(h, x, sin, sout, st, pf, logits, l0, l1, tok, next_tok);
 }
 
 void mega_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, float * v_first,
                      const uint32_t * tok, uint32_t * next_tok) {
-    if (is_ring(h)) { ring_v6_forward(h, x, sin, sout, st, pf, logits); return; }
+    if (is_ring(h)) { ring_v6_forward(h, x, sin, sout, st, pf, logits, tok, next_tok); return; }
     if (is_p47(h)) { p47_forward_range(h, x, v_first, sin, sout, st, pf, 0, p47_layers(h), logits, tok, next_tok); return; }
     MegaV6 * mg = (MegaV6 *) h;
     M6P q = mg->proto;

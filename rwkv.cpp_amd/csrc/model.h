@@ -226,7 +226,7 @@ void     mega_v6_forward_range(void * h, float * x, const float * sin, float * s
 bool     mega_v6_has_range(void * h);
 bool     mega_v6_folds_embed(void * h);      // the launch starts from the token id: the caller skips its embedding + ln0 launch
 bool     mega_v6_folds_argmax(void * h);     // a launch that produces logits also writes their argmax to next_tok
-bool     mega_v6_set_history(void * h, uint32_t * hist, hipStream_t st);   // (folds_argmax) tokens appended on the device, no copy per token
+bool     mega_v6_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st);   // (folds_argmax) tokens appended on the device (at most n), no copy per token
 bool     mega_v6_folds_head(void * h);
 bool     mega_v6_ctl_fetch(void * h, hipStream_t st);       // async copy of the control words into the pinned mirror
 bool     mega_v6_aborted_cached(void * h);                  // the mirror's abort word (valid after the stream was synchronised)
@@ -244,7 +244,7 @@ void     p47_forward_range(void * h, float * x, float * v_first, const float * s
                            float * logits = nullptr, const uint32_t * tok = nullptr, uint32_t * next_tok = nullptr);
 bool     p47_folds_embed(void * h);
 bool     p47_folds_head(void * h);
-bool     p47_set_history(void * h, uint32_t * hist, hipStream_t st);
+bool     p47_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st);
 int      p47_layers(void * h);
 bool     p47_ctl_fetch(void * h, hipStream_t st);
 bool     p47_aborted_cached(void * h);
@@ -256,9 +256,13 @@ bool     p47_trace(void * h, int layer, long long * out, bool fetch);
 // the same persistent launch on the LDS-DMA weight ring (ring_v6.hip); reached through the mega_v6_* entry points
 void *   ring_v6_create(const Model & m);
 void     ring_v6_destroy(void * h);
-void     ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits);
-void     ring_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1);
+void     ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, const uint32_t * tok = nullptr, uint32_t * next_tok = nullptr);
+void     ring_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1,
+                               const uint32_t * tok = nullptr, uint32_t * next_tok = nullptr);
 bool     ring_v6_folds_head(void * h);
+bool     ring_v6_folds_embed(void * h);
+bool     ring_v6_folds_argmax(void * h);
+bool     ring_v6_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st);
 bool     ring_v6_ctl_fetch(void * h, hipStream_t st);
 bool     ring_v6_aborted_cached(void * h);
 unsigned ring_v6_generation_cached(void * h);

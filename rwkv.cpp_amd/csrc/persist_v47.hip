@@ -1542,7 +1542,7 @@ struct K47 {
                     if (p.ctl[2] != 0u) {
                         unsigned * hist = reinterpret_cast<unsigned *>((unsigned long long) p.ctl[4] | ((unsigned long long) p.ctl[5] << 32));
                         const unsigned pos = p.ctl[3];
-                        hist[pos] = tokn;
+                        if (pos < p.ctl[6]) hist[pos] = tokn;   // (ctl[6]: the history's capacity)
                         p.ctl[3] = pos + 1u;
                     }
                 }
@@ -1819,10 +1819,10 @@ void p47_forward_range(void * h, float * x, float * v_first, const float * sin, 
     }
 }
 // greedy loops: the kernel appends every token it picks to hist (device memory, n entries) from position 0; nullptr switches it off
-bool p47_set_history(void * h, uint32_t * hist, hipStream_t st) {
+bool p47_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st) {
     P47Handle * g = (P47Handle *) h;
     const unsigned long long a = (unsigned long long) hist;
-    const unsigned w[4] = {hist ? 1u : 0u, 0u, (unsigned) (a & 0xFFFFFFFFull), (unsigned) (a >> 32)};
+    const unsigned w[5] = {hist ? 1u : 0u, 0u, (unsigned) (a & 0xFFFFFFFFull), (unsigned) (a >> 32), hist ? (unsigned) (n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n) : 0u};   // (ctl[6]: capacity)
     return hipMemcpyAsync(g->ctl + 2, w, sizeof(w), hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
 }
 int p47_layers(void * h) { return ((P47Handle *) h)->n_layers; }

@@ -53,6 +53,9 @@ struct R6P {
     int dbg;                                           // timing experiment: 8 = the loader alone (every other wave leaves at once; results are WRONG)
     // the head projection folded in behind the last layer (F16 head.weight of a last stage; logits == nullptr: not this launch)
     float * logits; long long lnout_w, lnout_b; int n_vocab;
+    // embedding + ln0 in front of the first layer (tok != nullptr: the launch starts from the token id; rwkv_graph.inc:655-658) and the argmax of the
+    // logits behind the head (next_tok != nullptr; every launch publishes its workgroups' candidates at `am`, only launches with logits pick)
+    const unsigned * tok; unsigned * next_tok; const void * emb; int emb_f16; long long ln0_w, ln0_b; int am;
     long long * trace; int trace_layer;
 };
 
@@ -61,7 +64,9 @@ enum { FL_LANDED = 0, FL_SWB = 1, FL_SWE = 2 /* wide sweeps begun / ended (the l
        FL_RED1 = 16, FL_RED2 = 17, FL_PRO = 18, FL_KEYS = 19,
        FL_HX = 20, FL_HACT = 21, FL_HYQ = 22, FL_HKQ = 23, FL_HTL = 24 /* "some wave saw its sentinel turn" per gather kind */,
        FL_PROX = 25 /* consumer waves 4, 5 are done with their share of a prologue's elementwise part */,
-       FL_HWB = 26, FL_HWE = 27 /* sentinel watches begun / ended (p.hthin: the loader's depth while a wave of the workgroup watches a hand-over) */, FL_WORDS = 32 };
+       FL_HWB = 26, FL_HWE = 27 /* sentinel watches begun / ended (p.hthin: the loader's depth while a wave of the workgroup watches a hand-over) */,
+       FL_XRQ = 28 /* waves done with the deferred quantisation of the ffn receptance input (quant_xr) */,
+       FL_AM = 29 /* consumer waves that have left their argmax candidate in l.bc */, FL_WORDS = 32 };
 
 struct R6Lds { size_t x, q1, q2, u, tl, bc, red, out, dl, misc, fl, ring, fixed; };
 __host__ __device__ inline R6Lds r6_lds(int D, int F) {
@@ -319,7 +324,8 @@ struct R6 {
     // plain != nullptr (the first layer of a launch): the vector lies in plain memory (written before the launch) and is read in the same
     // unit-shaped pieces -- one code path, so that the layer loop has no separate "first layer" branch (around which the register allocator
     // spilled the record buffers that are reserved across it)
-    static __device__ __forceinline__ void gather_x(Poll & pl, xrsrc xr, int buf, unsigned tag, int g, int lane, float * lx, const float * plain = nullptr) {
+    // keep = true (the first layer behind an in-launch embedding): l.x already holds the vector, nothing is stored
+    static __device__ __forceinline__ void gather_x(Poll & pl, xrsrc xr, int buf, unsigned tag, int g, int lane, float * lx, const float * plain = nullptr, bool keep = false) {
         constexpr int N = NBLK * NC;
         const int i0 = g * 64 + lane;
         v4u v[XSL];
@@ -349,7 +355,7 @@ struct R6 {
 #pragma unroll
         for (int k = 0; k < XSL; k++) {
             const unsigned i = (unsigned) (i0 + k * NG * 64);
-            if (i < (unsigned) N) {
+            if (i < (unsigned) N && !keep) {
                 const unsigned b = (i * 43691u) >> 18;         // i / 6 for i < 2^16
                 const unsigned c = i - 6u * b;
                 float * dst = lx + b * RE + c;
@@ -403,13 +409,31 @@ struct R6 {
     // another wave of the workgroup has seen its own turn (LDS word); only then the wide sweeps start.
     // idle(): called once per watch round (the consumers use the wait to take their first record of the coming phase out of the ring
     // as soon as it has landed: rows_pre)
+    // The look at a sentinel: the tag word of one unit, the same address on every lane. R6_SWATCH = 1 reads it through the SCALAR memory path
+    // (s_load_dword glc: past the scalar cache, served by the L2 like an sc1 vector load) -- it does not queue in the CU's vector memory pipe
+    // behind the LDS-DMA fills and the sweeps (tools/watch_bench.hip: a chain of idle hand-overs 1.16 us each against 1.62 us).
+#ifndef R6_SWATCH
+#define R6_SWATCH 0
+#endif
+    static __device__ __forceinline__ bool look_turned(const Poll & pl, xrsrc xr, int unit, unsigned tag) {
+#if R6_SWATCH
+        const unsigned off = (unsigned) __builtin_amdgcn_readfirstlane(unit) * 16u + 12u;
+        const unsigned long long a = (unsigned long long) pl.xch;
+        const unsigned long long base = (unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) a) | ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (a >> 32)) << 32);
+        unsigned t;
+        asm volatile("s_load_dword %0, %1, %2 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(base), "s"(off) : "memory");
+        return (t & 0xFFFFu) == (tag & 0xFFFFu);
+#else
+        const v4u v = tg_load(xr, unit);
+        return __builtin_amdgcn_readfirstlane((int) tg_ok(v, tag)) != 0;
+#endif
+    }
     template <typename Idle>
     static __device__ __forceinline__ void gather_hint(Poll & pl, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap, Idle && idle) {
         for (unsigned spin = 0;; spin++) {
             if (fl_ld(go) >= gen || pl.dead) break;
             asm volatile("" ::: "memory");
-            const v4u v = tg_load(xr, unit);
-            if (__builtin_amdgcn_readfirstlane((int) tg_ok(v, tag))) { fl_st(go, gen); break; }
+            if (look_turned(pl, xr, unit, tag)) { fl_st(go, gen); break; }
             idle();
             if (poll_backoff(pl, spin)) break;
             for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
@@ -507,8 +531,9 @@ struct R6 {
         return 1.0f / sqrtf(var + 1e-5f);
     }
     // A: LN1 + token shift + maa_x mix + quantise -> l.q1
-    static __device__ __forceinline__ void prologue_A(Poll & pl, const Lds & l, const PA & pa, float * sout_l, bool write_state, int c, int lane, unsigned gen) {
-        const float scale = c < 4 ? ln_stats(pl, l, c * 64 + lane, lane, gen) : ln_scale(pl, l, lane, gen);
+    // (gen = prologues so far; eg = 1 when an embedding LayerNorm ran in front of them: the reduction counters are one round further)
+    static __device__ __forceinline__ void prologue_A(Poll & pl, const Lds & l, const PA & pa, float * sout_l, bool write_state, int c, int lane, unsigned gen, unsigned eg) {
+        const float scale = c < 4 ? ln_stats(pl, l, c * 64 + lane, lane, gen + eg) : ln_scale(pl, l, lane, gen + eg);
         if (c == 0 && lane == 0) l.misc[0] = scale;
         const QVec lq = qvec_at(l.q1, D);
 #pragma unroll
@@ -537,8 +562,8 @@ struct R6 {
         fl_add(l.fl + (c < 4 ? FL_PRO : FL_PROX), 1u);
     }
     // F: LN2 + token shift + the two mixes + quantise -> l.q1 (key input), l.q2 (receptance input)
-    static __device__ __forceinline__ void prologue_F(Poll & pl, const Lds & l, const PF & pf, float * sout_l, bool write_state, int c, int lane, unsigned gen) {
-        const float scale = c < 4 ? ln_stats(pl, l, c * 64 + lane, lane, gen) : ln_scale(pl, l, lane, gen);
+    static __device__ __forceinline__ void prologue_F(Poll & pl, const Lds & l, const PF & pf, float * sout_l, bool write_state, int c, int lane, unsigned gen, unsigned eg) {
+        const float scale = c < 4 ? ln_stats(pl, l, c * 64 + lane, lane, gen + eg) : ln_scale(pl, l, lane, gen + eg);
         const QVec qk = qvec_at(l.q1, D), qr = qvec_at(l.q2, D);
 #pragma unroll
         for (int u = 0; u < SMAX; u++) {
@@ -565,15 +590,64 @@ struct R6 {
             unsigned packed; float d16, s16; int isum;
             quant_vec4(xk, packed, d16, s16, isum);
             qvec_store4(qk, nb, i, packed, d16, s16, isum);
+            if constexpr (DEFER_XR) *reinterpret_cast<float4 *>(l.x + i) = make_float4(xr[0], xr[1], xr[2], xr[3]);   // (this thread is the only reader of these four elements from here on)
+            else { quant_vec4(xr, packed, d16, s16, isum); qvec_store4(qr, nb, i, packed, d16, s16, isum); }
+        }
+        fl_add(l.fl + (c < 4 ? FL_PRO : FL_PROX), 1u);
+    }
+    // The key rows need the key input only; the kq hand-over behind them is on the layer's critical path, the receptance rows are not
+    // (their results are used in the value rows' epilogue, a hand-over later). So the prologue leaves the receptance input as floats in
+    // l.x (in place of x - mean) and its quantisation -- a third of the prologue's arithmetic -- runs here, behind the wave's key rows,
+    // under the kq hand-over. Same statements on the same values: bit-identical.
+#ifndef R6_DEFER_XR
+#define R6_DEFER_XR 1
+#endif
+    static constexpr bool DEFER_XR = R6_DEFER_XR != 0;
+    static __device__ __forceinline__ void quant_xr(const Lds & l, int c, int lane) {
+        const QVec qr = qvec_at(l.q2, D);
+#pragma unroll
+        for (int u = 0; u < SMAX; u++) {
+            if (u >= pslots(c)) break;
+            const int i = pelem(c, lane, u);
+            const float4 xc = *reinterpret_cast<const float4 *>(l.x + i);
+            const float xr[4] = {xc.x, xc.y, xc.z, xc.w};
+            unsigned packed; float d16, s16; int isum;
             quant_vec4(xr, packed, d16, s16, isum);
             qvec_store4(qr, nb, i, packed, d16, s16, isum);
         }
-        fl_add(l.fl + (c < 4 ? FL_PRO : FL_PROX), 1u);
+        fl_add(l.fl + FL_XRQ, 1u);
     }
     // everything a prologue leaves in LDS is there (gen = prologues so far)
     static __device__ __forceinline__ void prologue_wait(Poll & pl, const Lds & l, unsigned gen) {
         fl_wait(pl, l.fl + FL_PRO, 4u * gen);
         if constexpr (SHI > 0) fl_wait(pl, l.fl + FL_PROX, 2u * gen);
+    }
+
+    // embedding row of the token + ln0 -> l.x (rwkv_graph.inc:655-658; the statements of k_embed_ln0 / block_layernorm in kernels.hip: the same
+    // 256 partials, the same tree). Consumer waves 0..3, thread pt owns elements pt, pt + 256, ... through all of it: no meeting but the two
+    // reduction rounds. The other gathering waves find l.x complete behind the first layer's gather_meet.
+    static __device__ __forceinline__ void embed_ln0(const R6P & p, Poll & pl, const Lds & l, const M6Arena & ar, int pt, int lane) {
+        constexpr int NP = D / 256;
+        const unsigned tk = p.tok[0];
+        const long long row = tk < (unsigned) p.n_vocab ? (long long) tk : 0ll;   // (host-side token ids are range-checked by the API; this guards device-side ones)
+        const float * w0 = ar.f(p.ln0_w), * b0 = ar.f(p.ln0_b);
+        float wv[NP], bv[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const int e = pt + 256 * j;
+            l.x[e] = p.emb_f16 ? h2f_bits(reinterpret_cast<const uint16_t *>(p.emb)[row * D + e]) : reinterpret_cast<const float *>(p.emb)[row * D + e];
+            wv[j] = w0[e]; bv[j] = b0[e];
+        }
+        const float scale = ln_stats(pl, l, pt, lane, 1u);
+#pragma unroll
+        for (int j = 0; j < NP; j++) { const int e = pt + 256 * j; const float y = l.x[e] * scale; const float yw = y * wv[j]; l.x[e] = yw + bv[j]; }
+    }
+
+    // argmax candidates: greater value, then smaller index (k_argmax's rule in kernels.hip; NaN never wins)
+    static __device__ __forceinline__ void am_merge(float & best, int & bi, float ov, int oi) { if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } }
+    static __device__ __forceinline__ void am_wave(float & best, int & bi) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(best, o, WAVE); const int oi = __shfl_xor(bi, o, WAVE); am_merge(best, bi, ov, oi); }
     }
 
     // -----------------------------------------------------------------------------------------------------------
@@ -847,8 +921,7 @@ struct R6 {
                     // a landed record is taken at once -- except that every `look`-th take in a row is preceded by a look at the sentinel
                     if (landed && (spin > 0u || (unsigned) t % look != 0u)) { here = true; break; }
                     asm volatile("" ::: "memory");
-                    const v4u v = tg_load(xr, unit);
-                    if (__builtin_amdgcn_readfirstlane((int) tg_ok(v, tag))) { fl_st(go, gen); turned = true; break; }
+                    if (look_turned(pl, xr, unit, tag)) { fl_st(go, gen); turned = true; break; }
                     if (landed) { here = true; break; }
                     if (poll_backoff(pl, spin)) { turned = true; break; }
                     for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
@@ -979,6 +1052,14 @@ struct R6 {
     static constexpr int NPK = npcap((PRE_MASK & 4) ? R6_NPK : (Q8 ? 1 : 2), TFK);
     static constexpr int NPR = npcap((PRE_MASK & 128) ? 3 : (Q8 ? 1 : 2), TFE);
     static constexpr int NPG = npcap((PRE_MASK & 8) ? R6_NPG : 1, TFE);
+    // value records are taken ahead where one fits 48 registers (not Q8_0's 63 at F = 14336). Rounds 4 and 5 tested sizeof(RawRec) <= 192 here:
+    // the 16-byte aligned code vectors pad every block to 32 bytes, 7 blocks = 224, and the take was off for EVERY format at the 7B geometry
+    // (tools/trace_ring.py, "records already in registers": G 0.00) -- R6_G_PRE_OLD=1 rebuilds that.
+#ifndef R6_G_PRE_OLD
+#define R6_G_PRE_OLD 0
+#endif
+    static constexpr int rec_regs(int R, int U) { return U * R * (QF<FMT>::QS / 4 + 1 + (QF<FMT>::QH ? 1 : 0)); }
+    static constexpr bool G_PRE = R6_G_PRE_OLD ? sizeof(RawRec<FMT, 1, UF>) <= 48 * 4 : rec_regs(1, UF) <= 48;
 
     static __device__ __forceinline__ void consumer_main(const R6P & p, const Lds & l, int lane, int wave, unsigned base) {
         const int blk = blockIdx.x;
@@ -987,7 +1068,7 @@ struct R6 {
         // (The prologue parameters are loaded by EVERY consumer wave, also where waves 4, 5 take no part: a load under `if (pro)` is a
         //  conditional definition, and the compiler then waits for it and copies it right where it is issued.)
         const int F = p.F, nbF = F / 32;
-        Poll pl{p.ctl, false};
+        Poll pl{p.ctl, false, p.xch};
         const M6Arena ar{p.arena};
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         const RingShape sh = shape(p);
@@ -1005,6 +1086,9 @@ struct R6 {
         float xown[XT], rrow[XT];
 #pragma unroll
         for (int t = 0; t < XT; t++) { const int row = c + NC * t; xown[t] = row < RE ? p.x[blk * RE + row] : 0.0f; rrow[t] = 0.0f; }
+        const bool emb_in = p.tok != nullptr;          // the launch starts from the token id (wave-uniform)
+        const unsigned eg = emb_in ? 1u : 0u;
+        if (emb_in && c < 4) embed_ln0(p, pl, l, ar, c * 64 + opq(lane), opq(lane));
         // Where the prologue parameters are loaded (LayerNorm affine, token-shift source, mix weights: 4 / 5 float4 per slot and thread).
         // R6_LATE_PARAMS = 0 (round 3): a whole phase ahead -- 48 / 60 registers live across a hand-over wait. 1: at the start of the
         // prologue, in flight under the LayerNorm statistics (two reduction rounds, ~1 us; the lines are the same for every workgroup:
@@ -1033,6 +1117,7 @@ struct R6 {
             cs.next_block = li + 1 < p.n_layers ? cs.lbase + cs.cu.layer_bytes + first_own : head_first;
             R6STAMP(0);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 23] = cs.waited;
+            unsigned havepk = 0u;   // (tracing) records of each row phase already in registers when the phase starts, 4 bits per phase
             Pre<1, UD, 1> pw;
             pre_begin<RG_W1>(cs, pw);
             Pre<2, UD, NPC> pc;
@@ -1049,15 +1134,21 @@ struct R6 {
                 watch_end(l);
                 if (R6_LATE_PARAMS == 2 && !PA_EARLY) { issue_pa(pa, ar, L, sin_l, c, opq(lane)); __builtin_amdgcn_sched_barrier(0); }
                 sweep_begin(l);
-                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, c, opq(lane), l.x, first ? p.x : nullptr);
+                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, c, opq(lane), l.x, first ? p.x : nullptr, first && emb_in);
             }
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
             sweep_end(l);
             R6STAMP(1);
+            {   // behind an in-launch embedding the residual rows of this wave start from l.x (a select, not a branch: see gather_x)
+                const bool take = li == 0 && emb_in;
+#pragma unroll
+                for (int t = 0; t < XT; t++) { const int row = c + NC * t; const float v = l.x[blk * RE + (row < RE ? row : 0)]; xown[t] = take ? v : xown[t]; }
+            }
             if (R6_LATE_PARAMS == 1) { issue_pa(pa, ar, L, sin_l, c, opq(lane)); __builtin_amdgcn_sched_barrier(0); }
-            if (pro) prologue_A(pl, l, pa, sout_l, blk == 0, c, opq(lane), 2u * li + 1u);
+            if (pro) prologue_A(pl, l, pa, sout_l, blk == 0, c, opq(lane), 2u * li + 1u, eg);
             prologue_wait(pl, l, 2u * li + 1u);
             R6STAMP(2);
+            havepk |= pw.have;
             rows<RG_W1, 1, UD, 0, 1>(cs, pl, l, qvec_at(l.q1, D), nb, pw, [&](auto, int j, const float (&res)[1]) {
                 if (lane == 0) tg_store(xr, p.tl + blk + NBLK * j, __float_as_uint(det_tanhf(res[0])), 0u, 0u, 0u, tagL + SLOT_TL);
             });
@@ -1087,6 +1178,7 @@ struct R6 {
                 const int j0 = (int) rg_first_j(cs.cu, RG_C, c);
                 if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 20] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_C]);
                 R6RSTAMP(26);
+                havepk |= pc.have << 4;
                 rows<RG_C, 2, UD, NSET / NC, NPC>(cs, pl, l, qvec_at(l.act, D), nb, pc, [&](auto tc, int, const float (&res)[2]) {
                     constexpr int t = decltype(tc)::value;
                     all[2 * t] = res[0]; all[2 * t + 1] = res[1];
@@ -1116,6 +1208,7 @@ struct R6 {
             gather_meet(pl, l.fl + FL_GYQ, g1);
             sweep_end(l);
             R6STAMP(6);
+            havepk |= pe.have << 8;
             rows<RG_E, 1, UD, RE / NC, NPE>(cs, pl, l, qvec_at(l.yq, D), nb, pe, [&](auto tc, int, const float (&res)[1]) {
                 constexpr int t = decltype(tc)::value;
                 xown[t] = xown[t] + res[0];
@@ -1133,16 +1226,21 @@ struct R6 {
             sweep_end(l);
             R6STAMP(8);
             if (R6_LATE_PARAMS == 1) { issue_pf(pf, ar, L, sin_l, c, opq(lane)); __builtin_amdgcn_sched_barrier(0); }
-            if (pro) prologue_F(pl, l, pf, sout_l, blk == 0, c, opq(lane), 2u * li + 2u);
+            if (pro) prologue_F(pl, l, pf, sout_l, blk == 0, c, opq(lane), 2u * li + 2u, eg);
             prologue_wait(pl, l, 2u * li + 2u);
             R6STAMP(9); R6RSTAMP(28);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 21] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_FK]);
+            havepk |= (pk.have << 12) | (pr.have << 16);
             rows<RG_FK, 2, UD, TFK, NPK>(cs, pl, l, qvec_at(l.q1, D), nb, pk, [&](auto, int j, const float (&res)[2]) {
                 const float v = lane == 1 ? res[1] : res[0];
                 const float t = v > 0.0f ? v : 0.0f;
                 if (lane < 2) l.out[2 * j + lane] = t * t;
             });
             fl_add(l.fl + FL_KEYS, 1u);
+            if constexpr (DEFER_XR) {
+                if (pro) quant_xr(l, c, opq(lane));
+                fl_wait(pl, l.fl + FL_XRQ, (unsigned) (SHI > 0 ? NC : 4) * g1);
+            }
             R6STAMP(10);
             rows<RG_FR, 1, UD, RE / NC, NPR>(cs, pl, l, qvec_at(l.q2, D), nb, pr, [&](auto tc, int, const float (&res)[1]) {
                 constexpr int t = decltype(tc)::value;
@@ -1154,7 +1252,7 @@ struct R6 {
             pre_begin<RG_G>(cs, pg);
             // (registers: not the long Q8_0 rows of the 7B geometry)
             watch_begin(l);
-            hint_take(cs, pl, l, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap, (PRE_MASK & 8) != 0 && sizeof(RawRec<FMT, 1, UF>) <= 48 * 4, pg);
+            hint_take(cs, pl, l, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap, (PRE_MASK & 8) != 0 && G_PRE, pg);
             watch_end(l);
             sweep_begin(l);
             gather_qvec<KSL>(pl, xr, p.kq, F, tagL + SLOT_KQ, c, opq(lane), l.kq);
@@ -1162,6 +1260,7 @@ struct R6 {
             sweep_end(l);
             R6STAMP(12); R6RSTAMP(30);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 22] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_G]);
+            havepk |= pg.have << 20;
             rows<RG_G, 1, UF, RE / NC, NPG>(cs, pl, l, qvec_at(l.kq, F), nbF, pg, [&](auto tc, int j, const float (&res)[1]) {
                 constexpr int t = decltype(tc)::value;
                 const float gte = sigmoid_f(rrow[t]) * res[0];
@@ -1170,7 +1269,7 @@ struct R6 {
             });
             if (lane == 0) tg_store(xr, p.xffn + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
             R6STAMP(13); R6RSTAMP(14);
-            if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 25] = cs.waited;
+            if (p.trace && li == p.trace_layer && lane == 0) { p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 25] = cs.waited; p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 15] = (long long) havepk; }
             __builtin_amdgcn_sched_barrier(0);   // (the loads below stay behind the value rows: hoisted into them they cost 48 registers at the kernel's peak)
             if (PA_EARLY) {   // the next layer's prologue parameters: in flight while this wave watches the x hand-over's sentinel (not across G: registers)
                 // (unconditionally -- behind the last layer the same layer's again: under `if (li + 1 < n_layers)` the parameters are
@@ -1180,7 +1279,7 @@ struct R6 {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (p.logits) head_phase(p, l, cs, pl, xr, ar, hd, hbase, lane, wave, base);
+        if (p.logits) head_phase(p, l, cs, pl, xr, ar, hd, hbase, lane, wave, base, eg);
     }
 
     // -----------------------------------------------------------------------------------------------------------
@@ -1189,7 +1288,7 @@ struct R6 {
     // folded 16 / 8 / 4, (p0 + p1) + (p2 + p3) -- the order of k_mvf in kernels.hip: four lanes per row, lane q holds partials 8 q .. 8 q + 7)
     // -----------------------------------------------------------------------------------------------------------
     static __device__ __forceinline__ void head_phase(const R6P & p, const Lds & l, Cons & cs, Poll & pl, xrsrc xr, const M6Arena & ar, const RingHead & hd,
-                                                      unsigned hbase, int lane, int wave, unsigned base) {
+                                                      unsigned hbase, int lane, int wave, unsigned base, unsigned eg) {
         const int blk = blockIdx.x, c = cs.c, li = p.n_layers;       // (li: the layer index the stamps and generations continue with)
         const unsigned tagL = base + (unsigned) li * 8u;
         const int pt = c * 64 + lane;
@@ -1204,7 +1303,7 @@ struct R6 {
         sweep_end(l);
         R6STAMP(1);
         if (c < 4) {
-            const float scale = ln_stats(pl, l, pt, lane, 2u * li + 1u);
+            const float scale = ln_stats(pl, l, pt, lane, 2u * li + 1u + eg);
             const float * lw = ar.f(p.lnout_w), * lb = ar.f(p.lnout_b);
 #pragma unroll
             for (int u = 0; u < (D + 1023) / 1024; u++) {
@@ -1229,6 +1328,7 @@ struct R6 {
         const int ln = opq(lane), q = ln & 3;
         constexpr int CHK = nb / RG_HSTEPS;      // records per row group
         if (c >= hd.hg) { asm volatile("" ::: "memory"); __hip_atomic_store(dn, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        float am_best = -INFINITY; int am_i = 0x7fffffff;   // this lane's argmax candidate over the rows it finishes (q == 0 lanes)
         for (int ps = 0; ps < hd.passes; ps++) {
             const int g = RG_NC * ps + c;
             if (g >= hd.hg) break;
@@ -1283,9 +1383,14 @@ struct R6 {
 #pragma unroll
             for (int e = 0; e < 4; e++) ps8[e] += ps8[e + 4];
             const float r = (ps8[0] + ps8[1]) + (ps8[2] + ps8[3]);
-            if (q == 0) p.logits[(long long) blk * hd.hg * 16 + g * 16 + (ln >> 2)] = r;
+            const int vrow = blk * hd.hg * 16 + g * 16 + (ln >> 2);
+            if (q == 0) { p.logits[vrow] = r; if (r > am_best) { am_best = r; am_i = vrow; } }   // (rows come in increasing order per lane: ties keep the smaller index)
             if (ps < 4) R6STAMP(3 + ps);
         }
+        // this wave's candidate -> l.bc[c]; the comm wave merges the six and publishes the workgroup's (tail_argmax)
+        am_wave(am_best, am_i);
+        if (ln == 0) { l.bc[2 * c] = am_best; l.bc[2 * c + 1] = __int_as_float(am_i); }
+        fl_add(l.fl + FL_AM, 1u);
         R6STAMP(7); R6RSTAMP(17);
         if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 21] = waited;
     }
@@ -1299,7 +1404,7 @@ struct R6 {
         const int g = NC;                              // gather share
         const int F = p.F, DR = p.DR, R = p.R, H = p.H;
         const int nbF = F / 32;
-        Poll pl{p.ctl, false};
+        Poll pl{p.ctl, false, p.xch};
         const M6Arena ar{p.arena};
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         const int mat = (blk * (4 * D / NBLK)) / D;
@@ -1329,7 +1434,7 @@ struct R6 {
                 if (!first) gather_hint(pl, xr, p.xffn + ((blk * 37 + g * 211) & 1023), tagL - 8u + SLOT_XFFN, l.fl + FL_HX, 2u * li + 1u, p.nap);
                 watch_end(l);
                 sweep_begin(l);
-                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, g, opq(lane), l.x, first ? p.x : nullptr);
+                gather_x(pl, xr, p.xffn, tagL - 8u + SLOT_XFFN, g, opq(lane), l.x, first ? p.x : nullptr, first && p.tok != nullptr);
             }
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
             sweep_end(l);
@@ -1374,7 +1479,7 @@ struct R6 {
                     csx[q] = cpv[q] - cxn[q];
                 }
                 watch_begin(l);
-                gather_hint(pl, xr, p.tl + ((blk * 7) & 127), tagL + SLOT_TL, l.fl + FL_HTL, g1, p.nap);   // (one unit first, then the sweep)
+                if (!(p.dbg & 128)) gather_hint(pl, xr, p.tl + ((blk * 7) & 127), tagL + SLOT_TL, l.fl + FL_HTL, g1, p.nap);   // (one unit first, then the sweep; RWKV_MI_RING_DBG bit 7: the sweep at once -- one wave per workgroup, 5 KB per attempt)
                 poll_units<5, 64>(pl, xr, p.tl, 5 * R, tagL + SLOT_TL, ln, [&](int i, const v4u & v) { l.tl[i] = __uint_as_float(v.x); });
                 watch_end(l);
                 __builtin_amdgcn_wave_barrier();
@@ -1629,6 +1734,44 @@ struct R6 {
             gather_meet(pl, l.fl + FL_GX, 2u * li + 1u);
             sweep_end(l);
         }
+        tail_argmax(p, l, pl, xr, opq(lane), base);
+    }
+
+    // argmax of the logits inside the launch (k_argmax's rule; persist_v47.hip's tail): the six consumer waves leave their candidates in
+    // l.bc, this wave merges them and publishes the workgroup's as ONE unit under slot 7 of the last layer's tags; workgroup 0 gathers the
+    // 256 units and writes the token where the next launch's embedding reads it (and into the greedy loops' history: ctl[2..6]).
+    // EVERY launch publishes its units (without logits: an empty candidate), so the stale content of the buffer is always the previous
+    // launch's -- a launch 65536 / (8 layers) tokens back would carry the same 16-bit tag.
+    static __device__ __forceinline__ void tail_argmax(const R6P & p, const Lds & l, Poll & pl, xrsrc xr, int lane, unsigned base) {
+        const int blk = blockIdx.x;
+        const unsigned tagA = base + (unsigned) (p.n_layers - 1) * 8u + 7u;
+        float b = -INFINITY; int bi = 0x7fffffff;
+        if (p.logits) {
+            fl_wait(pl, l.fl + FL_AM, (unsigned) NC);
+            if (lane < NC) { b = l.bc[2 * lane]; bi = __float_as_int(l.bc[2 * lane + 1]); }
+            am_wave(b, bi);
+        }
+        if (lane == 0) tg_store(xr, p.am + blk, __float_as_uint(b), (unsigned) bi, 0u, 0u, tagA);
+        if (!p.logits || !p.next_tok || blk != 0) return;
+        int ptr[NBLK / 64]; bool valid[NBLK / 64]; v4u dv[NBLK / 64];
+#pragma unroll
+        for (int k = 0; k < NBLK / 64; k++) { ptr[k] = p.am + lane + 64 * k; valid[k] = true; }
+        poll_ptrs<NBLK / 64>(pl, xr, ptr, valid, tagA, dv);
+        float b3 = -INFINITY; int i3 = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < NBLK / 64; k++) am_merge(b3, i3, __uint_as_float(dv[k].x), (int) dv[k].y);
+        am_wave(b3, i3);
+        if (lane == 0) {
+            // (no element compared greater than -inf: every logit is NaN or -inf -- the token feeds the next embedding lookup and must stay a row of the table)
+            const unsigned tokn = i3 == 0x7fffffff ? 0u : (unsigned) i3;
+            p.next_tok[0] = tokn;
+            if (p.ctl[2] != 0u) {   // greedy loops: history pointer ctl[4..5], position ctl[3], capacity ctl[6]
+                unsigned * hist = reinterpret_cast<unsigned *>((unsigned long long) p.ctl[4] | ((unsigned long long) p.ctl[5] << 32));
+                const unsigned pos = p.ctl[3];
+                if (pos < p.ctl[6]) hist[pos] = tokn;
+                p.ctl[3] = pos + 1u;
+            }
+        }
     }
 };
 
@@ -1755,7 +1898,9 @@ struct RingShared {
     uint64_t bytes = 0;
     bool head = false;            // the head projection is folded into the launch (F16 head.weight, vocabulary a multiple of 4096)
     uint64_t bytes_head = 0;      // its algorithmic bytes: head.weight, ln_out, the logits written
-    long long lnw_off = 0, lnb_off = 0;
+    bool embed = false;           // embedding + ln0 are folded into the launch (F16 / F32 emb.weight of a stage that owns it)
+    uint64_t bytes_embed = 0;     // one row of emb.weight + ln0
+    long long lnw_off = 0, lnb_off = 0, ln0w_off = 0, ln0b_off = 0;
     int64_t D = 0, F = 0, DR = 0, R = 0;
 };
 
@@ -1915,6 +2060,16 @@ static RingShared * ring_shared_build(const Model & m) {
         bytes += 2 * (uint64_t) m.state_per_layer() * sizeof(float);
     }
     rs->bytes = bytes;
+    {
+        const char * nf = getenv("RWKV_MI_RING_NO_EMBED");   // (measurement aid: the embedding and the argmax as their own launches, as up to round 5)
+        if (!(nf && nf[0] == '1') && m.has_embed && m.emb && m.ln0_w && m.ln0_b && (m.emb->type == T_F16 || m.emb->type == T_F32) && in_arena) {
+            rs->embed = true;
+            rs->ln0w_off = off(m.ln0_w->data); rs->ln0b_off = off(m.ln0_b->data);
+            rs->bytes_embed = (uint64_t) D * (m.emb->type == T_F16 ? 2 : 4) + m.ln0_w->nbytes + m.ln0_b->nbytes;
+            if (!in_arena) rs->embed = false;
+            in_arena = true;   // (ln0 outside the arena only switches the fold off)
+        }
+    }
     if (fold_head && in_arena) {
         rs->lnw_off = off(m.ln_out_w->data); rs->lnb_off = off(m.ln_out_b->data);
         const RingHead hd = rg_head((int) m.n_vocab(), (int) D);
@@ -1968,11 +2123,11 @@ void * ring_v6_create(const Model & m) {
     const int64_t PAD = 2048;   // polls read whole rounds of 7 x 64 lanes: keep every buffer readable past its end
     auto up = [](int64_t v) { return (v + 63) / 64 * 64; };
     const int64_t act_stride = up(3 * nbD), xunits = up(RG_NBLK * RG_NC);
-    const int64_t sizes[8] = {up(1280) + PAD, 5 * act_stride + PAD, 2 * D + PAD, 256 + PAD, act_stride + PAD, xunits + PAD, up(3 * nbF) + PAD, xunits + PAD};
+    const int64_t sizes[9] = {up(1280) + PAD, 5 * act_stride + PAD, 2 * D + PAD, 256 + PAD, act_stride + PAD, xunits + PAD, up(3 * nbF) + PAD, xunits + PAD, up(RG_NBLK) + PAD};
     int64_t units = 0;
     for (int64_t z : sizes) units += z;
     bool ok = hipMalloc(&rg->xch, (size_t) units * 16) == hipSuccess && hipMemset(rg->xch, 0, (size_t) units * 16) == hipSuccess
-      && hipMalloc((void **) &rg->ctl, 256) == hipSuccess
+      && hipMalloc((void **) &rg->ctl, 256) == hipSuccess && hipMemset(rg->ctl, 0, 256) == hipSuccess   // (ctl[2..6]: the greedy history words)
       && hipHostMalloc((void **) &rg->h_ctl, 64, hipHostMallocDefault) == hipSuccess;
     if (ok) { rg->h_ctl[0] = 8u; rg->h_ctl[1] = 0u; }
     const unsigned init[2] = {8u, 0u};
@@ -1984,8 +2139,8 @@ void * ring_v6_create(const Model & m) {
     q.state_stride = m.state_per_layer();
     q.xch = rg->xch; q.xch_bytes = (unsigned) (units * 16);
     int u = 0;
-    int * slots[8] = {&q.tl, &q.act5, &q.rkvg, &q.dl, &q.yq, &q.xatt, &q.kq, &q.xffn};
-    for (int i = 0; i < 8; i++) { *slots[i] = u; u += (int) sizes[i]; }
+    int * slots[9] = {&q.tl, &q.act5, &q.rkvg, &q.dl, &q.yq, &q.xatt, &q.kq, &q.xffn, &q.am};
+    for (int i = 0; i < 9; i++) { *slots[i] = u; u += (int) sizes[i]; }
     q.act_stride = (int) act_stride;
     q.ctl = rg->ctl;
     q.stream = rs->stream; q.cus = rs->d_cus;
@@ -1997,6 +2152,7 @@ void * ring_v6_create(const Model & m) {
     q.head_wg0 = env_int("RWKV_MI_RING_HEAD_WG", NB / 2);
     if (q.head_wg0 < 0 || q.head_wg0 + (int) m.head_count > NB) q.head_wg0 = 0;
     q.logits = nullptr; q.lnout_w = rs->lnw_off; q.lnout_b = rs->lnb_off; q.n_vocab = (int) m.n_vocab();
+    q.tok = nullptr; q.next_tok = nullptr; q.emb = rs->embed ? m.emb->data : nullptr; q.emb_f16 = (rs->embed && m.emb->type == T_F16) ? 1 : 0; q.ln0_w = rs->ln0w_off; q.ln0_b = rs->ln0b_off;
     auto snap = [](int w) { w &= ~3; return w < 4 ? 4 : (w > 52 ? 52 : w); };
     q.inflight = snap(env_int("RWKV_MI_RING_INFLIGHT", 48));
     q.thin = snap(env_int("RWKV_MI_RING_THIN", 16));
@@ -2033,19 +2189,32 @@ uint64_t ring_v6_bytes(void * h) { return ((RingV6 *) h)->sh->bytes; }
 bool ring_v6_folds_head(void * h) { return ((RingV6 *) h)->sh->head; }
 
 // logits != nullptr (only when ring_v6_folds_head): ln_out + head run inside the launch and the logits land there
-void ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits) {
-    ring_v6_forward_range(h, x, sin, sout, st, pf, logits, 0, ((RingV6 *) h)->sh->n_layers);
+void ring_v6_forward(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, const uint32_t * tok, uint32_t * next_tok) {
+    ring_v6_forward_range(h, x, sin, sout, st, pf, logits, 0, ((RingV6 *) h)->sh->n_layers, tok, next_tok);
+}
+bool ring_v6_folds_embed(void * h) { return ((RingV6 *) h)->sh->embed; }
+bool ring_v6_folds_argmax(void * h) { return ((RingV6 *) h)->sh->head; }
+// greedy loops: the kernel appends every token it picks to hist (device memory, n entries) from position 0; nullptr switches it off
+bool ring_v6_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st) {
+    RingV6 * rg = (RingV6 *) h;
+    const unsigned long long a = (unsigned long long) hist;
+    const unsigned w[5] = {hist ? 1u : 0u, 0u, (unsigned) (a & 0xFFFFFFFFull), (unsigned) (a >> 32), hist ? (unsigned) (n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n) : 0u};
+    return hipMemcpyAsync(rg->ctl + 2, w, sizeof(w), hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
 }
 
 // Layers [l0, l1) of the stage in one launch (sin / sout: state of the stage's FIRST layer; x: the residual stream in plain memory, read
 // by the first and written by the last layer of the launch). logits (only with l1 == the stage's last layer): ln_out + head inside.
-void ring_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1) {
+// tok (only with l0 == 0 and ring_v6_folds_embed): the launch starts from the token id; next_tok (only with logits): where the argmax of the logits lands.
+void ring_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1,
+                           const uint32_t * tok, uint32_t * next_tok) {
     RingV6 * rg = (RingV6 *) h;
     R6P q = rg->proto;
     q.x = x;
+    q.tok = (rg->sh->embed && l0 == 0) ? tok : nullptr;
     q.layers = rg->sh->d_layers + l0; q.n_layers = l1 - l0; q.layer0 = l0; q.layers_total = rg->sh->n_layers;
     q.sin = sin + (long long) l0 * q.state_stride; q.sout = sout + (long long) l0 * q.state_stride;
     q.logits = (rg->sh->head && l1 == rg->sh->n_layers) ? logits : nullptr;
+    q.next_tok = q.logits ? next_tok : nullptr;
     const RingKernel fn = g_ring_variants[rg->sh->variant].fn;
     if (pf && pf->on) {
         if (pf->used * 2 + 2 > pf->events.size()) {
@@ -2053,7 +2222,7 @@ void ring_v6_forward_range(void * h, float * x, const float * sin, float * sout,
             (void) hipEventCreate(&a); (void) hipEventCreate(&c);
             pf->events.push_back(a); pf->events.push_back(c); pf->bytes.push_back(0);
         }
-        pf->bytes[pf->used] = rg->sh->bytes * (uint64_t) (l1 - l0) / (uint64_t) rg->sh->n_layers + (q.logits ? rg->sh->bytes_head : 0);
+        pf->bytes[pf->used] = rg->sh->bytes * (uint64_t) (l1 - l0) / (uint64_t) rg->sh->n_layers + (q.logits ? rg->sh->bytes_head : 0) + (q.tok ? rg->sh->bytes_embed : 0);
         hipExtLaunchKernelGGL(fn, dim3((unsigned) rg->sh->n_blocks), dim3(512), (uint32_t) rg->sh->lds, st, pf->events[pf->used * 2], pf->events[pf->used * 2 + 1], 0, q);
         pf->used++;
     } else {

@@ -40,6 +40,10 @@ print('comm D.head on the head workgroups (%d of them, first %d):' % (len(hw), h
 if os.environ.get('RWKV_MI_RING_DBG', '0') != '0' and int(os.environ['RWKV_MI_RING_DBG']) & 16:
     pr = t[:, 2:, 16:20]
     print('C.rows split (cycles, mean over consumer waves): load+wait %.0f  arithmetic+butterfly %.0f  epilogue %.0f' % (pr[:, :, 0].mean(), pr[:, :, 2].mean(), pr[:, :, 3].mean()))
+hv = t[:, 2:, 15].astype(np.int64)
+print('records already in registers at the start of a row phase (mean over workgroups, by consumer):')
+for nm, sh in (('W1', 0), ('C', 4), ('E', 8), ('FK', 12), ('FR', 16), ('G', 20)):
+    print('   %-3s' % nm, ' '.join('%.2f' % ((hv[:, c] >> sh) & 15).mean() for c in range(6)))
 ah = t[:, 2:, 20:23] / 1024
 print('loader ahead of the phase start when the consumers begin (KiB, mean / min / max): C %.0f %.0f %.0f   keys %.0f %.0f %.0f   G %.0f %.0f %.0f' % (ah[:, :, 0].mean(), ah[:, :, 0].min(), ah[:, :, 0].max(), ah[:224, :, 1].mean(), ah[:224, :, 1].min(), ah[:224, :, 1].max(), ah[:, :, 2].mean(), ah[:, :, 2].min(), ah[:, :, 2].max()))
 ld = t[:, 0, :4]
