@@ -44,7 +44,20 @@ enum { RG_W1 = 0, RG_C = 1, RG_DW1 = 2, RG_E = 3, RG_FK = 4, RG_FR = 5, RG_G = 6
 struct RingShape {
     int D, F, R5, DR;        // n_embed, ffn size, 5 x mix rank (rows of time_maa_w1), decay rank (rows of time_decay_w1)
     int qs, scb, qhb;        // bytes per block: codes (16 | 32), scales (2 | 4), fifth bits (0 | 4)
+    int bal = 0;             // 1: the two-row sets of C and FK are dealt to the consumer waves by SIMD share (RG_BAL_*; D = 4096 only)
 };
+
+// Which consumer wave takes which record. Default: record j of a phase -> consumer (j + rot) % 6, a wave's records are six apart.
+// Round 6 (profiles/r06_*_cp_*: real-time stamps per wave): the eight waves of a workgroup sit two per SIMD -- (loader, c2), (comm, c3),
+// (c0, c4), (c1, c5) -- and a SIMD issues for its OLDER wave first: c4 and c5 finish every row phase last (C rows 3.4 us against 2.4), and
+// the hand-over behind a phase waits for the last wave of 1536. A SIMD with two consumers retires a two-row record every ~800 cycles,
+// a consumer beside the loader or the comm wave one every ~1000: 32 sets are dealt 5 5 7 7 4 4 (9 per shared SIMD, 7 per single), the
+// 30 streamed key sets 5 5 6 6 4 4. Per PAIR of consumers (c >> 1) the record numbers of the even one; the odd one takes the next record.
+constexpr int RG_BAL_C_N[3] = {5, 7, 4};
+constexpr int RG_BAL_C_J[3][7] = {{2, 8, 14, 22, 28, 99, 99}, {0, 6, 10, 16, 20, 24, 30}, {4, 12, 18, 26, 99, 99, 99}};
+constexpr int RG_BAL_K_N[3] = {5, 6, 4};
+constexpr int RG_BAL_K_J[3][7] = {{2, 8, 14, 20, 26, 99, 99}, {0, 6, 12, 16, 22, 28, 99}, {4, 10, 18, 24, 99, 99, 99}};
+constexpr int RG_BAL_C_SETS = 32, RG_BAL_K_SETS = 30, RG_BAL_TMAX = 7;
 
 RG_HD int rg_steps(int K) { return (K / 32 + 63) / 64; }
 RG_HD uint32_t rg_rec_bytes(const RingShape & s, int R, int K) { return (uint32_t) (rg_steps(K) * R * 64 * (s.qs + s.scb + s.qhb)); }
@@ -74,6 +87,7 @@ struct RingCu {
     uint32_t rec[RG_NPHASE];   // bytes per record
     uint32_t off[RG_NPHASE];   // offset of the phase's first record in the layer block
     uint32_t rot[RG_NPHASE];   // record j -> consumer (j + rot) % RG_NC
+    uint32_t bal[RG_NPHASE];   // 0: the rot mapping; 1: RG_BAL_C; 2: RG_BAL_K
     uint32_t layer_bytes;
 };
 
@@ -96,7 +110,9 @@ RG_HD RingCu rg_cu(const RingShape & s, int b) {
     // with the loader and the comm wave, not with another consumer); the decay row goes to a wave with the fewest r/k/v/g sets
     c.rot[RG_W1] = 0; c.rot[RG_DW1] = RG_NC - 1; c.rot[RG_C] = 2; c.rot[RG_E] = 0; c.rot[RG_FK] = (rg_key_sets(s, b) - rg_key_comm(s, b)) % RG_NC ? 2 : 0; c.rot[RG_FR] = 0; c.rot[RG_G] = 0;
     uint32_t p = 0;
-    for (int ph = 0; ph < RG_NPHASE; ph++) { c.off[ph] = p; p += c.n[ph] * c.rec[ph]; }
+    for (int ph = 0; ph < RG_NPHASE; ph++) { c.off[ph] = p; p += c.n[ph] * c.rec[ph]; c.bal[ph] = 0; }
+    if (s.bal && c.n[RG_C] == (uint32_t) RG_BAL_C_SETS) c.bal[RG_C] = 1;
+    if (s.bal && c.n[RG_FK] == (uint32_t) RG_BAL_K_SETS) c.bal[RG_FK] = 2;
     c.layer_bytes = p;
     return c;
 }
@@ -116,8 +132,23 @@ RG_HD RingRec rg_rec(const RingShape & s, int b, int phase, int j) {
     return r;
 }
 
-// first record of consumer c in a phase (its records are j0, j0 + RG_NC, ... < n)
-RG_HD uint32_t rg_first_j(const RingCu & c, int phase, int cons) { return (uint32_t) ((cons + RG_NC - (int) c.rot[phase] % RG_NC) % RG_NC); }
+// record number of consumer cons' t-th record of a phase (>= n[phase]: it has no t-th), and how many it has
+RG_HD uint32_t rg_own_j(const RingCu & c, int phase, int cons, int t) {
+    if (c.bal[phase]) {
+        const int pr = cons >> 1;
+        if (t >= RG_BAL_TMAX) return 0xFFFFu;
+        const int j = c.bal[phase] == 1 ? RG_BAL_C_J[pr][t] : RG_BAL_K_J[pr][t];
+        return j >= 99 ? 0xFFFFu : (uint32_t) (j + (cons & 1));
+    }
+    return (uint32_t) ((cons + RG_NC - (int) c.rot[phase] % RG_NC) % RG_NC) + (uint32_t) (RG_NC * t);
+}
+RG_HD uint32_t rg_own_count(const RingCu & c, int phase, int cons) {
+    if (c.bal[phase]) return (uint32_t) (c.bal[phase] == 1 ? RG_BAL_C_N[cons >> 1] : RG_BAL_K_N[cons >> 1]);
+    const uint32_t j0 = rg_own_j(c, phase, cons, 0);
+    return j0 < c.n[phase] ? (c.n[phase] - j0 + RG_NC - 1) / RG_NC : 0u;
+}
+// first record of consumer c in a phase
+RG_HD uint32_t rg_first_j(const RingCu & c, int phase, int cons) { return rg_own_j(c, phase, cons, 0); }
 
 // Offset in the layer block of the first record consumer `cons` owns in phase `from` or later; RG_NONE when it owns none any more in
 // this layer (the caller then continues with the next block of its stream: the next layer, or the head).

@@ -290,7 +290,20 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 // the kernel. EPT = D / 512, NBD = decay rank / 32, UF = 64-block steps of an F-long row, KSL = gather slots per lane for the
 // quantised F-vector. Exactly RG_NBLK workgroups of 512 threads.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef R6_ROWS_WAIT   /* 1 (debugging aid): every take inside a row phase waits for its LDS reads at once */
+#define R6_ROWS_WAIT 0
+#endif
+#ifndef R6_REPOLL_MISSING
+#define R6_REPOLL_MISSING 0
+#endif
+#ifndef R6_RT_STAMPS   /* 1: every phase stamp from the 100 MHz real-time counter (one clock for all workgroups: tools/trace_ring_cp.py) instead of the shader clock */
+#define R6_RT_STAMPS 0
+#endif
+#if R6_RT_STAMPS
+#define R6STAMP(K) do { if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + (K)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
 #define R6STAMP(K) do { if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + (K)] = (long long) __builtin_readcyclecounter(); } while (0)
+#endif
 #define R6RSTAMP(K) do { if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + (K)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
 
 template <int FMT, int EPT, int NBD, int UF, int KSL>
@@ -314,8 +327,19 @@ struct R6 {
     static __device__ __forceinline__ RingShape shape(const R6P & p) {
         RingShape s; s.D = D; s.F = p.F; s.R5 = 5 * p.R; s.DR = p.DR;
         s.qs = QF<FMT>::QS; s.scb = QF<FMT>::HM ? 4 : 2; s.qhb = QF<FMT>::QH ? 4 : 0;
+        s.bal = BAL ? 1 : 0;
         return s;
     }
+    // two-row sets of C and FK dealt by SIMD share (ring_geom.h, RG_BAL_*): the D = 4096 geometry. Built, bit-identical, measured, OFF:
+    // 649.4 tokens/s against 662.4 for the even deal on one box (profiles/r06_balance_ab.txt). The deal moved nothing where it was aimed --
+    // c4 / c5 finish the r/k/v/g rows at 8100 cycles with four records as with five -- because a SIMD issues one VALU instruction per four
+    // cycles whether one wave or two feed it: the row phases are bound by the CU's 4 x 1 issue slots (32 sets in ~8000 cycles), a wave that
+    // shares its SIMD with an older one simply gets the slots the older one leaves, and the seven-record waves became the new last ones.
+#ifndef R6_BALANCE
+#define R6_BALANCE 0
+#endif
+    static constexpr bool BAL = R6_BALANCE != 0 && EPT == 8;
+    template <int PH> static constexpr bool balph() { return BAL && (PH == RG_C || PH == RG_FK); }
 
     // -----------------------------------------------------------------------------------------------------------
     // cooperative gathers: the NG gathering waves each poll a share of the units and stage it into LDS, then meet on a counter
@@ -328,8 +352,17 @@ struct R6 {
     static __device__ __forceinline__ void gather_x(Poll & pl, xrsrc xr, int buf, unsigned tag, int g, int lane, float * lx, const float * plain = nullptr, bool keep = false) {
         constexpr int N = NBLK * NC;
         const int i0 = g * 64 + lane;
-        v4u v[XSL];
+        auto stage = [&](int k, const v4u & u) {
+            const unsigned i = (unsigned) (i0 + k * NG * 64);
+            const unsigned b = (i * 43691u) >> 18;         // i / 6 for i < 2^16
+            const unsigned c = i - 6u * b;
+            float * dst = lx + b * RE + c;
+            dst[0] = __uint_as_float(u.x);
+            if (XT > 1 && c + NC < (unsigned) RE) dst[NC] = __uint_as_float(u.y);
+            if (XT > 2 && c + 2 * NC < (unsigned) RE) dst[2 * NC] = __uint_as_float(u.z);
+        };
         if (plain) {
+            v4u v[XSL];
 #pragma unroll
             for (int k = 0; k < XSL; k++) {
                 const unsigned i = (unsigned) (i0 + k * NG * 64);
@@ -341,28 +374,31 @@ struct R6 {
                 v[k].z = __float_as_uint(src[(XT > 2 && c + 2 * NC < (unsigned) RE) ? 2 * NC : 0]);
                 v[k].w = 0u;
             }
-        } else
+#pragma unroll
+            for (int k = 0; k < XSL; k++) if (i0 + k * NG * 64 < N && !keep) stage(k, v[k]);
+            return;
+        }
+        // A sweep that comes back incomplete re-reads only what was missing (R6_REPOLL_MISSING): a unit is staged by the sweep that finds it,
+        // and a lane that has its unit of a slot reads the buffer's first unit instead (one address for all of them: one request) -- the
+        // retries of a hand-over's last microsecond cost a few requests, not the vector again. (Unconditional loads with a selected
+        // address: loads under `if (missing)` are conditional redefinitions, around which the allocator copies and spills.)
+        bool have[XSL];
+#pragma unroll
+        for (int k = 0; k < XSL; k++) have[k] = i0 + k * NG * 64 >= N;
         for (unsigned spin = 0;; spin++) {
             asm volatile("" ::: "memory");
+            v4u v[XSL];
 #pragma unroll
-            for (int k = 0; k < XSL; k++) v[k] = tg_load(xr, buf + i0 + k * NG * 64);
+            for (int k = 0; k < XSL; k++) v[k] = tg_load(xr, (R6_REPOLL_MISSING && have[k]) ? buf : buf + i0 + k * NG * 64);
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < XSL; k++) ok = ok && (i0 + k * NG * 64 >= N || tg_ok(v[k], tag));
+            for (int k = 0; k < XSL; k++) {
+                const bool now = !have[k] && tg_ok(v[k], tag);
+                if (now) stage(k, v[k]);
+                have[k] = have[k] || now; ok = ok && have[k];
+            }
             if (__all(ok) || pl.dead) break;
             if (poll_backoff(pl, spin)) break;
-        }
-#pragma unroll
-        for (int k = 0; k < XSL; k++) {
-            const unsigned i = (unsigned) (i0 + k * NG * 64);
-            if (i < (unsigned) N && !keep) {
-                const unsigned b = (i * 43691u) >> 18;         // i / 6 for i < 2^16
-                const unsigned c = i - 6u * b;
-                float * dst = lx + b * RE + c;
-                dst[0] = __uint_as_float(v[k].x);
-                if (XT > 1 && c + NC < (unsigned) RE) dst[NC] = __uint_as_float(v[k].y);
-                if (XT > 2 && c + 2 * NC < (unsigned) RE) dst[2 * NC] = __uint_as_float(v[k].z);
-            }
         }
     }
     // quantised vector of K elements (3 units per 32-element block, see tq_store_block) into its lohi image
@@ -372,34 +408,38 @@ struct R6 {
         const QVec q = qvec_at(l, K);
         unsigned * img = reinterpret_cast<unsigned *>(l);
         const int i0 = g * 64 + lane;
-        v4u v[SL];
-        for (unsigned spin = 0;; spin++) {
-            asm volatile("" ::: "memory");
+        auto stage = [&](int k, const v4u & u) {
+            const unsigned i = (unsigned) (i0 + k * NG * 64);
+            const unsigned b = (i * 43691u) >> 17;         // i / 3 for i < 2^16
+            const unsigned kk = i - 3u * b;
+            const unsigned j0 = 3u * kk, j1 = j0 + 1u;     // dword index of .x / .y within the block's eight code dwords
+            img[(j0 < 4u ? 0u : 4u * nbk) + 4u * b + (j0 & 3u)] = u.x;
+            img[(j1 < 4u ? 0u : 4u * nbk) + 4u * b + (j1 & 3u)] = u.y;
+            if (kk < 2u) {
+                const unsigned j2 = j0 + 2u;
+                img[(j2 < 4u ? 0u : 4u * nbk) + 4u * b + (j2 & 3u)] = u.z;
+            } else {
+                q.d[b] = h2f_bits((uint16_t) (u.z & 0xFFFFu)); q.s[b] = h2f_bits((uint16_t) (u.z >> 16));
+                q.isum[b] = (int) (short) (u.w >> 16);
+            }
+        };
+        bool have[SL];
 #pragma unroll
-            for (int k = 0; k < SL; k++) v[k] = tg_load(xr, src + i0 + k * NG * 64);
+        for (int k = 0; k < SL; k++) have[k] = i0 + k * NG * 64 >= n;
+        for (unsigned spin = 0;; spin++) {   // (a retry re-reads only what was missing: see gather_x)
+            asm volatile("" ::: "memory");
+            v4u v[SL];
+#pragma unroll
+            for (int k = 0; k < SL; k++) v[k] = tg_load(xr, (R6_REPOLL_MISSING && have[k]) ? src : src + i0 + k * NG * 64);
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < SL; k++) ok = ok && (i0 + k * NG * 64 >= n || tg_ok(v[k], tag));
+            for (int k = 0; k < SL; k++) {
+                const bool now = !have[k] && tg_ok(v[k], tag);
+                if (now) stage(k, v[k]);
+                have[k] = have[k] || now; ok = ok && have[k];
+            }
             if (__all(ok) || pl.dead) break;
             if (poll_backoff(pl, spin)) break;
-        }
-#pragma unroll
-        for (int k = 0; k < SL; k++) {
-            const unsigned i = (unsigned) (i0 + k * NG * 64);
-            if (i < (unsigned) n) {
-                const unsigned b = (i * 43691u) >> 17;         // i / 3 for i < 2^16
-                const unsigned kk = i - 3u * b;
-                const unsigned j0 = 3u * kk, j1 = j0 + 1u;     // dword index of .x / .y within the block's eight code dwords
-                img[(j0 < 4u ? 0u : 4u * nbk) + 4u * b + (j0 & 3u)] = v[k].x;
-                img[(j1 < 4u ? 0u : 4u * nbk) + 4u * b + (j1 & 3u)] = v[k].y;
-                if (kk < 2u) {
-                    const unsigned j2 = j0 + 2u;
-                    img[(j2 < 4u ? 0u : 4u * nbk) + 4u * b + (j2 & 3u)] = v[k].z;
-                } else {
-                    q.d[b] = h2f_bits((uint16_t) (v[k].z & 0xFFFFu)); q.s[b] = h2f_bits((uint16_t) (v[k].z >> 16));
-                    q.isum[b] = (int) (short) (v[k].w >> 16);
-                }
-            }
         }
     }
     // Stage 1 of a gather. Sweeping all units while the producers are still microseconds away is what the first version did: 256
@@ -817,23 +857,35 @@ struct R6 {
     // the coming phase -- all of them where the registers allow -- and the loader streams the phase after that into the room they
     // leave. Record t of the wave lives in buffer t % NP; rows() takes what is still missing (blocking), one record ahead of the
     // arithmetic, so NP = 2 is the old double buffer and NP = 1 the single one (Q8_0's long value rows).
-    template <int R, int U, int NP> struct Pre {
-        static constexpr int R_ = R, U_ = U, NP_ = NP;
+    template <int PH, int R, int U, int NP> struct Pre {
+        static constexpr int PH_ = PH, R_ = R, U_ = U, NP_ = NP;
         static constexpr unsigned RECB = (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0));
         RawRec<FMT, R, U> w[NP];
         unsigned have;         // records of this wave taken out of the ring so far in this phase
         unsigned cnt;          // records this wave owns in this phase
         unsigned pos, ro;      // stream position / ring offset of the next record to take
         unsigned after;        // where this wave's stream continues behind the phase
+        unsigned base;         // stream position of the phase's record 0
     };
+    // record number of this wave's T-th record of phase PH: six apart, or by the balanced deal (scalar selects on the wave's pair, no table in memory)
+    template <int PH, int T>
+    static __device__ __forceinline__ unsigned ownj(const Cons & cs) {
+        if constexpr (balph<PH>()) {
+            constexpr int TT = T < RG_BAL_TMAX ? T : RG_BAL_TMAX - 1;
+            constexpr unsigned a = (unsigned) (PH == RG_C ? RG_BAL_C_J[0][TT] : RG_BAL_K_J[0][TT]), b = (unsigned) (PH == RG_C ? RG_BAL_C_J[1][TT] : RG_BAL_K_J[1][TT]),
+                               d = (unsigned) (PH == RG_C ? RG_BAL_C_J[2][TT] : RG_BAL_K_J[2][TT]);
+            const unsigned pr = (unsigned) cs.c >> 1;
+            return (pr == 0u ? a : (pr == 1u ? b : d)) + ((unsigned) cs.c & 1u);
+        } else return rg_first_j(cs.cu, PH, cs.c) + (unsigned) (NC * T);
+    }
     template <int R, int U> static constexpr unsigned recb() { return (unsigned) (U * R * 64) * (QF<FMT>::QS + (QF<FMT>::HM ? 4 : 2) + (QF<FMT>::QH ? 4 : 0)); }
     template <int PH, int R, int U, int NP>
-    static __device__ __forceinline__ void pre_begin(const Cons & cs, Pre<R, U, NP> & pre) {
+    static __device__ __forceinline__ void pre_begin(const Cons & cs, Pre<PH, R, U, NP> & pre) {
         constexpr unsigned RECB = recb<R, U>();
-        const unsigned n = cs.cu.n[PH];
         const unsigned j0 = rg_first_j(cs.cu, PH, cs.c);
         pre.have = 0;
-        pre.cnt = __builtin_amdgcn_readfirstlane(j0 < n ? (n - j0 + NC - 1) / NC : 0u);
+        pre.cnt = __builtin_amdgcn_readfirstlane(rg_own_count(cs.cu, PH, cs.c));
+        pre.base = __builtin_amdgcn_readfirstlane(cs.lbase + cs.cu.off[PH]);
         pre.pos = __builtin_amdgcn_readfirstlane(cs.lbase + cs.cu.off[PH] + j0 * RECB);
         pre.ro = __builtin_amdgcn_readfirstlane(pre.pos - (pre.pos / cs.RB) * cs.RB);   // (once per phase)
         const unsigned nxt = rg_next_own_in_layer(cs.cu, cs.c, PH + 1);
@@ -845,8 +897,8 @@ struct R6 {
     // WAIT = false: the reads are still in flight on return -- the caller calls rec_wait on the buffer before its first use, with only
     // straight arithmetic on OTHER buffers in between (no hardware interlock covers a register with an LDS read pending: a copy the
     // compiler made in between would copy the old contents)
-    template <int T, int R, int U, int NP, bool WAIT = true>
-    static __device__ __forceinline__ bool rec_take(Cons & cs, Poll & pl, const Lds & l, Pre<R, U, NP> & pre, bool block) {
+    template <int T, int PH, int R, int U, int NP, bool WAIT = true>
+    static __device__ __forceinline__ bool rec_take(Cons & cs, Poll & pl, const Lds & l, Pre<PH, R, U, NP> & pre, bool block) {
         constexpr unsigned RECB = recb<R, U>(), STRIDE = NC * RECB;
         const unsigned need = (pre.pos + RECB + 1023u) >> 10;
         if (cs.landed < need) {
@@ -867,13 +919,16 @@ struct R6 {
         // the reads above are in the LDS queue: the ring may be refilled up to this wave's next record (every lane writes the same word)
         asm volatile("" ::: "memory");
         const bool last = pre.have + 1u >= pre.cnt;
-        __hip_atomic_store(l.fl + FL_DONE + 2 + cs.c, last ? pre.after : pre.pos + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // this wave's next record: NC records on, or where the balanced deal puts it (behind the last one: not used)
+        unsigned nxt;
+        if constexpr (balph<PH>()) nxt = pre.base + ownj<PH, T + 1>(cs) * RECB; else nxt = pre.pos + STRIDE;
+        __hip_atomic_store(l.fl + FL_DONE + 2 + cs.c, last ? pre.after : nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if constexpr (WAIT) rec_wait<FMT, R, U>(pre.w[T % NP]);
         pre.have += 1u;
         // (a wave's records are NC records apart: more than one lap of the ring for the long Q8_0 value rows)
-        pre.pos += STRIDE; pre.ro += STRIDE;
+        pre.ro += nxt - pre.pos; pre.pos = nxt;
         pre.ro = pre.ro >= cs.RB ? pre.ro - cs.RB : pre.ro;
-        if constexpr (STRIDE > 32768u) { pre.ro = pre.ro >= cs.RB ? pre.ro - cs.RB : pre.ro; pre.ro = pre.ro >= cs.RB ? pre.ro - cs.RB : pre.ro; }
+        if constexpr (!balph<PH>() && STRIDE > 32768u) { pre.ro = pre.ro >= cs.RB ? pre.ro - cs.RB : pre.ro; pre.ro = pre.ro >= cs.RB ? pre.ro - cs.RB : pre.ro; }
         return true;
     }
     // which phases take records ahead (1: r/k/v/g, 2: output, 4: ffn key, 8: ffn value), and how many per wave. D = 2048: none -- a layer
@@ -903,9 +958,9 @@ struct R6 {
     // `a` is in registers: a wave releases ring space in stream order). With one phase per wait the loader found the ring full again
     // 2 - 3 us into every wait -- the records of the NEXT phase sat in it until the next wait; now they leave during this one, and
     // what streams in behind them is two phases ahead.
-    template <int RA, int UA, int NA, int RB_, int UB_, int NB_, int RC, int UC, int NC_>
+    template <int PA_, int RA, int UA, int NA, int PB_, int RB_, int UB_, int NB_, int PC_, int RC, int UC, int NC_>
     static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap,
-                                                     bool on_a, Pre<RA, UA, NA> & a, bool on_b, Pre<RB_, UB_, NB_> & b, bool on_c, Pre<RC, UC, NC_> & c3, bool no_handover = false) {
+                                                     bool on_a, Pre<PA_, RA, UA, NA> & a, bool on_b, Pre<PB_, RB_, UB_, NB_> & b, bool on_c, Pre<PC_, RC, UC, NC_> & c3, bool no_handover = false) {
         bool turned = no_handover;            // (the first layer of a launch: nothing to wait for, nothing taken ahead)
         const unsigned look = cs.look;
         auto step = [&](auto & pre, auto tc, bool ok) {
@@ -926,7 +981,7 @@ struct R6 {
                     if (poll_backoff(pl, spin)) { turned = true; break; }
                     for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
                 }
-                if (here) (void) rec_take<t, P::R_, P::U_, P::NP_>(cs, pl, l, pre, false);
+                if (here) (void) rec_take<t, P::PH_, P::R_, P::U_, P::NP_>(cs, pl, l, pre, false);
             }
         };
         if (!(cs.dbg & 64)) {
@@ -936,17 +991,17 @@ struct R6 {
         }
         if (!turned) gather_hint(pl, xr, unit, tag, go, gen, nap);
     }
-    template <int RA, int UA, int NA, int RB_, int UB_, int NB_>
+    template <int PA_, int RA, int UA, int NA, int PB_, int RB_, int UB_, int NB_>
     static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap,
-                                                     bool on_a, Pre<RA, UA, NA> & a, bool on_b, Pre<RB_, UB_, NB_> & b, bool no_handover = false) {
-        Pre<1, 1, 1> none;
-        none.have = 0u; none.cnt = 0u; none.pos = 0u; none.ro = 0u; none.after = 0u;
+                                                     bool on_a, Pre<PA_, RA, UA, NA> & a, bool on_b, Pre<PB_, RB_, UB_, NB_> & b, bool no_handover = false) {
+        Pre<RG_W1, 1, 1, 1> none;
+        none.have = 0u; none.cnt = 0u; none.pos = 0u; none.ro = 0u; none.after = 0u; none.base = 0u;
         hint_take(cs, pl, l, xr, unit, tag, go, gen, nap, on_a, a, on_b, b, false, none, no_handover);
     }
-    template <int R, int U, int NP>
-    static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap, bool on, Pre<R, U, NP> & pre) {
-        Pre<1, 1, 1> none;
-        none.have = 0u; none.cnt = 0u; none.pos = 0u; none.ro = 0u; none.after = 0u;
+    template <int PH, int R, int U, int NP>
+    static __device__ __forceinline__ void hint_take(Cons & cs, Poll & pl, const Lds & l, xrsrc xr, int unit, unsigned tag, unsigned * go, unsigned gen, int nap, bool on, Pre<PH, R, U, NP> & pre) {
+        Pre<RG_W1, 1, 1, 1> none;
+        none.have = 0u; none.cnt = 0u; none.pos = 0u; none.ro = 0u; none.after = 0u; none.base = 0u;
         hint_take(cs, pl, l, xr, unit, tag, go, gen, nap, on, pre, false, none, false, none);
     }
 
@@ -956,12 +1011,16 @@ struct R6 {
     // register. epi(integral_constant<t>, j, res) receives the row sums of the wave's t-th record (record j of the phase).
     // (The first version walked the records in a loop with the cursor in a struct: ~300 overhead instructions per record -- half of
     //  them scalar, forty branches -- around ~140 useful ones; a C phase took 13.7 k cycles for 3.6 k cycles of arithmetic.)
-    template <int PH, int R, int U, int TF, int NP, typename EpiF>
-    static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, Pre<R, U, NP> & pre, EpiF && epi) {
-        static_assert(NP >= 1 && NP <= TF + 1, "rows: buffers");
+    // TMIN: every wave that owns any record of the phase owns at least TMIN (= TF when the records are dealt six apart; the smallest share of
+    // a balanced deal). Steps t < TMIN are unconditional code; the others ask `t < cnt` (wave-uniform) -- and where there are several of those
+    // (balanced deal) their takes wait for their LDS reads at once: a buffer with reads in flight must not cross a join of control flow,
+    // where the register allocator may copy it (the copy would carry the old contents). With every step conditional Q8_0 computed garbage.
+    template <int PH, int R, int U, int TF, int NP, int TMIN = TF, typename EpiF>
+    static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, Pre<PH, R, U, NP> & pre, EpiF && epi) {
+        static_assert(NP >= 1 && NP <= TF + 1 && TMIN <= TF, "rows: buffers");
         if (pre.cnt == 0u) return;
-        const bool tail = pre.cnt > (unsigned) TF;                  // wave-uniform
-        const unsigned j0 = rg_first_j(cs.cu, PH, cs.c);
+        constexpr bool SAFE = TMIN < TF || R6_ROWS_WAIT != 0;       // conditional takes wait at once
+        auto has = [&](int t) { return t < TMIN || (unsigned) t < pre.cnt; };
         const int ln = opq(cs.lane);
         ActRegs<U> ar;
         act_load<U>(ar, act, nbk, ln);
@@ -989,40 +1048,39 @@ struct R6 {
         // what is not in registers yet (blocking), up to NP records; then the arithmetic, and behind record t its buffer takes record t + NP
         Unroll<0, NP>::run([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            if ((t < TF || tail) && pre.have <= (unsigned) t) (void) rec_take<t, R, U, NP, false>(cs, pl, l, pre, true);
+            if (has(t) && pre.have <= (unsigned) t) (void) rec_take<t, PH, R, U, NP, (SAFE && t >= TMIN)>(cs, pl, l, pre, true);
         });
         // (record t's reads were issued NP - 1 takes ago; the take issued right before this wait -- of record t - 1 + NP, behind the
         //  arithmetic of record t - 1 -- may stay in flight: its LDS latency overlaps the arithmetic instead of preceding it)
         bool took = false;                                         // the previous iteration issued a take (wave-uniform)
         Unroll<0, TF + 1>::run([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            if (t < TF || tail) {
+            if (has(t)) {
                 if (NP >= 2 && took) rec_wait<FMT, R, U, rec_lds_ops<FMT, R, U>()>(pre.w[t % NP]);
                 else rec_wait<FMT, R, U>(pre.w[t % NP]);
                 finish(tc, pre.w[t % NP]);
                 took = false;
-                if constexpr (t + NP <= TF) { if (t + NP < TF || tail) { (void) rec_take<t + NP, R, U, NP, false>(cs, pl, l, pre, true); took = true; } }
+                if constexpr (t + NP <= TF) {
+                    constexpr bool W = SAFE && t + NP >= TMIN;
+                    if (has(t + NP)) { (void) rec_take<t + NP, PH, R, U, NP, W>(cs, pl, l, pre, true); took = !W; }
+                }
             }
         });
         wave_sum_n<(TF + 1) * R>(part);
-        Unroll<0, TF>::run([&](auto tc) {
+        Unroll<0, TF + 1>::run([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            float res[R];
+            if (has(t)) {
+                float res[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) res[r] = part[t * R + r];
-            epi(tc, (int) (j0 + NC * t), res);
+                for (int r = 0; r < R; r++) res[r] = part[t * R + r];
+                epi(tc, (int) ownj<PH, t>(cs), res);
+            }
         });
-        if (tail) {
-            float res[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) res[r] = part[TF * R + r];
-            epi(std::integral_constant<int, TF>{}, (int) (j0 + NC * TF), res);
-        }
     }
     // a phase without records taken ahead
     template <int PH, int R, int U, int TF, int NP, typename EpiF>
     static __device__ __forceinline__ void rows(Cons & cs, Poll & pl, const Lds & l, const QVec & act, int nbk, EpiF && epi) {
-        Pre<R, U, NP> pre;
+        Pre<PH, R, U, NP> pre;
         pre_begin<PH>(cs, pre);
         rows<PH, R, U, TF, NP>(cs, pl, l, act, nbk, pre, epi);
     }
@@ -1031,8 +1089,12 @@ struct R6 {
     // rows (R), ffn value rows (G). With records taken ahead (PRE_MASK): as many as the register file holds without spilling
     // (tools/check_ring_regs.sh prints the budget of every instantiation); without: the double buffer (one buffer for Q8_0's 36-register
     // blocks and for the long value rows).
-    static constexpr int TFC = (D * 4 / NBLK / 2) / NC, TFE = RE / NC, KSETS = UF * 64 > NBLK ? 32 : 16 /* two-row key sets of a workgroup that owns any */,
-                         KCOMM = (KSETS % NC <= 2) ? KSETS % NC : 0 /* ... of which the comm wave takes the last ones (ring_geom.h, rg_key_comm) */, TFK = (KSETS - KCOMM) / NC;
+    // (TFx: a wave owns TFx or TFx + 1 records of the phase -- dealt six apart; with the balanced deal of C and FK: up to TFx + 1)
+    static constexpr int KSETS = UF * 64 > NBLK ? 32 : 16 /* two-row key sets of a workgroup that owns any */,
+                         KCOMM = (KSETS % NC <= 2) ? KSETS % NC : 0 /* ... of which the comm wave takes the last ones (ring_geom.h, rg_key_comm) */;
+    static constexpr int TFC = BAL ? RG_BAL_C_N[1] - 1 : (D * 4 / NBLK / 2) / NC, TFE = RE / NC, TFK = BAL ? RG_BAL_K_N[1] - 1 : (KSETS - KCOMM) / NC;
+    static constexpr int TMC = BAL ? RG_BAL_C_N[2] : TFC, TMK = BAL ? RG_BAL_K_N[2] : TFK;   // the smallest share of a wave that owns any
+    static_assert(!BAL || (D * 4 / NBLK / 2 == RG_BAL_C_SETS && KSETS - KCOMM == RG_BAL_K_SETS), "balanced deal: geometry");
     static constexpr bool Q8 = QF<FMT>::QS == 32, Q5 = QF<FMT>::QH;
     static constexpr int npcap(int want, int tf) { return want < 1 ? 1 : (want > tf + 1 ? tf + 1 : want); }
 #ifndef R6_NPC
@@ -1118,9 +1180,9 @@ struct R6 {
             R6STAMP(0);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 23] = cs.waited;
             unsigned havepk = 0u;   // (tracing) records of each row phase already in registers when the phase starts, 4 bits per phase
-            Pre<1, UD, 1> pw;
+            Pre<RG_W1, 1, UD, 1> pw;
             pre_begin<RG_W1>(cs, pw);
-            Pre<2, UD, NPC> pc;
+            Pre<RG_C, 2, UD, NPC> pc;
             pre_begin<RG_C>(cs, pc);
             // (per-lane offsets are derived from an opaque copy of the lane index in every phase: left alone, the compiler hoists a
             //  hundred loop-invariant address registers of the gathers out of the layer loop and spills them)
@@ -1154,7 +1216,7 @@ struct R6 {
             });
             R6STAMP(3);
             // ---- C: the mixed inputs (this workgroup's matrix reads ONE of the five), decay row, r/k/v/g sets ----
-            Pre<1, UD, NPE> pe;
+            Pre<RG_E, 1, UD, NPE> pe;
             pre_begin<RG_E>(cs, pe);
             {
                 const int img = (0x4213 >> (4 * mat)) & 0xF;   // r, k, v, g -> mix image (w, k, v, r, g order)
@@ -1171,15 +1233,14 @@ struct R6 {
             {
                 // all row sums first, then ONE epilogue: lane 2 t + r finishes row r of this wave's t-th set (the gate's silu is a double-
                 // precision exp: once per phase, not once per record) and lanes 0, 2, 4, ... store their set's unit with one instruction
-                constexpr int NSET = D * 4 / NBLK / 2, MAXT = (NSET + NC - 1) / NC;
+                constexpr int MAXT = TFC + 1;
                 float all[2 * MAXT];
 #pragma unroll
                 for (int t = 0; t < 2 * MAXT; t++) all[t] = 0.0f;
-                const int j0 = (int) rg_first_j(cs.cu, RG_C, c);
                 if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 20] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_C]);
                 R6RSTAMP(26);
                 havepk |= pc.have << 4;
-                rows<RG_C, 2, UD, NSET / NC, NPC>(cs, pl, l, qvec_at(l.act, D), nb, pc, [&](auto tc, int, const float (&res)[2]) {
+                rows<RG_C, 2, UD, TFC, NPC, TMC>(cs, pl, l, qvec_at(l.act, D), nb, pc, [&](auto tc, int, const float (&res)[2]) {
                     constexpr int t = decltype(tc)::value;
                     all[2 * t] = res[0]; all[2 * t + 1] = res[1];
                 });
@@ -1187,7 +1248,8 @@ struct R6 {
                 float v = pick_lane<2 * MAXT>(all, ln);
                 if (mat == 3) v = v / (1.0f + det_expf(-v));     // gate: silu
                 const int v1 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true);   // lane 2 t collects row 1 (row_shl:1)
-                const int j = j0 + NC * (ln >> 1);
+                int j = 0x7fff;   // record number of the set lane ln >> 1 finishes (a select chain over this wave's records)
+                Unroll<0, MAXT>::run([&](auto tc) { constexpr int t = decltype(tc)::value; const int jt = (t < TMC || (unsigned) t < pc.cnt) ? (int) ownj<RG_C, t>(cs) : 0x7fff; j = (ln >> 1) == t ? jt : j; });
                 if (ln < 2 * MAXT && (ln & 1) == 0 && j < (int) cs.cu.n[RG_C])
                     tg_store(xr, p.rkvg + ((mat * D + cbase + 2 * j) >> 1), __float_as_uint(v), (unsigned) v1, 0u, 0u, tagL + SLOT_RKVG);
             }
@@ -1196,9 +1258,9 @@ struct R6 {
             if (PF_EARLY) issue_pf(pf, ar, L, sin_l, c, opq(lane));
             __builtin_amdgcn_sched_barrier(0);
             // ---- E: output projection + residual ----
-            Pre<2, UD, NPK> pk;
+            Pre<RG_FK, 2, UD, NPK> pk;
             pre_begin<RG_FK>(cs, pk);
-            Pre<1, UD, NPR> pr;
+            Pre<RG_FR, 1, UD, NPR> pr;
             pre_begin<RG_FR>(cs, pr);
             watch_begin(l);
             hint_take(cs, pl, l, xr, p.yq + ((blk * 7 + c * 19) & 127), tagL + SLOT_YQ, l.fl + FL_HYQ, g1, p.nap, (PRE_MASK & 2) != 0, pe, (PRE_MASK & 64) != 0, pk, (PRE_MASK & 128) != 0, pr);
@@ -1231,7 +1293,7 @@ struct R6 {
             R6STAMP(9); R6RSTAMP(28);
             if (p.trace && li == p.trace_layer && lane == 0) p.trace[((long long) blockIdx.x * 8 + wave) * 32 + 21] = (long long) fl_ld(l.fl + FL_LANDED) * 1024ll - (long long) (cs.lbase + cs.cu.off[RG_FK]);
             havepk |= (pk.have << 12) | (pr.have << 16);
-            rows<RG_FK, 2, UD, TFK, NPK>(cs, pl, l, qvec_at(l.q1, D), nb, pk, [&](auto, int j, const float (&res)[2]) {
+            rows<RG_FK, 2, UD, TFK, NPK, TMK>(cs, pl, l, qvec_at(l.q1, D), nb, pk, [&](auto, int j, const float (&res)[2]) {
                 const float v = lane == 1 ? res[1] : res[0];
                 const float t = v > 0.0f ? v : 0.0f;
                 if (lane < 2) l.out[2 * j + lane] = t * t;
@@ -1248,7 +1310,7 @@ struct R6 {
             });
             R6STAMP(11); R6RSTAMP(29);
             // ---- G: value projection, x += sigmoid(r) * (Wv k) ----
-            Pre<1, UF, NPG> pg;
+            Pre<RG_G, 1, UF, NPG> pg;
             pre_begin<RG_G>(cs, pg);
             // (registers: not the long Q8_0 rows of the 7B geometry)
             watch_begin(l);

@@ -39,10 +39,9 @@ static void check_shape(const RingShape & s, const char * name) {
                     if (row >= 0 && row < (int) v.size()) v[(size_t) row]++;
                 }
                 int owner = -1, owners = 0;
-                for (int cons = 0; cons < RG_NC; cons++) {
-                    const uint32_t j0 = rg_first_j(c, ph, cons);
-                    if (j >= j0 && (j - j0) % RG_NC == 0) { owner = cons; owners++; }
-                }
+                for (int cons = 0; cons < RG_NC; cons++)
+                    for (uint32_t t = 0; t < rg_own_count(c, ph, cons); t++)
+                        if (rg_own_j(c, ph, cons, (int) t) == j) { owner = cons; owners++; }
                 CHECK(owners == 1, "%s wg %d phase %d record %u: %d owners", name, b, ph, j, owners);
                 if (owner >= 0) by_consumer[owner].emplace_back(off + j * c.rec[ph], ph, (int) j);
             }
@@ -53,6 +52,16 @@ static void check_shape(const RingShape & s, const char * name) {
             for (int q = 0; q < 2; q++) { const int row = b * rg_gpb(s) * 32 + 2 * j + q; auto & v = seen[{RG_FK, 0}]; CHECK(row < (int) v.size(), "comm key row"); if (row < (int) v.size()) v[(size_t) row]++; }
         CHECK((int) c.n[RG_FK] + rg_key_comm(s, b) == rg_key_sets(s, b) && rg_key_comm(s, b) <= 2, "%s wg %d: key sets", name, b);
         CHECK(c.layer_bytes == off, "%s wg %d: layer bytes", name, b);
+        for (int ph = 0; ph < RG_NPHASE; ph++) {   // a wave's records: as many as rg_own_count says, increasing, inside the phase, nothing behind them
+            uint32_t total = 0;
+            for (int cons = 0; cons < RG_NC; cons++) {
+                const uint32_t k = rg_own_count(c, ph, cons);
+                total += k;
+                for (uint32_t t = 0; t < k; t++) CHECK(rg_own_j(c, ph, cons, (int) t) < c.n[ph] && (t == 0 || rg_own_j(c, ph, cons, (int) t) > rg_own_j(c, ph, cons, (int) t - 1)), "%s wg %d phase %d consumer %d: record %u", name, b, ph, cons, t);
+                CHECK(rg_own_j(c, ph, cons, (int) k) >= c.n[ph], "%s wg %d phase %d consumer %d: a record behind the last", name, b, ph, cons);
+            }
+            CHECK(total == c.n[ph], "%s wg %d phase %d: %u of %u records owned", name, b, ph, total, c.n[ph]);
+        }
         if (b == 0) layer_bytes0 = c.layer_bytes;
         // the cursor of a consumer wave: first own record of phase >= from, in stream order
         for (int cons = 0; cons < RG_NC; cons++) {
@@ -104,9 +113,11 @@ int main() {
     struct Geo { int D, F, R5, DR; } geos[] = {{2048, 7168, 160, 64}, {4096, 14336, 320, 128}, {4096, 14336, 160, 64}, {2560, 8960, 160, 64}};
     for (const Fmt & f : fmts)
         for (const Geo & g : geos) {
-            RingShape s; s.D = g.D; s.F = g.F; s.R5 = g.R5; s.DR = g.DR; s.qs = f.qs; s.scb = f.scb; s.qhb = f.qhb;
-            char name[64]; snprintf(name, sizeof name, "%s D=%d", f.name, g.D);
-            check_shape(s, name);
+            for (int bal = 0; bal <= (g.D == 4096 ? 1 : 0); bal++) {
+                RingShape s; s.D = g.D; s.F = g.F; s.R5 = g.R5; s.DR = g.DR; s.qs = f.qs; s.scb = f.scb; s.qhb = f.qhb; s.bal = bal;
+                char name[64]; snprintf(name, sizeof name, "%s D=%d bal=%d", f.name, g.D, bal);
+                check_shape(s, name);
+            }
         }
     for (int v : {4096, 8192, 32768, 65536}) for (int K : {2048, 2560, 4096}) check_head(v, K);
     if (fails) { fprintf(stderr, "%d checks failed\n", fails); return 1; }

@@ -20,13 +20,13 @@ typedef __amdgpu_buffer_rsrc_t xrsrc;
 
 enum { W_VEC = 0, W_SCALAR_GLC = 1, W_SCALAR_INV = 2, W_NONE = 3 };
 
-template <int MODE, int DEPTH>
+template <int MODE, int DEPTH, int NPOLL>
 __global__ void __launch_bounds__(512) k(unsigned * xch, const unsigned char * bulk, size_t bulk_bytes, int rounds, unsigned long long * out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned stop;
+    __shared__ unsigned stop, done_round;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = blockIdx.x;
-    if (tid == 0) stop = 0u;
+    if (tid == 0) { stop = 0u; done_round = 0u; }
     __syncthreads();
     if (wave == 0) {
         if (DEPTH == 0) return;
@@ -56,12 +56,13 @@ __global__ void __launch_bounds__(512) k(unsigned * xch, const unsigned char * b
         if (lane == 0) out[2 + blk] = n;
         return;
     }
-    if (wave != 1) return;
+    if (wave < 1 || wave > NPOLL) return;
     const xrsrc xr = __builtin_amdgcn_make_buffer_rsrc(xch, 0, 2 * 512 * 16, 0x00020000);
     unsigned stale = 0;
     for (int r = 1; r <= rounds; r++) {
         const int buf = (r & 1) * 512;
-        if (lane == 0) { const v4u v = {(unsigned) r, 1u, 2u, (unsigned) r}; __builtin_amdgcn_raw_buffer_store_b128(v, xr, (buf + blk) * 16, 0, 16); }
+        if (lane == 0 && wave == 1) { const v4u v = {(unsigned) r, 1u, 2u, (unsigned) r}; __builtin_amdgcn_raw_buffer_store_b128(v, xr, (buf + blk) * 16, 0, 16); }
+        if (NPOLL > 1) for (int i = 0; i < (wave - 1) * 2; i++) __builtin_amdgcn_s_sleep(2);   // stagger the pollers (~110 ns apart at 2.4 GHz)
         const int wu = buf + ((blk * 37 + 11) & 255);
         if (MODE == W_VEC) {
             for (int spin = 0; spin < 2000000; spin++) {
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__(512) k(unsigned * xch, const unsigned char * b
         }
         // the sweep: 256 units, four per lane
         for (int spin = 0; spin < 2000000; spin++) {
+            if (NPOLL > 1 && (int) __hip_atomic_load(&done_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= r) break;
             asm volatile("" ::: "memory");
             v4u v[4];
 #pragma unroll
@@ -91,22 +93,23 @@ __global__ void __launch_bounds__(512) k(unsigned * xch, const unsigned char * b
             bool ok = true;
 #pragma unroll
             for (int u = 0; u < 4; u++) ok = ok && (int) v[u].w >= r;
-            if (__all(ok)) break;
+            if (__all(ok)) { if (NPOLL > 1 && lane == 0) __hip_atomic_store(&done_round, (unsigned) r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    if (wave != 1) return;
     if (lane == 0) { __hip_atomic_store(&stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (blk == 0) out[0] = stale; }
 }
 
-template <int MODE, int DEPTH>
+template <int MODE, int DEPTH, int NPOLL = 1>
 static void run(const char * name, unsigned * xch, const unsigned char * bulk, size_t bulk_bytes, unsigned long long * out) {
     const int rounds = MODE == W_VEC || MODE == W_NONE ? 4000 : 1000;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    CK(hipFuncSetAttribute((const void *) k<MODE, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    CK(hipFuncSetAttribute((const void *) k<MODE, DEPTH, NPOLL>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     for (int rep = 0; rep < 2; rep++) {
         CK(hipMemset(xch, 0, 2 * 512 * 16)); CK(hipMemset(out, 0, 8 * 300));
         CK(hipEventRecord(a));
-        k<MODE, DEPTH><<<256, 512, 100 * 1024>>>(xch, bulk, bulk_bytes, rounds, out);
+        k<MODE, DEPTH, NPOLL><<<256, 512, 100 * 1024>>>(xch, bulk, bulk_bytes, rounds, out);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         unsigned long long h[300]; CK(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost));
@@ -125,5 +128,16 @@ int main() {
     run<W_SCALAR_GLC, D>("scalar watch glc, depth " #D, xch, bulk, bulk_bytes, out); \
     run<W_SCALAR_INV, D>("scalar watch dcache_inv, depth " #D, xch, bulk, bulk_bytes, out);
     ROW(0) ROW(16) ROW(48)
+    // the same chain with several waves of the workgroup sweeping the same units a fraction of a round trip apart (the first to see the
+    // round complete ends it): what a finer sampling of the hand-over's completion is worth
+    run<W_NONE, 0, 1>("sweep polls, 1 wave, depth 0", xch, bulk, bulk_bytes, out);
+    run<W_NONE, 0, 2>("sweep polls, 2 waves, depth 0", xch, bulk, bulk_bytes, out);
+    run<W_NONE, 0, 4>("sweep polls, 4 waves, depth 0", xch, bulk, bulk_bytes, out);
+    run<W_NONE, 0, 7>("sweep polls, 7 waves, depth 0", xch, bulk, bulk_bytes, out);
+    run<W_VEC, 0, 4>("vector watch, 4 waves, depth 0", xch, bulk, bulk_bytes, out);
+    run<W_VEC, 0, 7>("vector watch, 7 waves, depth 0", xch, bulk, bulk_bytes, out);
+    run<W_NONE, 16, 1>("sweep polls, 1 wave, depth 16", xch, bulk, bulk_bytes, out);
+    run<W_NONE, 16, 4>("sweep polls, 4 waves, depth 16", xch, bulk, bulk_bytes, out);
+    run<W_NONE, 16, 7>("sweep polls, 7 waves, depth 16", xch, bulk, bulk_bytes, out);
     return 0;
 }
