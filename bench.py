@@ -353,14 +353,18 @@ def bench_decode(args, pkg, lib, path, spec, torch):
     return result
 
 
-class exact_arms:
-    """Context manager: sequence mode on the arms that reproduce the CPU oracle bit for bit (F16 matrices on k_mvf in ggml's addition order,
-    quantised matrices on the walk of k_mmq_mfma) instead of the timed defaults (k_mmf16_seq / k_mmq_fast: same operands, plain order)."""
-    VARS = {"RWKV_MI_SEQ_F16": "valu", "RWKV_MI_SEQ_Q": "exact"}
+class seq_arms:
+    """Context manager: sequence mode on the named arms. "exact" (the product's default since round 6): F16 matrices on k_mvf in ggml's addition
+    order, quantised matrices on the walk of k_mmq_mfma -- bit for bit the CPU oracle and the serial path. "fast" (opt-in): k_mmq_fast /
+    k_mmf16_seq -- the same operands, the f32 additions in plain order."""
+    ENV = {"exact": {"RWKV_MI_SEQ_F16": "valu", "RWKV_MI_SEQ_Q": "exact"}, "fast": {"RWKV_MI_SEQ_F16": "mfma", "RWKV_MI_SEQ_Q": "fast"}}
+
+    def __init__(self, arm):
+        self.vars = self.ENV[arm]
 
     def __enter__(self):
-        self.prev = {k: os.environ.get(k) for k in self.VARS}
-        os.environ.update(self.VARS)
+        self.prev = {k: os.environ.get(k) for k in self.vars}
+        os.environ.update(self.vars)
 
     def __exit__(self, *a):
         for k, v in self.prev.items():
@@ -368,6 +372,42 @@ class exact_arms:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def exact_arms():
+    return seq_arms("exact")
+
+
+def fast_arm_gate(args, model, prompt, spec, np):
+    """The opt-in arms against the default ones on the WHOLE benchmarked model (the analogue of the reference's own criterion for quantised
+    formats, tests/logit_difference_validator.inc:68,83: |sum of logit differences| <= 1.05 x a recorded value): after the T-token pass the
+    next 64 greedy tokens must be the exact arm's, and sum(logits_fast - logits_exact) over the vocabulary must sit inside 1.05 x the value
+    recorded in tests/reference_constants.py for this (config, dtype, T)."""
+    import reference_constants as R
+    out = {}
+    res = {}
+    for arm in ("exact", "fast"):
+        with seq_arms(arm):
+            model.state_load(None)
+            lg = model.eval_resident(prompt, want_logits=True)
+        tok0 = int(np.argmax(lg))
+        toks, _ = model.decode_greedy(tok0, 64)
+        res[arm] = (lg.astype(np.float64), [tok0] + [int(t) for t in toks])
+    sigma = float((res["fast"][0] - res["exact"][0]).sum())
+    same = res["fast"][1] == res["exact"][1]
+    key = (args.config, args.dtype, len(prompt))
+    rec = getattr(R, "FAST_ARM_LOGIT_DIFFERENCE_SUM", {}).get(key)
+    out = {"greedy_tokens_after_the_pass_equal": bool(same), "tokens_compared": 65, "logit_difference_sum": sigma,
+           "max_abs_logit_diff": float(np.abs(res["fast"][0] - res["exact"][0]).max()), "recorded_sum": rec,
+           "within_recorded_bound": (None if rec is None else bool(abs(sigma) <= 1.05 * abs(rec) + 1e-6))}
+    want_same = getattr(R, "FAST_ARM_GREEDY_CONTINUATION_EQUAL", {}).get(key)
+    out["greedy_continuation_equal_when_recorded"] = want_same
+    if not same:
+        a, b = res["fast"][1], res["exact"][1]
+        out["first_divergence_at_token"] = next(i for i in range(len(a)) if a[i] != b[i])
+    # fails when the sum leaves the recorded bound, or when a continuation that was equal when recorded is not any more
+    out["ok"] = bool((rec is None or out["within_recorded_bound"]) and (same or want_same is not True))
+    return out
 
 
 def bench_prefill(args, pkg, lib, path, spec, torch):
@@ -398,11 +438,29 @@ def bench_prefill(args, pkg, lib, path, spec, torch):
         "load_seconds": load_s,
     }
     peak = MFMA_I8_PEAK_TOPS if args.dtype.startswith("Q") else MFMA_F16_PEAK_TOPS
+    # the opt-in arms (RWKV_MI_SEQ_Q=fast RWKV_MI_SEQ_F16=mfma) timed the same way, as a side figure: `value` is the product's default
+    with seq_arms("fast"):
+        model.state_load(None)
+        for _ in range(max(1, args.warmup)):
+            model.eval_resident(prompt, want_logits=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model.eval_resident(prompt, want_logits=True)
+        torch.cuda.synchronize()
+        fwall = time.perf_counter() - t0
+        model.state_load(None)
+        fpp = model.profile_prefill(prompt)
+    result["fast_arms"] = {"tokens_per_s": args.steps * T / fwall, "ms_per_step": fwall * 1e3 / args.steps,
+                           "gemm_TOPs_in_launches": (fpp["ops"] / max(fpp["kernel_ms"], 1e-9) / 1e9 if fpp["launches"] else 0.0),
+                           "gemm_avg_launch_us": fpp["kernel_ms"] * 1e3 / max(fpp["launches"], 1), "env": seq_arms.ENV["fast"],
+                           "note": "opt-in: k_mmq_fast (block sums in plain K order) and k_mmf16_seq (F16 matrices on the matrix cores); not bit-identical to "
+                                   "the serial path, gated below (`parity.fast_arms`)"}
     # dominant kernel: the int8 MFMA GEMM (k_mmq_mfma), timed per launch with HIP events on the context's stream in a separate pass
     model.state_load(None)
     pp = model.profile_prefill(prompt)
     gemm = pp["ops"] / max(pp["kernel_ms"], 1e-9) / 1e9 if pp["launches"] else 0.0
-    result["roofline"] = {"bound": "mfma", "kernel": f"k_mmq_fast / k_mmq_mfma [{args.dtype}] (v_mfma_i32_32x32x32_i8; every quantised projection of the sequence pass)",
+    result["roofline"] = {"bound": "mfma", "kernel": f"k_mmq_mfma [{args.dtype}] (v_mfma_i32_32x32x32_i8; every quantised projection of the sequence pass, ggml's addition order)",
                           "achieved": gemm, "peak": peak, "unit": "TOP/s (int8)" if args.dtype.startswith("Q") else "TFLOP/s", "frac": gemm / peak,
                           "traffic": None, "launches": pp["launches"], "avg_launch_us": pp["kernel_ms"] * 1e3 / max(pp["launches"], 1),
                           "ops_per_pass_in_these_launches": pp["ops"], "whole_pass_TOPs": flops * args.steps / wall_s / 1e12, "flops_per_pass": flops,
@@ -419,26 +477,21 @@ def bench_prefill(args, pkg, lib, path, spec, torch):
         ol, ost = om.eval_sequence(prompt[:n], om.init_state())
         cpu_s = time.time() - t0
         om.free()
-        # Two arms for F16 matrices in sequence mode (csrc/kernels.hip): the exact one (k_mvf, ggml's addition order: bit for bit) and the
-        # timed default (k_mmf16_seq on the matrix cores: same operand rounding, another addition order -> equal to rounding; only RWKV-7's
-        # F16 low-rank stages and FP16 files reach it). The exact arm must equal the oracle; the timed arm must be within the stated tolerance.
-        with exact_arms():
-            model.state_load(None)
-            gl = model.eval_resident(prompt[:n], want_logits=True)
-            gst = model.state_store()
-        exact = bool(np.array_equal(gl, ol) and np.array_equal(gst, ost))
+        # The default arms must equal the oracle bit for bit on the whole model. The opt-in arms (same operands, other addition order) are
+        # held to a tolerance where it means something -- a TWO-layer slice of the same geometry (a 24 - 32-layer network of RANDOM weights
+        # amplifies a 1e-7 difference to 1e-2 over 32 layers x 128 tokens) -- and to the whole-model gate of fast_arm_gate().
         model.state_load(None)
-        tl = model.eval_resident(prompt[:n], want_logits=True)
-        tst = model.state_store()
+        gl = model.eval_resident(prompt[:n], want_logits=True)
+        gst = model.state_store()
+        exact = bool(np.array_equal(gl, ol) and np.array_equal(gst, ost))
+        with seq_arms("fast"):
+            model.state_load(None)
+            tl = model.eval_resident(prompt[:n], want_logits=True)
+            tst = model.state_store()
         err_l, err_s = float(np.abs(tl - ol).max()), float(np.abs(tst - ost).max())
         timed = {"bit_identical": bool(err_l == 0.0 and err_s == 0.0), "max_abs_logit_diff_full_model": err_l, "max_abs_state_diff_full_model": err_s}
         timed_ok = True
         if not timed["bit_identical"]:
-            # The matrix-core arm ran (F16 low-rank stages / FP16 file). Its products agree with the oracle's to rounding, but a 24 - 32-layer
-            # network of RANDOM weights amplifies any rounding difference (it is chaotic: 1e-7 grows to 1e-2 over 32 layers x 128 tokens), so
-            # the tolerance is checked where it means something: on a TWO-layer slice of the same geometry, same tokens -- exact arm bit for
-            # bit, timed arm within 1e-2 * (1 + max |oracle|) on logits and state (what tests/test_gpu_seq_f16.py asserts and explains:
-            # every PRODUCT is inside 2e-6 relative; RWKV-7's recurrence amplifies a last-bit difference to ~4e-3 over 128 tokens).
             from rwkv_cpp_amd import synth as synth_mod
             sp = os.path.join(args.model_dir, f"synthetic-{args.config}-{args.dtype}-slice2.bin")
             synth_mod.write_model(sp, spec, args.dtype, seed=42, limit_layers=2)
@@ -446,32 +499,33 @@ def bench_prefill(args, pkg, lib, path, spec, torch):
             sol, sost = som.eval_sequence(prompt[:n], som.init_state())
             som.free()
             sm = pkg.RWKVModel(lib, sp, thread_count=1, gpu_layer_count=3)
-            sm.state_load(None)
-            sl = sm.eval_resident(prompt[:n], want_logits=True)
-            sst = sm.state_store()
-            with exact_arms():
+            with seq_arms("fast"):
                 sm.state_load(None)
-                xl = sm.eval_resident(prompt[:n], want_logits=True)
-                xst = sm.state_store()
+                sl = sm.eval_resident(prompt[:n], want_logits=True)
+                sst = sm.state_store()
+            sm.state_load(None)
+            xl = sm.eval_resident(prompt[:n], want_logits=True)
+            xst = sm.state_store()
             sm.free()
             os.remove(sp)
-            # RWKV-7 / FP16 files (F16 matrices on the matrix cores feed the decay and the in-context learning rate): 1e-2; files whose only
-            # non-exact arm is the quantised GEMM in plain K order: 1e-3
-            # (measured on the two-layer 1.6B slice over 1024 tokens: 1.4e-3 -- a random-weight network amplifies the 1e-6 of a product a
-            #  thousandfold through two layers of exp / WKV accumulation; one-layer slices stay inside 1e-4: tests/test_gpu_prefill_fast.py)
+            # 1e-2 * (1 + max |oracle|) on logits and state: a product is inside 2e-6 relative (tests/test_gpu_prefill_fast.py, test_gpu_seq_f16.py);
+            # two layers of exp / WKV accumulation amplify it (1.4e-3 measured on the 1.6B slice over 1024 tokens, 4e-3 on RWKV-7's recurrence
+            # over 128); one-layer slices stay inside 1e-4 in the test suite
             rel = 1e-2
             tol_l, tol_s = rel * (1.0 + float(np.abs(sol).max())), rel * (1.0 + float(np.abs(sost).max()))
             e_l, e_s = float(np.abs(sl - sol).max()), float(np.abs(sst - sost).max())
             timed_ok = bool(e_l <= tol_l and e_s <= tol_s and np.array_equal(xl, sol) and np.array_equal(xst, sost))
             timed.update({"two_layer_slice": {"max_abs_logit_diff": e_l, "max_abs_state_diff": e_s, "tolerance_logits": tol_l, "tolerance_state": tol_s,
-                                              "exact_arm_bit_identical": bool(np.array_equal(xl, sol) and np.array_equal(xst, sost)), "within_tolerance": timed_ok}})
+                                              "default_arm_bit_identical": bool(np.array_equal(xl, sol) and np.array_equal(xst, sost)), "within_tolerance": timed_ok}})
+        gate = fast_arm_gate(args, model, prompt, spec, np)
+        timed["whole_model_gate"] = gate
+        timed_ok = timed_ok and gate["ok"]
         equal = exact and timed_ok
-        result["parity"] = {"tokens_checked": n, "equal": equal, "exact_arm_bit_identical": exact, "timed_arm": timed,
-                            "what": "logits and state after the first tokens of the prompt, GPU sequence pass vs CPU oracle: bit for bit on the exact arms "
-                                    "(RWKV_MI_SEQ_F16=valu RWKV_MI_SEQ_Q=exact); the timed defaults run the quantised GEMM with the block sums in plain K order "
-                                    "(k_mmq_fast) and F16 matrices on the matrix cores (k_mmf16_seq): same operands, equal to rounding per product "
-                                    "(tests/test_gpu_prefill_fast.py, tests/test_gpu_seq_f16.py), checked end to end on a two-layer slice of the same geometry "
-                                    "within 1e-2 * (1 + max |oracle|); ONE-layer slices are held to 1e-4 in the test suite"}
+        result["parity"] = {"tokens_checked": n, "equal": equal, "default_arms_bit_identical": exact, "fast_arms": timed,
+                            "what": "logits and state after the first tokens of the prompt, GPU sequence pass vs CPU oracle: bit for bit on the default arms "
+                                    "(k_mmq_mfma / k_mvf: what `value` times); the opt-in arms (RWKV_MI_SEQ_Q=fast RWKV_MI_SEQ_F16=mfma) within 1e-2 * (1 + max |oracle|) "
+                                    "on a two-layer slice of the same geometry, and on the whole model: the 64 greedy tokens behind the pass equal the default arms', "
+                                    "|sum(logits_fast - logits_default)| <= 1.05 x the value recorded in tests/reference_constants.py"}
         result["cpu_baseline"] = {"value": n / cpu_s, "unit": "tokens/s", "cores": usable_cores(), "kind": "port",
                                   "sample": f"{n}-token sequence pass of the same file on the host CPU ({cpu_s:.1f}s)"}
         if not equal:

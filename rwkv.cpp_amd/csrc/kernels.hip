@@ -278,7 +278,7 @@ static void launch_mvf_t(const DevTensor & W, const float * x, int64_t ldx, int6
 // rounding: measured <= 3e-6 relative on the logits. The contract allows exactly that: the reference promises serial == sequence
 // bit for bit only for FP32 files (tests/test_eval_sequence_in_chunks.c:54 runs on an FP32 model) and validates FP16 against recorded
 // thresholds (tests/test_tiny_rwkv.c:38-54). FP32 matrices therefore stay on k_mvf (memcmp equality), F16 matrices take this kernel
-// from k_mfma_min_tokens tokens per pass on (RWKV_MI_SEQ_F16=valu keeps them on k_mvf: the bit-exact A/B arm of the tests).
+// from k_mfma_min_tokens tokens per pass on WHEN RWKV_MI_SEQ_F16=mfma asks for it (round 6: the default keeps them on k_mvf, bit-identical to the serial path).
 //
 // These products are short (K = 64 .. 320 for the second low-rank stages, N = 64 .. 320 for the first) and were 22 % of an RWKV-7 2.9B
 // pass on the VALU kernel (62 of 281 ms, round-3 review).
@@ -407,9 +407,10 @@ __global__ __launch_bounds__(256) void k_mmf16_combine(MfArgs p) {
 
 std::atomic<unsigned long long> g_mmf16_launches{0};   // launches of k_mmf16_seq by this process (tests assert that the arm they mean to test ran)
 
+// RWKV_MI_SEQ_F16 = valu (default since round 6: ggml's addition order, sequence == serial bit for bit) | mfma (opt-in: k_mmf16_seq on the matrix cores)
 static bool seq_f16_on_mfma() {   // (read per call: the test suite runs both arms in one process)
     const char * e = getenv("RWKV_MI_SEQ_F16");
-    return !(e && e[0] == 'v');
+    return e && e[0] == 'm';
 }
 
 // workspace of the split-K form (partial tiles), one per device and STREAM SLOT: launches of one stream are ordered, so a stream can

@@ -50,7 +50,7 @@ __device__ __forceinline__ void tg_store(xrsrc xr, int unit, unsigned a, unsigne
 __device__ __forceinline__ v4u tg_load(xrsrc xr, int unit) { return __builtin_amdgcn_raw_buffer_load_b128(xr, unit * 16, 0, 16); }
 __device__ __forceinline__ bool tg_ok(const v4u & v, unsigned tag) { return (v.w & 0xFFFFu) == (tag & 0xFFFFu); }
 
-struct Poll { unsigned * ctl; bool dead; const void * xch = nullptr; /* base of the exchange arena (ring_v6.hip: the scalar-path look at a sentinel) */ };
+struct Poll { unsigned * ctl; bool dead; const void * xch = nullptr; /* base of the exchange arena (ring_v6.hip: the scalar-path look at a sentinel) */ bool sw = false; /* ... this wave looks through the scalar path */ };
 
 __device__ __forceinline__ bool poll_backoff(Poll & pl, unsigned spin) {
     if ((spin & 63u) == 63u) {

@@ -1255,7 +1255,7 @@ bool launch_mmq_mfma_batched(int n, const DevTensor * const * Ws, const TileAct 
                              const MmqWs * ws, hipStream_t st) {
     if (n < 1 || n > MMQ_BATCH) return false;
     for (int i = 1; i < n; i++) if (Ws[i]->type != Ws[0]->type || Ws[i]->rows() != Ws[0]->rows() || Ws[i]->cols() != Ws[0]->cols()) return false;
-    // the default arm: block sums in plain K order (prefill_fast.hip) where the shape fills the chip; RWKV_MI_SEQ_Q=exact keeps the walk below
+    // RWKV_MI_SEQ_Q=fast: block sums in plain K order (prefill_fast.hip) where the shape fills the chip; the default is the walk below (bit-identical to the serial path)
     if (launch_mmq_fast(n, Ws, xs, ys, epis, T, ldy, st)) return true;
     switch (Ws[0]->type) {
         case T_Q4_0: return launch_mmq_mfma_t<T_Q4_0>(n, Ws, xs, ys, epis, T, ldy, ws, st);

@@ -1,6 +1,7 @@
 // prefill_fast.hip -- the quantised projections of sequence mode (every ggml_mul_mat of rwkv_build_sequential_graph, rwkv_graph.inc:744-866,
 // with T >= 64 columns) as an int8 GEMM on v_mfma_i32_32x32x32_i8 whose block sums are accumulated in PLAIN K ORDER, one f32 accumulator
-// per output: the default arm of sequence mode for quantised matrices (RWKV_MI_SEQ_Q=exact keeps k_mmq_mfma of prefill.hip).
+// per output: the opt-in arm of sequence mode for quantised matrices (RWKV_MI_SEQ_Q=fast; the default keeps k_mmq_mfma of prefill.hip, bit-identical
+// to the serial path -- round 5 shipped this arm as the default, round 6 turned that around: ADVICE.md, `chunking must not change results`).
 //
 // What is kept of ggml's product: the quantised operands (Q8_0 / Q8_1 activations per 32-block, the weight codes), the exact integer block
 // sums, f32 accumulation of d_w d_x isum (+ m_w s_x). What is not: the ORDER of the f32 additions (ggml / the single-token kernel: 64
@@ -293,12 +294,15 @@ __global__ __launch_bounds__(256, 2) void k_mmq_fast(FastArgs A) {
 
 std::atomic<unsigned long long> g_mmq_fast_launches{0};   // launches of k_mmq_fast by this process (tests assert the arm they mean ran)
 
-// RWKV_MI_SEQ_Q = fast (default) | exact | force (tests: the plain-order kernel also on shapes with too few tiles to be worth it). Read per
-// call: the test suite runs the arms in one process.
+// RWKV_MI_SEQ_Q = exact (default since round 6) | fast | force (tests: the plain-order kernel also on shapes with too few tiles to be worth
+// it). Read per call: the test suite runs the arms in one process. The default is the arm that keeps rwkv_eval_sequence bit-identical to
+// repeated rwkv_eval whatever the chunking (ggml's mul_mat runs the same vec_dot per column for every T, so the reference has that property
+// for quantised files too); the plain-order kernel is an opt-in for callers that take its stated tolerance for +15 % prefill throughput.
 static int seq_q_arm() {
     const char * e = getenv("RWKV_MI_SEQ_Q");
-    if (e && e[0] == 'e') return 0;
-    return (e && e[0] == 'f' && e[1] == 'o') ? 2 : 1;
+    if (e && e[0] == 'f' && e[1] == 'a') return 1;
+    if (e && e[0] == 'f' && e[1] == 'o') return 2;
+    return 0;
 }
 
 static std::mutex g_fast_mu;

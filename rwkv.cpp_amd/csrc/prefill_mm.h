@@ -92,7 +92,7 @@ struct MmqArgs {
 };
 
 
-// prefill_fast.hip: the same product with the block sums accumulated in plain K order (RWKV_MI_SEQ_Q = fast | exact); false = this shape
+// prefill_fast.hip: the same product with the block sums accumulated in plain K order (RWKV_MI_SEQ_Q = exact (default) | fast); false = this shape
 // or format stays on the exact kernel
 bool launch_mmq_fast(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy, hipStream_t st);
 void mmq_fast_prepare_current_device();

@@ -457,6 +457,7 @@ struct R6 {
 #endif
     static __device__ __forceinline__ bool look_turned(const Poll & pl, xrsrc xr, int unit, unsigned tag) {
 #if R6_SWATCH
+        if (!pl.sw) { const v4u v = tg_load(xr, unit); return __builtin_amdgcn_readfirstlane((int) tg_ok(v, tag)) != 0; }   // (R6_SWATCH = 2: the comm wave only)
         const unsigned off = (unsigned) __builtin_amdgcn_readfirstlane(unit) * 16u + 12u;
         const unsigned long long a = (unsigned long long) pl.xch;
         const unsigned long long base = (unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) a) | ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (a >> 32)) << 32);
@@ -1130,7 +1131,7 @@ struct R6 {
         // (The prologue parameters are loaded by EVERY consumer wave, also where waves 4, 5 take no part: a load under `if (pro)` is a
         //  conditional definition, and the compiler then waits for it and copies it right where it is issued.)
         const int F = p.F, nbF = F / 32;
-        Poll pl{p.ctl, false, p.xch};
+        Poll pl{p.ctl, false, p.xch, R6_SWATCH == 1};
         const M6Arena ar{p.arena};
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         const RingShape sh = shape(p);
@@ -1466,7 +1467,7 @@ struct R6 {
         const int g = NC;                              // gather share
         const int F = p.F, DR = p.DR, R = p.R, H = p.H;
         const int nbF = F / 32;
-        Poll pl{p.ctl, false, p.xch};
+        Poll pl{p.ctl, false, p.xch, R6_SWATCH != 0};
         const M6Arena ar{p.arena};
         const xrsrc xr = make_xrsrc(p.xch, p.xch_bytes);
         const int mat = (blk * (4 * D / NBLK)) / D;

@@ -43,6 +43,11 @@ def lib():
         L.orc_bytes_per_token.argtypes = [P]
         L.orc_init_state.argtypes = [P, P]
         L.orc_set_threads.argtypes = [ctypes.c_int]
+        # (tests: at most 16 threads -- the models are small, and a shared host with more threads than free cores crawls; bench.py sets its own count)
+        try:
+            L.orc_set_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+        except Exception:
+            pass
         L.orc_set_fast.argtypes = [ctypes.c_int]
         L.orc_fast_uses_vnni.restype = ctypes.c_int
         L.orc_eval.restype = ctypes.c_int

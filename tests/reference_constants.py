@@ -68,3 +68,20 @@ def expected_logits(golden_dir, version):
     import os
     import numpy as np
     return np.fromfile(os.path.join(golden_dir, f"expected-logits-{version}.bin"), dtype=np.float32)
+
+
+# The opt-in sequence arms (RWKV_MI_SEQ_Q=fast RWKV_MI_SEQ_F16=mfma) against the default ones on the WHOLE benchmarked model, recorded on an MI355X
+# by `bench.py --mode prefill` (round 6; synthetic weights of the named geometry, seed 42, the bench's prompt). The analogue of the reference's
+# criterion for quantised formats (tests/logit_difference_validator.inc:68,83): (config, dtype, prompt tokens) ->
+# sum over the vocabulary of (logits_fast - logits_default) after the pass; a later run must stay inside 1.05 x |recorded|.
+FAST_ARM_LOGIT_DIFFERENCE_SUM = {
+    ("rwkv6-1b6", "Q4_0", 1024): -0.7023004796355963,
+    ("rwkv7-2b9", "Q5_1", 1024): +0.7769884578883648,
+}
+# ... and whether the 64 greedy tokens behind the pass were the default arms' when that was recorded. RWKV-6 1.6B: yes. RWKV-7 2.9B: NO -- with
+# random weights its logits are nearly flat (the arms differ by 0.04 at most) and the continuation parts ways: the opt-in arms are not offered as
+# equivalent there, which is one reason they are not the default.
+FAST_ARM_GREEDY_CONTINUATION_EQUAL = {
+    ("rwkv6-1b6", "Q4_0", 1024): True,
+    ("rwkv7-2b9", "Q5_1", 1024): False,
+}

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from conftest import FAST_ARM_REL_TOL, SEQ_ARM_ENV
 from gpu_lib import library, model, synth
 
 pytestmark = pytest.mark.gpu
@@ -64,6 +65,20 @@ def _check(tmp_path, name, fmt, seed, want_path, env_off, env_on=None):
     assert np.array_equal(gst, ost), (name, fmt, "sequence state", float(np.abs(gst - ost).max()))
     cl, cst = g.eval_sequence_in_chunks(seq, None, chunk_size=40)
     assert np.array_equal(cl, ol) and np.array_equal(cst, ost)
+    # ... and the same pass on the opt-in arms (plain-order quantised GEMM, F16 matrices on the matrix cores): the stated tolerance
+    prev = {k: os.environ.get(k) for k in SEQ_ARM_ENV["fast"]}
+    os.environ.update(SEQ_ARM_ENV["fast"])
+    try:
+        fl, fst = m.eval_sequence(seq, None)
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for got, want, what in ((fl, ol, "logits"), (fst, ost, "state")):
+        err, tol = float(np.abs(got - want).max()), FAST_ARM_REL_TOL * (1.0 + float(np.abs(want).max()))
+        assert np.isfinite(got).all() and err <= tol, (name, fmt, "fast arms", what, err, tol)
     m.free(); g.free(); om.free()
 
 

@@ -19,6 +19,8 @@ import subprocess
 
 import pytest
 
+from conftest import SEQ_ARM_ENV
+
 from gpu_lib import library
 
 pytestmark = pytest.mark.gpu
@@ -37,22 +39,40 @@ def _binary(name):
     return p
 
 
-def _run(name, tmp_path):
+def _run(name, tmp_path, arm="exact"):
     library()  # makes sure librwkv.so is built
     for f in os.listdir(GOLDEN):
         if f.endswith(".bin"):
             shutil.copy(os.path.join(GOLDEN, f), tmp_path / f)
     env = dict(os.environ)
     env.pop("RWKV_MI_NO_MEGA", None)
+    env.update(SEQ_ARM_ENV[arm])   # the product's default arms (exact) / the opt-in arms: the reference's own thresholds hold on both
     return subprocess.run([_binary(name)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
 
 
+@pytest.mark.parametrize("arm", ["exact", "fast"])
 @pytest.mark.parametrize("name", ["test_quantization_format_compatibility", "test_eval_sequence_in_chunks",
                                   "test_logit_calculation_skipping", "test_context_cloning"])
-def test_reference_program_passes(name, tmp_path):
-    r = _run(name, tmp_path)
+def test_reference_program_passes(name, arm, tmp_path):
+    r = _run(name, tmp_path, arm)
     assert r.returncode == 0, f"{name} exited with {r.returncode}\n{r.stderr[-4000:]}"
     assert "Assertion failed" not in r.stderr
+
+
+@pytest.mark.parametrize("arm", ["exact", "fast"])
+def test_reference_tiny_rwkv_with_the_missing_6v0_entry_skipped(arm, tmp_path):
+    """The reference's test_tiny_rwkv.c, its 6v0 entry skipped at build time (oracle/Makefile: the mount has no 6v0 FP32 / FP16 fixture): RWKV-4,
+    5.1, 5.2 and RWKV-7 in FP32, FP16 and every quantised format from both sources -- 48 models, serial and sequence mode, every recorded
+    threshold of test_tiny_rwkv.c:38-134 for them -- must pass, i.e. the program exits 0 (it aborts at the end when any check failed)."""
+    r = _run("test_tiny_rwkv_no6v0", tmp_path, arm)
+    err = r.stderr
+    assert r.returncode == 0, f"exit code {r.returncode}\n{err[-4000:]}"
+    assert "Assertion failed" not in err and "6v0" not in err
+    tested = [l for l in err.splitlines() if l.startswith("Testing tiny-rwkv-")]
+    assert len(tested) == 48, tested
+    for arch in ("4v0-660K", "5v1-730K", "5v2-730K", "7v0-834K"):
+        assert sum(arch in l for l in tested) == 12
+    assert err.count("Serial difference sum") == 48 and err.count("Sequence difference sum") == 48
 
 
 def test_reference_tiny_rwkv_passes_until_the_missing_fixture(tmp_path):

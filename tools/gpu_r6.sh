@@ -48,6 +48,16 @@ fold)   # embedding + ln0 + argmax inside k6_ring: tests, parity against the CPU
     for v in ${VARIANTS:-f e}; do RWKV_LIB_DIR=lib_$v bench_one ${v}_$rep rwkv6-7b Q4_0 --parity-tokens 0; done
   done
   ;;
+seq)    # sequence mode: default (exact) and opt-in (fast) arms -- tests, then the prefill lines with the whole-model gate
+  timeout 1500 python -X faulthandler -m pytest tests/test_gpu_prefill.py tests/test_gpu_prefill_fast.py tests/test_gpu_seq_f16.py tests/test_gpu_real_geometry.py tests/test_gpu_reference_programs.py -m gpu -x -q -p no:cacheprovider > $O/pytest.txt 2>&1; tail -5 $O/pytest.txt
+  pline() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline',{}); p=d.get('parity',{}); f=d.get('fast_arms',{})
+print('\$1', round(d['value'],1), d['unit'], round(d['ms_per_step'],3), 'ms/pass', 'gemm TOP/s', round(r.get('achieved',0),1), '| fast arms', round(f.get('tokens_per_s',0),1), 'tok/s', round(f.get('gemm_TOPs_in_launches',0),1), 'TOP/s | parity', p.get('equal'), p.get('default_arms_bit_identical'), json.dumps(p.get('fast_arms',{}))[:700], flush=True)
+" | sed "s/^\\\$1/$1/"; }
+  timeout 500 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 25 --parity-tokens ${PARITY:-128} > $O/prefill_1b6_q4_0.json 2> $O/prefill_1b6.err; tail -1 $O/prefill_1b6_q4_0.json | pline 1b6; tail -2 $O/prefill_1b6.err
+  timeout 500 python bench.py --config rwkv7-2b9 --dtype Q5_1 --mode prefill --steps 3 --warmup 1 --cpu-seconds 8 --parity-tokens 128 > $O/prefill_7v_2b9_q5_1.json 2> $O/prefill_2b9.err; tail -1 $O/prefill_7v_2b9_q5_1.json | pline 2b9; tail -2 $O/prefill_2b9.err
+  ;;
 suite)
   ( timeout 2700 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15 ) > $O/pytest.txt; cat $O/pytest.txt
   grep -q " passed" $O/pytest.txt || { echo "SUITE DID NOT FINISH: no evidence recorded"; exit 1; }
