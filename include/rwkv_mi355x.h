@@ -69,6 +69,11 @@ RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx);
 /* Which persistent kernel serves decode path 2: 2 = weights streamed through an LDS ring by a loader wave (LDS-DMA; the default where the
  * model qualifies), 1 = weights prefetched into the registers of the waves that use them (RWKV_MI_PERSIST=regs), 0 = path 2 not active. */
 RWKV_API int rwkv_mi_persist_kind(const struct rwkv_context * ctx);
+/* "persist: ring|regs|k47|none; <why>" -- the kernel above by name and what decided it: the device (the persistent kernels need all 256 CUs of an
+ * unpartitioned MI355X; rwkv_get_system_info_string() carries PERSISTENT_DECODE=available|unavailable for the current device), the model's
+ * format / geometry, the environment, the calibration's two figures, or a fall-back after a poll time-out at run time (a second process on the
+ * GPU). The string is valid until the next call on this thread. */
+RWKV_API const char * rwkv_mi_persist_info(struct rwkv_context * ctx);
 
 /* How long the payload of the model file took to reach HBM at rwkv_init_from_file (parallel reads into pinned staging buffers,
  * asynchronous copies, re-pack kernels; the reference reads one tensor at a time, rwkv_file_format.inc:302-313), and its bytes. */

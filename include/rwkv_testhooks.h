@@ -17,6 +17,9 @@ RWKV_API bool rwkv_mi_test_set_tag(struct rwkv_context * ctx, uint32_t base);
 /* Test hook (used by tests/ only): the next n state initialisations inside rwkv_eval / rwkv_init fail (error-path tests). */
 RWKV_API void rwkv_mi_test_fail_state_init(int n);
 
+/* Sets the persistent kernel's abort word as a timed-out poll would: the next single-token step drains at once and the context falls back. */
+RWKV_API bool rwkv_mi_test_force_abort(struct rwkv_context * ctx);
+
 /* Test hook (used by tests/ only): how often the F16 matrix-core sequence kernel has been launched by this process. */
 RWKV_API uint64_t rwkv_mi_test_mmf16_launches(void);
 

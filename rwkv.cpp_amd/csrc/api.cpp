@@ -236,6 +236,8 @@ RWKV_API const char * rwkv_get_system_info_string(void) {
             (void) hipGetDevice(&dev);
             if (hipGetDeviceProperties(&p, dev) == hipSuccess) {
                 s += " | HIP=1 DEVICES=" + std::to_string(n) + " ARCH=" + std::string(p.gcnArchName) + " CU=" + std::to_string(p.multiProcessorCount);
+                // the one-launch-per-token kernels need every CU of an unpartitioned part (rwkv_mi_persist_info says what a context got and why)
+                s += p.multiProcessorCount == 256 ? " PERSISTENT_DECODE=available" : " PERSISTENT_DECODE=unavailable(needs_256_CUs)";
             }
         } else {
             s += " | HIP=0";
@@ -475,6 +477,16 @@ RWKV_API bool rwkv_mi_decode_healthy(struct rwkv_context * ctx) {
 
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx) { return ctx->mega ? 2 : ((ctx->fused_v6 || ctx->fused_v7 || ctx->fused_v4) ? 1 : 0); }
 RWKV_API int rwkv_mi_persist_kind(const struct rwkv_context * ctx) { return mega_v6_kind(ctx->mega); }
+// "persist: ring | regs | k47 | none; <why>": which persistent kernel serves this context's single-token steps and what decided it
+// (geometry / device / environment at creation, the calibration's figures, a fall-back after a poll time-out). Valid until the next call on ctx.
+RWKV_API const char * rwkv_mi_persist_info(struct rwkv_context * ctx) {
+    static thread_local std::string out;
+    rwkv_context * c = ctx->stages.empty() ? ctx : ctx->stages.front();
+    const int k = mega_v6_kind(c->mega);
+    out = std::string("persist: ") + (k == 2 ? "ring" : (k == 1 ? "regs" : (k == 3 ? "k47" : "none")));
+    if (!c->persist_note.empty()) out += "; " + c->persist_note;
+    return out.c_str();
+}
 
 // seconds the payload of the model file took to reach HBM (reads + host-to-device copies + re-pack kernels), and its bytes
 RWKV_API void rwkv_mi_load_stats(const struct rwkv_context * ctx, double * seconds, uint64_t * bytes) {

@@ -996,6 +996,28 @@ bool mega_v6_clear_abort(void * h, hipStream_t st) {
     mg->h_ctl[1] = 0u;
     return hipMemsetAsync(mg->ctl + 1, 0, sizeof(unsigned), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
 }
+unsigned * mega_v6_ctl(void * h) { return is_ring(h) ? ring_v6_ctl(h) : (is_p47(h) ? p47_ctl(h) : ((MegaV6 *) h)->ctl); }
+// Test hook: the abort word set from the host, as a poll that timed out would set it -- the next launch drains at once, the host finds the
+// word behind it and the context falls back to the per-layer launches (engine.hip, recover_from_abort).
+bool mega_v6_force_abort(void * h, hipStream_t st) {
+    if (!h || hipStreamSynchronize(st) != hipSuccess) return false;
+    const unsigned one = 1u;
+    return hipMemcpy(mega_v6_ctl(h) + 1, &one, sizeof(one), hipMemcpyHostToDevice) == hipSuccess;
+}
+// Why no persistent kernel serves this model on this device (nullptr: one does). The kernels give every CU one workgroup and hand vectors
+// over between them inside the launch: they need all 256 CUs of an unpartitioned MI355X (a CPX / DPX partition or another part reports
+// fewer), quantised matrices of one format, 64-wide heads and a geometry that has an instantiation.
+const char * persist_unavailable_reason(const Model & m) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m.device) != hipSuccess) return "the device properties could not be read";
+    static thread_local char buf[160];
+    if (prop.multiProcessorCount != 256) { snprintf(buf, sizeof buf, "the device reports %d CUs: the persistent kernels need all 256 of an unpartitioned MI355X (SPX mode)", prop.multiProcessorCount); return buf; }
+    if (m.head_size != 64) return "head size is not 64";
+    if (m.arch_major == 5) return "RWKV-5 has no persistent kernel (per-op launches)";
+    const int t = (int) m.header.data_type;
+    if (t == T_F32 || t == T_F16) return "FP32 / FP16 files run the per-op launches (the persistent kernels stream quantised matrices)";
+    return "no instantiation for this geometry (n_embed / ffn size / ranks / vocabulary)";
+}
 // the tag generation the next launch starts from (ctl[0]), through the pinned mirror
 unsigned mega_v6_generation(void * h, hipStream_t st) {
     if (!mega_v6_ctl_fetch(h, st) || hipStreamSynchronize(st) != hipSuccess) return 0;

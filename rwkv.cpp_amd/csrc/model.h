@@ -1,5 +1,6 @@
 // model.h -- weights resident in HBM + the per-context execution state of librwkv.so.
 #pragma once
+#include <string>
 
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -166,6 +167,7 @@ struct rwkv_context {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t mega_done = nullptr;   // completion of this context's latest persistent-kernel launch (engine.hip: launches are chained per device)
+    std::string persist_note;         // why this context runs the single-token path it runs (rwkv_mi_persist_info: chosen kernel, calibration, fall-backs)
 
     // fused single-token path (fused_v6.hip) when the model qualifies
     bool  fused_v6 = false;
@@ -232,6 +234,11 @@ bool     mega_v6_ctl_fetch(void * h, hipStream_t st);       // async copy of the
 bool     mega_v6_aborted_cached(void * h);                  // the mirror's abort word (valid after the stream was synchronised)
 bool     mega_v6_aborted(void * h, hipStream_t st);         // fetch + synchronise + check
 bool     mega_v6_clear_abort(void * h, hipStream_t st);
+bool     mega_v6_force_abort(void * h, hipStream_t st);   // test hook: sets the abort word as a timed-out poll would
+unsigned * mega_v6_ctl(void * h);
+unsigned * p47_ctl(void * h);
+unsigned * ring_v6_ctl(void * h);
+const char * persist_unavailable_reason(const Model & m);   // nullptr: a persistent kernel exists for this model on this device
 bool     mega_v6_set_tag(void * h, unsigned base, hipStream_t st);
 unsigned mega_v6_generation(void * h, hipStream_t st);   // the hand-over generation the next launch starts from
 uint64_t mega_v6_bytes(void * h);

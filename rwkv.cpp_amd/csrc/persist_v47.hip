@@ -1831,6 +1831,7 @@ bool p47_ctl_fetch(void * h, hipStream_t st) {
     P47Handle * g = (P47Handle *) h;
     return hipMemcpyAsync(g->h_ctl, g->ctl, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess;
 }
+unsigned * p47_ctl(void * h) { return ((P47Handle *) h)->ctl; }
 bool p47_aborted_cached(void * h) { return ((P47Handle *) h)->h_ctl[1] != 0; }
 unsigned p47_generation_cached(void * h) { return ((P47Handle *) h)->h_ctl[0]; }
 bool p47_clear_abort(void * h, hipStream_t st) {

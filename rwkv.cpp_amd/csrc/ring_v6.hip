@@ -2297,6 +2297,7 @@ bool ring_v6_ctl_fetch(void * h, hipStream_t st) {
     RingV6 * rg = (RingV6 *) h;
     return hipMemcpyAsync(rg->h_ctl, rg->ctl, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess;
 }
+unsigned * ring_v6_ctl(void * h) { return ((RingV6 *) h)->ctl; }
 bool ring_v6_aborted_cached(void * h) { return ((RingV6 *) h)->h_ctl[1] != 0; }
 unsigned ring_v6_generation_cached(void * h) { return ((RingV6 *) h)->h_ctl[0]; }
 bool ring_v6_clear_abort(void * h, hipStream_t st) {

@@ -51,6 +51,12 @@ RWKV_API bool rwkv_mi_test_set_tag(struct rwkv_context * ctx, uint32_t base) {
     return mega_v6_set_tag(ctx->mega, base, ctx->stream);
 }
 
+// Test hook: the persistent kernel's abort word set from the host (what a poll that timed out leaves behind).
+RWKV_API bool rwkv_mi_test_force_abort(struct rwkv_context * ctx) {
+    if (!ctx->mega || hipSetDevice(ctx->model->device) != hipSuccess) return false;
+    return mega_v6_force_abort(ctx->mega, ctx->stream);
+}
+
 // Test hook: the next n state initialisations (state_from_host) of this process fail -- the error paths of rwkv_eval.
 RWKV_API void rwkv_mi_test_fail_state_init(int n) { g_test_fail_state_init.store(n); }
 

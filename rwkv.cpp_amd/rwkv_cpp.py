@@ -117,6 +117,9 @@ class RWKVSharedLibrary:
         L.rwkv_mi_decode_path.restype = ctypes.c_int
         L.rwkv_mi_persist_kind.argtypes = [c_ctx]
         L.rwkv_mi_persist_kind.restype = ctypes.c_int
+        if hasattr(L, "rwkv_mi_persist_info"):   # (absent from older A/B builds loaded through RWKV_LIB_DIR)
+            L.rwkv_mi_persist_info.argtypes = [c_ctx]
+            L.rwkv_mi_persist_info.restype = ctypes.c_char_p
         L.rwkv_mi_load_stats.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         L.rwkv_mi_load_stats.restype = None
         L.rwkv_mi_decode_healthy.argtypes = [c_ctx]
@@ -409,6 +412,10 @@ class RWKVModel:
         sec, b = ctypes.c_double(0.0), ctypes.c_uint64(0)
         self._library.library.rwkv_mi_load_stats(self._ctx.ptr, ctypes.byref(sec), ctypes.byref(b))
         return float(sec.value), int(b.value)
+
+    def persist_info(self) -> str:
+        """"persist: ring|regs|k47|none; <what decided it>" (rwkv_mi_persist_info)."""
+        return self._library.library.rwkv_mi_persist_info(self._ctx.ptr).decode("utf-8")
 
     def healthy(self) -> bool:
         return bool(self._library.library.rwkv_mi_decode_healthy(self._ctx.ptr))
