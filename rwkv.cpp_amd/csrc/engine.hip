@@ -706,6 +706,7 @@ bool forward(rwkv_context * ctx, int64_t T, bool want_logits) {
 // both directions at once from two threads); state_in == state_out is fine (a slice is read before its group runs, written after).
 // The state on the device is complete afterwards (state[cur]): a poll time-out of the persistent kernel falls back as before.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int k_abi_max_groups = 32;
 struct AbiStreamer {
     hipStream_t up = nullptr, down = nullptr;
     std::vector<hipEvent_t> ev_up, ev_done;
@@ -783,7 +784,7 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
         RW_CTX_CHECK(ctx, RWKV_ERROR_ALLOC, false, a != nullptr, "out of memory");
         a->device = m.device;
         bool ok = hipStreamCreateWithFlags(&a->up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&a->down, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; i < 8 && ok; i++) {
+        for (int i = 0; i < k_abi_max_groups && ok; i++) {
             hipEvent_t e1 = nullptr, e2 = nullptr;
             ok = hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
             if (e1) a->ev_up.push_back(e1);
@@ -794,7 +795,34 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
         ctx->abi_streamer = a;
     }
     const uint32_t L = m.layer_end - m.layer_begin;
-    const int G = (int) (L < 8 ? L : 8);
+    // Layer groups. What a call cannot hide is the upload of its FIRST slice and the download of its LAST one, so the groups are small at both
+    // ends and grow towards the middle: 1 1 2 4 8 | 8 4 2 1 1 layers for 32 (round 4 cut eight even groups: 4.3 MB exposed at each end of a 7B
+    // token, now 1.1 MB; two more launches). RWKV_MI_ABI_GROUPS=even restores the even cut (A/B).
+    std::vector<uint32_t> gsz;
+    {
+        static const bool even = [] { const char * e = getenv("RWKV_MI_ABI_GROUPS"); return e && e[0] == 'e'; }();
+        const char * lst = getenv("RWKV_MI_ABI_GROUPS");     // (measurement aid: an explicit list of group sizes, e.g. 1,3,12,12,3,1)
+        if (lst && lst[0] >= '0' && lst[0] <= '9') {
+            uint32_t sum = 0;
+            for (const char * q = lst; *q && (int) gsz.size() < k_abi_max_groups;) { const uint32_t v = (uint32_t) strtoul(q, (char **) &q, 10); if (v == 0) break; gsz.push_back(v); sum += v; if (*q == ',') q++; }
+            if (sum != L) gsz.clear();
+        }
+        if (!gsz.empty()) {}
+        else if (even || L < 8) { const uint32_t G0 = L < 8 ? L : 8; for (uint32_t g = 0; g < G0; g++) gsz.push_back((uint32_t) ((uint64_t) L * (g + 1) / G0 - (uint64_t) L * g / G0)); }
+        else {
+            std::vector<uint32_t> left, right;
+            uint32_t rest = L;
+            for (uint32_t i = 0, sz = 1; rest > 0; i++) {
+                const uint32_t a = sz < rest ? sz : rest; left.push_back(a); rest -= a;
+                if (rest > 0) { const uint32_t b = sz < rest ? sz : rest; right.push_back(b); rest -= b; }
+                if (i >= 1 && sz < 8) sz *= 2;      // 1 1 2 4 8 8 ...
+                if ((int) (left.size() + right.size()) >= k_abi_max_groups - 2 && rest > 0) { left.back() += rest; rest = 0; }
+            }
+            gsz = left;
+            for (size_t i = right.size(); i-- > 0;) gsz.push_back(right[i]);
+        }
+    }
+    const int G = (int) gsz.size();
     const int64_t per = m.state_per_layer();
     float * sin = ctx->state[ctx->cur];
     float * sout = ctx->state[ctx->cur ^ 1];
@@ -806,12 +834,16 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
     {
         std::lock_guard<std::mutex> lk(a->mu);
         a->slices.clear();
+        uint32_t lb = m.layer_begin;
         for (int g = 0; g < G; g++) {
-            const uint32_t lb = m.layer_begin + (uint32_t) ((uint64_t) L * g / G), le = m.layer_begin + (uint32_t) ((uint64_t) L * (g + 1) / G);
+            const uint32_t le = lb + gsz[(size_t) g];
             ranges.push_back({lb, le});
             a->slices.push_back({(int64_t) lb * per, (int64_t) (le - lb) * per});
+            lb = le;
         }
-        a->n_groups = h_out ? G : 0; a->published = 0; a->finished = 0; a->failed = false;
+        // (the LAST group's slice is brought back by this thread on the compute stream, right behind its layers and in front of the logits: handing
+        //  it to the download thread cost a wake-up of that thread and one of this one on the only part of the call nothing overlaps)
+        a->n_groups = h_out ? G - 1 : 0; a->published = 0; a->finished = 0; a->failed = false;
         a->h_out = h_out; a->d_out = sout;
         a->call++;
     }
@@ -830,7 +862,11 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
         }
         head_done = r.run_layers(ranges[(size_t) g].first, ranges[(size_t) g].second, want_logits) || head_done;
         ok = hipEventRecord(a->ev_done[(size_t) g], ctx->stream) == hipSuccess;
-        if (ok && h_out) { { std::lock_guard<std::mutex> lk(a->mu); a->published = g + 1; } a->cv.notify_all(); }
+        if (ok && h_out && g + 1 < G) { { std::lock_guard<std::mutex> lk(a->mu); a->published = g + 1; } a->cv.notify_all(); }
+    }
+    if (ok && h_out) {
+        const auto sl = a->slices[(size_t) (G - 1)];
+        ok = hipMemcpyAsync(h_out + sl.first, sout + sl.first, (size_t) sl.second * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
     }
     if (chained) mega_chain_end(ctx);
     if (ok && want_logits && !head_done) r.run_head();
