@@ -47,6 +47,7 @@ struct R6P {
     unsigned ring_bytes, mirror_bytes;                 // LDS ring (multiple of 4 KiB) and how much of its head is repeated behind its end
     int inflight, thin;                                // loader: DMA instructions in flight (normal / while the workgroup gathers)
     int look;                                          // consumers: records taken per look at a hand-over's sentinel (hint_take)
+    int look_g;                                        // ... at the kq hand-over (value records; RWKV_MI_RING_LOOKG)
     int hthin;                                         // ... while a wave of the workgroup watches a hand-over's sentinel (= inflight: no third level)
     int nap;                                           // extra 64-cycle sleeps between two looks at a gather's sentinel unit
     int burst;                                         // loader: fills issued per round (between two looks at the consumers' positions)
@@ -940,7 +941,10 @@ struct R6 {
 #ifndef R6_PRE_MASK
 #define R6_PRE_MASK 255
 #endif
-    static constexpr int PRE_MASK = EPT > 4 ? R6_PRE_MASK : 0;
+#ifndef R6_PRE_MASK_SMALL   /* the same for D = 2048: rounds 3 / 4 measured -2.5 % and left it off; on round 6's kernel +0.6 % (1427.6 against 1419.5 tokens/s on the 1.6B, two alternations) */
+#define R6_PRE_MASK_SMALL 255
+#endif
+    static constexpr int PRE_MASK = EPT > 4 ? R6_PRE_MASK : R6_PRE_MASK_SMALL;
     // Stage 1 of a gather (gather_hint) with the wait put to use: until the hand-over's sentinel turns, the wave takes its records of
     // the coming phase as they land -- record 0, then 1, ... up to NP -- and never waits for a record once the hand-over is there.
     // Written as a straight sequence of NP steps (each: spin until "record t has landed" or "the hand-over turned"), not as one loop that
@@ -1315,7 +1319,9 @@ struct R6 {
             pre_begin<RG_G>(cs, pg);
             // (registers: not the long Q8_0 rows of the 7B geometry)
             watch_begin(l);
-            hint_take(cs, pl, l, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap, (PRE_MASK & 8) != 0 && G_PRE, pg);
+            { const unsigned lk = cs.look; cs.look = (unsigned) __builtin_amdgcn_readfirstlane(p.look_g);
+              hint_take(cs, pl, l, xr, p.kq + ((blk * 5 + c * 173) & 511), tagL + SLOT_KQ, l.fl + FL_HKQ, g1, p.nap, (PRE_MASK & 8) != 0 && G_PRE, pg);
+              cs.look = lk; }
             watch_end(l);
             sweep_begin(l);
             gather_qvec<KSL>(pl, xr, p.kq, F, tagL + SLOT_KQ, c, opq(lane), l.kq);
@@ -2222,6 +2228,8 @@ void * ring_v6_create(const Model & m) {
     q.hthin = snap(env_int("RWKV_MI_RING_HTHIN", q.inflight));
     q.look = env_int("RWKV_MI_RING_LOOK", 1);
     if (q.look < 1) q.look = 1;
+    q.look_g = env_int("RWKV_MI_RING_LOOKG", q.look);
+    if (q.look_g < 1) q.look_g = 1;
     q.nap = env_int("RWKV_MI_RING_NAP", 2);
     q.dbg = env_int("RWKV_MI_RING_DBG", 0);
     q.burst = env_int("RWKV_MI_RING_BURST", 24) / 4;   // in groups of four fills

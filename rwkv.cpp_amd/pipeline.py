@@ -404,8 +404,11 @@ def bench_pipeline(args, lib, path, spec, dist, rank, local_rank, world):
         "metric": "tokens/sec single-stream decode", "value": single_tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": single * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "int8 x int4 dot, f32 accumulate (Q4_0 weights, Q8_0 activations); f16 head", "data": "synthetic",
-        "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode through a layer pipeline of {world} GPUs (RCCL send/recv of the "
-                               f"residual stream between stages), state resident in HBM",
+        "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode through a layer pipeline of {world} ranks ("
+                               + ("RCCL send/recv of the residual stream between stages over xGMI" if dist.get_backend() == "nccl"
+                                  else f"torch.distributed backend '{dist.get_backend()}': host-staged send/recv of the residual stream, NOT RCCL") +
+                               "), state resident in HBM",
+                   "transport": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(),
                    "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": f"pp{world}", "stage_layers": ranges, "stage_decode_path": path_used,
                    "decode_loop": "librwkv.so stage runner (ncclSend / ncclRecv on the stage stream)" if comms else "torch.distributed send / recv per token"},
         "multi_stream": {"streams": world, "tokens_per_s_aggregate": total_tok_s, "ms_per_step": multi * 1e3 / args.steps,

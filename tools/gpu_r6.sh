@@ -58,6 +58,15 @@ print('\$1', round(d['value'],1), d['unit'], round(d['ms_per_step'],3), 'ms/pass
   timeout 500 python bench.py --config rwkv6-1b6 --dtype Q4_0 --mode prefill --steps 5 --warmup 2 --cpu-seconds 25 --parity-tokens ${PARITY:-128} > $O/prefill_1b6_q4_0.json 2> $O/prefill_1b6.err; tail -1 $O/prefill_1b6_q4_0.json | pline 1b6; tail -2 $O/prefill_1b6.err
   timeout 500 python bench.py --config rwkv7-2b9 --dtype Q5_1 --mode prefill --steps 3 --warmup 1 --cpu-seconds 8 --parity-tokens 128 > $O/prefill_7v_2b9_q5_1.json 2> $O/prefill_2b9.err; tail -1 $O/prefill_7v_2b9_q5_1.json | pline 2b9; tail -2 $O/prefill_2b9.err
   ;;
+sweep)  # the ring kernel's run-time knobs once more (records taken ahead in G and the deferred quantisation moved the balance): one box, alternating
+  export RWKV_MI_NO_AUTOTUNE=1 RWKV_MI_PERSIST=ring
+  for rep in 1 2; do
+    bench_one base_$rep rwkv6-7b Q4_0 --parity-tokens 0 --no-profile
+    for kv in NAP=0 NAP=1 NAP=4 LOOK=2 LOOK=3 THIN=8 THIN=24 INFLIGHT=32 INFLIGHT=40 HTHIN=16 HTHIN=24 BURST=12 BURST=16 HEAD_WG=0 HEAD_WG=64 HEAD_WG=192; do
+      env RWKV_MI_RING_$kv bash -c "$(declare -f line bench_one); O=$O; STEPS=${STEPS:-256}; bench_one ${kv}_$rep rwkv6-7b Q4_0 --parity-tokens 0 --no-profile"
+    done
+  done
+  ;;
 suite)
   ( timeout 2700 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15 ) > $O/pytest.txt; cat $O/pytest.txt
   grep -q " passed" $O/pytest.txt || { echo "SUITE DID NOT FINISH: no evidence recorded"; exit 1; }
