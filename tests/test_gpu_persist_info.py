@@ -2,6 +2,7 @@
 fall-back when its polls time out: the abort word is set from the host (what a timed-out poll leaves behind -- a second process on the GPU,
 a partitioned device), the next steps must still equal the oracle bit for bit, on the per-layer launches, and the context must say so."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -32,7 +33,8 @@ def test_fallback_after_a_forced_abort_keeps_parity_and_says_why(tmp_path, name,
     if m.decode_path() != 2:
         pytest.skip(f"the persistent path is not active on this box: {info}")
     assert info.split(";")[0] in tuple("persist: " + k for k in kinds), info
-    assert "calibration" in info and "ms / token" in info, info
+    if os.environ.get("RWKV_MI_NO_AUTOTUNE") != "1":     # (an earlier test of the session may have switched the timing at context creation off)
+        assert "calibration" in info and "ms / token" in info, info
     ost, st = om.init_state(), None
     for t in TOKENS[:3]:
         ol, ost = om.eval(t, ost)
