@@ -205,16 +205,43 @@ __device__ __forceinline__ void rec_wait(RawRec<FMT, R, U> & w) {
         }
 }
 
+// Round 6: 4-bit codes against NIBBLE PLANES of the activations (R6_DOT8; Q4_0 / Q4_1). The row phases are bound by VALU issue,
+// and 12 of a Q4 block's ~26 VALU instructions only unpack its nibbles into bytes for v_dot4. v_dot8_u32_u4 multiplies the packed nibbles as they
+// lie: with b = a + 128 (one xor per activation dword, 1 <= b <= 255) = 16 bh + bl,
+//     sum w a = 16 sum w bh + sum w bl - 128 sum w,
+// three dot8 per code dword (the last against 0x11111111) and no unpacking: 12 + 3 instead of 12 + 8 + 1 instructions per block. The nibble
+// planes are built once per phase and lane, in the order the weight nibbles lie in a code dword (byte t of dword j: low nibble = element 4 j + t,
+// high nibble = element 16 + 4 j + t). Integers are exact in any order: the block sum -- and everything behind it -- is bit for bit the same.
+// Built, bit-identical (parity tests + bench parity green), measured, OFF: 662.0 against 672.5 tokens/s on the 7B (three alternations on one box),
+// 1420.8 against 1432.3 on the 1.6B -- a third fewer VALU instructions per block and 1.5 % SLOWER: v_dot8_u32_u4 does not issue at v_dot4's rate on
+// this part, or the phases are less issue-bound than the per-SIMD record counts suggest; profiles/r06_dot8_ab.txt.
+#ifndef R6_DOT8
+#define R6_DOT8 0
+#endif
+template <int FMT> constexpr bool r6_nib() { return R6_DOT8 != 0 && (FMT == T_Q4_0 || FMT == T_Q4_1); }
 // The activation blocks a lane needs are the same for every record of a phase (block 64 u + lane of the image): read once per phase.
+// (nibble planes: alo[u] = the low nibbles of b, ahi[u] = the high nibbles, one dword per code dword)
 template <int U> struct ActRegs { int4 alo[U], ahi[U]; float dx[U], sx[U]; int asum[U]; };
-template <int U>
+template <int FMT, int U>
 __device__ __forceinline__ void act_load(ActRegs<U> & ar, const QVec & a, int nbk, int lane) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int bb = u * WAVE + lane;
         const int b = bb < nbk ? bb : nbk - 1;
-        ar.alo[u] = *reinterpret_cast<const int4 *>(a.q + b * 16);
-        ar.ahi[u] = *reinterpret_cast<const int4 *>(a.q + nbk * 16 + b * 16);
+        const int4 lo = *reinterpret_cast<const int4 *>(a.q + b * 16);
+        const int4 hi = *reinterpret_cast<const int4 *>(a.q + nbk * 16 + b * 16);
+        if constexpr (r6_nib<FMT>()) {
+            const unsigned l4[4] = {(unsigned) lo.x ^ 0x80808080u, (unsigned) lo.y ^ 0x80808080u, (unsigned) lo.z ^ 0x80808080u, (unsigned) lo.w ^ 0x80808080u};
+            const unsigned h4[4] = {(unsigned) hi.x ^ 0x80808080u, (unsigned) hi.y ^ 0x80808080u, (unsigned) hi.z ^ 0x80808080u, (unsigned) hi.w ^ 0x80808080u};
+            unsigned bl[4], bh[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bl[j] = (l4[j] & 0x0F0F0F0Fu) | ((h4[j] << 4) & 0xF0F0F0F0u);
+                bh[j] = ((l4[j] >> 4) & 0x0F0F0F0Fu) | (h4[j] & 0xF0F0F0F0u);
+            }
+            ar.alo[u] = make_int4((int) bl[0], (int) bl[1], (int) bl[2], (int) bl[3]);
+            ar.ahi[u] = make_int4((int) bh[0], (int) bh[1], (int) bh[2], (int) bh[3]);
+        } else { ar.alo[u] = lo; ar.ahi[u] = hi; }
         ar.dx[u] = a.d[b]; ar.sx[u] = a.s[b]; ar.asum[u] = a.isum[b];
     }
 }
@@ -229,6 +256,53 @@ __device__ __forceinline__ void rec_acc(const RawRec<FMT, R, U> & w, const ActRe
     constexpr int GU = (GB / R) < U ? ((GB / R) > 0 ? (GB / R) : 1) : U;
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
+    if constexpr (r6_nib<FMT>()) {
+        // nibble planes (see act_load): three v_dot8_u32_u4 chains per block, breadth first over the GU x R blocks of a group
+#pragma unroll
+        for (int u0 = 0; u0 < U; u0 += GU) {
+            unsigned sl[GU][R], sh[GU][R], sw[GU][R];
+#pragma unroll
+            for (int g = 0; g < GU; g++)
+#pragma unroll
+                for (int r = 0; r < R; r++) { sl[g][r] = 0u; sh[g][r] = 0u; sw[g][r] = 0u; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int g = 0; g < GU; g++) {
+                    if (u0 + g < U) {
+                        const int u = u0 + g;
+                        const unsigned bl = (unsigned) (k == 0 ? ar.alo[u].x : (k == 1 ? ar.alo[u].y : (k == 2 ? ar.alo[u].z : ar.alo[u].w)));
+                        const unsigned bh = (unsigned) (k == 0 ? ar.ahi[u].x : (k == 1 ? ar.ahi[u].y : (k == 2 ? ar.ahi[u].z : ar.ahi[u].w)));
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const wv4i & q = w.raw[u][r].q[0];
+                            const unsigned c = (unsigned) (k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w)));
+                            sl[g][r] = __builtin_amdgcn_udot8(c, bl, sl[g][r], false);
+                            sh[g][r] = __builtin_amdgcn_udot8(c, bh, sh[g][r], false);
+                            sw[g][r] = __builtin_amdgcn_udot8(c, 0x11111111u, sw[g][r], false);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < GU; g++) {
+                if (u0 + g < U) {
+                    const int u = u0 + g;
+                    const bool valid = u + 1 < U || u * WAVE + lane < nbk;   // (only the last step of a row can be short)
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        int sv = (int) ((sh[g][r] << 4) + sl[g][r]) - (int) (sw[g][r] << 7);      // sum w a = 16 sum w bh + sum w bl - 128 sum w
+                        if constexpr (QF<FMT>::OFF != 0) sv -= QF<FMT>::OFF * ar.asum[u];
+                        const float wd = h2f_bits((uint16_t) (w.raw[u][r].sc & 0xFFFFu));
+                        const float dd = wd * ar.dx[u];
+                        acc[r] = fmaf(dd, valid ? (float) sv : 0.0f, acc[r]);
+                        if constexpr (QF<FMT>::HM) acc[r] = fmaf(h2f_bits((uint16_t) (w.raw[u][r].sc >> 16)), valid ? ar.sx[u] : 0.0f, acc[r]);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int u0 = 0; u0 < U; u0 += GU) {
         WBlk<FMT> wb[GU][R];
@@ -1028,7 +1102,7 @@ struct R6 {
         auto has = [&](int t) { return t < TMIN || (unsigned) t < pre.cnt; };
         const int ln = opq(cs.lane);
         ActRegs<U> ar;
-        act_load<U>(ar, act, nbk, ln);
+        act_load<FMT, U>(ar, act, nbk, ln);
         // per-lane partial sums of every record of the phase; ONE interleaved butterfly over all of them at the end (a butterfly is six
         // dependent cross-lane steps: per record they ran back to back, two chains at a time)
         float part[(TF + 1) * R];
@@ -1601,7 +1675,7 @@ struct R6 {
             if (has_dw1) {
                 const int ln = opq(lane);
                 ActRegs<UD> arw;
-                act_load<UD>(arw, qvec_at(l.actw, D), nb, ln);
+                act_load<FMT, UD>(arw, qvec_at(l.actw, D), nb, ln);
                 float part[1];
                 rec_acc<FMT, 1, UD>(dwr, arw, nb, ln, part);
                 wave_sum_n<1>(part);
@@ -1755,7 +1829,7 @@ struct R6 {
                     prologue_wait(pl, l, 2u * li + 2u);              // l.q1 holds the quantised key input
                     const int lnK = opq(lane);
                     ActRegs<UD> ark;
-                    act_load<UD>(ark, qvec_at(l.q1, D), nb, lnK);
+                    act_load<FMT, UD>(ark, qvec_at(l.q1, D), nb, lnK);
                     float part[2 * KCOMM];
 #pragma unroll
                     for (int q = 0; q < KCOMM; q++) rec_acc<FMT, 2, UD>(kxr[q], ark, nb, lnK, part + 2 * q);
