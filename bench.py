@@ -568,7 +568,7 @@ def bench_chain(args, pkg, lib, path, spec, torch):
         "ms_per_step": ms / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": DTYPE_DESC.get(args.dtype, args.dtype), "data": "synthetic",
         "config": {"workload": f"{spec.name} {args.dtype} single-stream greedy decode through a layer chain of {n} stage(s) in one process "
-                               f"(RWKV_MI_DEVICES={devices}; C++ decode loop, per-stage hipGraphs, peer copies of the residual stream)",
+                               f"(RWKV_MI_DEVICES={devices}; C++ decode loop, one direct launch per stage, the residual stream stored by a stage's last layer in the next stage's buffer)",
                    "layers": spec.n_layer, "n_embed": spec.n_embed, "n_vocab": spec.n_vocab, "parallelism": f"pp{n} (one process)"},
         "multi_stream": {"streams": len(streams), "tokens_per_s_aggregate": len(streams) * args.steps / (mms / 1e3), "ms_per_step": mms / args.steps,
                          "note": "independent decode streams (clones) interleaved through the same chain: aggregate throughput"},

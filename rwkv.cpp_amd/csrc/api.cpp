@@ -476,7 +476,7 @@ RWKV_API bool rwkv_mi_decode_healthy(struct rwkv_context * ctx) {
 }
 
 RWKV_API int rwkv_mi_decode_path(const struct rwkv_context * ctx) { return ctx->mega ? 2 : ((ctx->fused_v6 || ctx->fused_v7 || ctx->fused_v4) ? 1 : 0); }
-RWKV_API int rwkv_mi_persist_kind(const struct rwkv_context * ctx) { return mega_v6_kind(ctx->mega); }
+RWKV_API int rwkv_mi_persist_kind(const struct rwkv_context * ctx) { return mega_v6_kind((ctx->stages.empty() ? ctx : ctx->stages.front())->mega); }   // (a chain: its first stage's)
 // "persist: ring | regs | k47 | none; <why>": which persistent kernel serves this context's single-token steps and what decided it
 // (geometry / device / environment at creation, the calibration's figures, a fall-back after a poll time-out). Valid until the next call on ctx.
 RWKV_API const char * rwkv_mi_persist_info(struct rwkv_context * ctx) {

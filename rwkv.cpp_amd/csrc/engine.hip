@@ -887,13 +887,27 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
     return true;
 }
 
+// A single-token step that is ONE persistent launch issued directly (no graph): no embedding launch in front of it (none to do, or folded)
+// and no head launches behind it (none wanted, or folded). A whole model additionally folds the argmax (the greedy loops' condition since
+// round 5); a pipeline stage qualifies since round 6 -- a chain of N stages paid N replays of a one-node graph per token
+// (RWKV_MI_STAGE_GRAPH=1 restores that for A/B). runner.cpp relies on this: only a direct launch sees a changed mega_v6_set_x_out.
+bool single_launch_step(const rwkv_context * ctx, bool want_logits) {
+    if (!ctx->mega) return false;
+    const Model & mm = *ctx->model;
+    static const bool replay = getenv("RWKV_MI_STAGE_GRAPH") != nullptr;
+    const bool one_launch = (!mm.has_embed || mega_v6_folds_embed(ctx->mega)) && (!(want_logits && mm.has_head) || mega_v6_folds_head(ctx->mega));
+    if (!one_launch) return false;
+    return (mm.has_embed && mm.has_head) ? mega_v6_folds_argmax(ctx->mega) : !replay;
+}
+
 // Single-token step through a captured hipGraph: one graph per (state parity, logits on/off), replayed per token so
 // that the ~100 short launches of a decode step cost one graph launch on the host.
 bool forward_decode(rwkv_context * ctx, bool want_logits) {
     if (!ctx->use_graph) return forward(ctx, 1, want_logits);
     // one launch per token (persist_v47.hip with embedding, head and argmax inside it): a direct launch from a busy stream costs the host
     // 3 - 5 us, the replay of a one-node graph 10 - 16 (guide row graph-replay-floor) -- at 250 us per token of the 169M that is the gap
-    if (ctx->mega && ctx->model->has_embed && ctx->model->has_head && mega_v6_folds_embed(ctx->mega) && mega_v6_folds_argmax(ctx->mega)) return forward(ctx, 1, want_logits);
+    // Round 6: the same holds for every stage of a layer pipeline whose step is ONE persistent launch (single_launch_step below).
+    if (single_launch_step(ctx, want_logits)) return forward(ctx, 1, want_logits);
     if (!ensure_scratch(ctx, 1)) return false;
     hipGraphExec_t & ge = ctx->graph_exec[ctx->cur][want_logits ? 1 : 0];
     if (!ge) {

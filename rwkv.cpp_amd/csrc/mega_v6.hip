@@ -946,6 +946,13 @@ bool mega_v6_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st) {
     if (is_p47(h)) return p47_set_history(h, hist, n, st);
     return is_ring(h) && ring_v6_set_history(h, hist, n, st);
 }
+// Pipeline stages: the launch that runs the stage's last layer writes the residual stream to x_out (the NEXT stage's input buffer, on this
+// or on a peer device) instead of back into its own x; nullptr restores the in-place form. false: this kernel has no such output.
+bool mega_v6_set_x_out(void * h, float * x_out) {
+    if (is_ring(h)) { ring_v6_set_x_out(h, x_out); return true; }
+    if (is_p47(h)) { p47_set_x_out(h, x_out); return true; }
+    return x_out == nullptr;
+}
 void mega_v6_forward_range(void * h, float * x, const float * sin, float * sout, hipStream_t st, rwkv_context::Prof * pf, float * logits, int l0, int l1, float * v_first,
                            const uint32_t * tok, uint32_t * next_tok) {
     if (is_p47(h)) { p47_forward_range(h, x, v_first, sin, sout, st, pf, l0, l1, logits, tok, next_tok); return; }

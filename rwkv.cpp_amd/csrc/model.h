@@ -230,6 +230,7 @@ bool     mega_v6_folds_embed(void * h);      // the launch starts from the token
 bool     mega_v6_folds_argmax(void * h);     // a launch that produces logits also writes their argmax to next_tok
 bool     mega_v6_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st);   // (folds_argmax) tokens appended on the device (at most n), no copy per token
 bool     mega_v6_folds_head(void * h);
+bool     mega_v6_set_x_out(void * h, float * x_out);        // the stage's last layer leaves x there (pipeline hops without a copy); nullptr: in place
 bool     mega_v6_ctl_fetch(void * h, hipStream_t st);       // async copy of the control words into the pinned mirror
 bool     mega_v6_aborted_cached(void * h);                  // the mirror's abort word (valid after the stream was synchronised)
 bool     mega_v6_aborted(void * h, hipStream_t st);         // fetch + synchronise + check
@@ -252,6 +253,7 @@ void     p47_forward_range(void * h, float * x, float * v_first, const float * s
 bool     p47_folds_embed(void * h);
 bool     p47_folds_head(void * h);
 bool     p47_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st);
+void     p47_set_x_out(void * h, float * x_out);
 int      p47_layers(void * h);
 bool     p47_ctl_fetch(void * h, hipStream_t st);
 bool     p47_aborted_cached(void * h);
@@ -270,6 +272,7 @@ bool     ring_v6_folds_head(void * h);
 bool     ring_v6_folds_embed(void * h);
 bool     ring_v6_folds_argmax(void * h);
 bool     ring_v6_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st);
+void     ring_v6_set_x_out(void * h, float * x_out);
 bool     ring_v6_ctl_fetch(void * h, hipStream_t st);
 bool     ring_v6_aborted_cached(void * h);
 unsigned ring_v6_generation_cached(void * h);
@@ -295,6 +298,7 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
 void abi_streamer_free(void * p);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
 bool forward_decode(rwkv_context * ctx, bool want_logits);
+bool single_launch_step(const rwkv_context * ctx, bool want_logits);   // the step is one directly issued persistent launch (no graph replay)
 // grows the per-context activation scratch to hold T tokens
 bool ensure_scratch(rwkv_context * ctx, int64_t T);
 uint32_t * folded_argmax_target(const rwkv_context * ctx);

@@ -79,6 +79,7 @@ struct P47 {
     const P47Layer * layers; int l0, l1;
     const unsigned char * arena;
     float * x; float * v_first;
+    float * x_out;                                   // where the last layer of the launch leaves x (= x; a pipeline stage: the next stage's x)
     const float * sin; float * sout; long long state_stride;
     void * xch; unsigned xch_bytes;
     int u_a, u_lr1, u_y, u_xatt, u_kq, u_xffn;      // unit (16-byte) offsets of the tagged buffers in the exchange arena
@@ -965,7 +966,7 @@ struct K47 {
                     if constexpr (V7) xown[r] = xown[r] + res[r];
                     else { const float gte = sigmoid_f(rgate[r]) * res[r]; xown[r] = xown[r] + gte; }
                 }
-                if (last && !p.logits) { const float xv = pick_lane<GPB>(xown, lane); if (lane < GPB) p.x[myrow] = xv; }
+                if (last && !p.logits) { const float xv = pick_lane<GPB>(xown, lane); if (lane < GPB) p.x_out[myrow] = xv; }
                 else x_store(p.u_xffn, tagL + S47_XFFN);        // (the last layer's x goes to every workgroup's ln_out when the head follows in this launch)
             }
             T47(10);
@@ -1613,6 +1614,7 @@ struct P47Handle {
     std::vector<uint64_t> layer_bytes;   // algorithmic bytes per layer: every tensor once + the recurrent state read and written
     bool fold_embed = false, fold_head = false;
     uint64_t embed_bytes = 0, head_bytes = 0;
+    float * x_out = nullptr;      // p47_set_x_out (pipeline stages, runner.cpp)
 };
 
 typedef void (*P47Kernel)(P47);
@@ -1798,6 +1800,7 @@ void p47_forward_range(void * h, float * x, float * v_first, const float * sin, 
     P47Handle * g = (P47Handle *) h;
     P47 q = g->proto;
     q.x = x; q.v_first = v_first; q.sin = sin; q.sout = sout; q.l0 = l0; q.l1 = l1;
+    q.x_out = (g->x_out && l1 == g->n_layers) ? g->x_out : x;
     q.tok = (g->fold_embed && l0 == 0) ? tok : nullptr;
     q.logits = (g->fold_head && l1 == g->n_layers) ? logits : nullptr;
     q.next_tok = next_tok;
@@ -1826,6 +1829,8 @@ bool p47_set_history(void * h, uint32_t * hist, size_t n, hipStream_t st) {
     return hipMemcpyAsync(g->ctl + 2, w, sizeof(w), hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
 }
 int p47_layers(void * h) { return ((P47Handle *) h)->n_layers; }
+
+void p47_set_x_out(void * h, float * x_out) { ((P47Handle *) h)->x_out = x_out; }
 
 bool p47_ctl_fetch(void * h, hipStream_t st) {
     P47Handle * g = (P47Handle *) h;

@@ -35,6 +35,7 @@ struct R6P {
     const unsigned char * arena;
     const float * w2b;                                 // W2 of every layer in the chunk-blocked layout (k_block_w2, mega_v6.hip)
     float * x;                                         // plain residual stream: input of the first layer, output of the last
+    float * x_out;                                     // where the last layer of the launch leaves it (= x; a pipeline stage: the next stage's x, through the peer mapping)
     const float * sin; float * sout; long long state_stride;
     void * xch; unsigned xch_bytes;                     // the exchange arena ...
     int tl, act5, rkvg, dl, yq, xatt, kq, xffn;         // ... buffers at these unit (16-byte) offsets
@@ -1408,7 +1409,7 @@ struct R6 {
                 constexpr int t = decltype(tc)::value;
                 const float gte = sigmoid_f(rrow[t]) * res[0];
                 xown[t] = xown[t] + gte;
-                if (li == p.n_layers - 1 && lane == 0) p.x[blk * RE + j] = xown[t];
+                if (li == p.n_layers - 1 && lane == 0) p.x_out[blk * RE + j] = xown[t];
             });
             if (lane == 0) tg_store(xr, p.xffn + blk * NC + c, __float_as_uint(xown[0]), __float_as_uint(xown[XT > 1 ? 1 : 0]), __float_as_uint(xown[XT > 2 ? 2 : 0]), 0u, tagL + SLOT_XFFN);
             R6STAMP(13); R6RSTAMP(14);
@@ -2056,6 +2057,7 @@ struct RingV6 {
     unsigned * h_ctl = nullptr;
     R6P proto{};
     long long * trace = nullptr;
+    float * x_out = nullptr;      // ring_v6_set_x_out: the last layer's x goes there instead of back into the launch's x (pipeline stages, runner.cpp)
 };
 
 typedef void (*RingKernel)(R6P);
@@ -2355,6 +2357,7 @@ void ring_v6_forward_range(void * h, float * x, const float * sin, float * sout,
     RingV6 * rg = (RingV6 *) h;
     R6P q = rg->proto;
     q.x = x;
+    q.x_out = (rg->x_out && l1 == rg->sh->n_layers) ? rg->x_out : x;
     q.tok = (rg->sh->embed && l0 == 0) ? tok : nullptr;
     q.layers = rg->sh->d_layers + l0; q.n_layers = l1 - l0; q.layer0 = l0; q.layers_total = rg->sh->n_layers;
     q.sin = sin + (long long) l0 * q.state_stride; q.sout = sout + (long long) l0 * q.state_stride;
@@ -2374,6 +2377,8 @@ void ring_v6_forward_range(void * h, float * x, const float * sin, float * sout,
         hipLaunchKernelGGL(fn, dim3((unsigned) rg->sh->n_blocks), dim3(512), rg->sh->lds, st, q);
     }
 }
+
+void ring_v6_set_x_out(void * h, float * x_out) { ((RingV6 *) h)->x_out = x_out; }
 
 bool ring_v6_ctl_fetch(void * h, hipStream_t st) {
     RingV6 * rg = (RingV6 *) h;

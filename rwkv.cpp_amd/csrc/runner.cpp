@@ -45,18 +45,48 @@ struct Hop {
     // call for a message is made before the receiver's.
     virtual bool send(int j, int msg, const void * src, size_t bytes, hipStream_t st) = 0;   // current device = the sender's
     virtual bool recv(int j, int msg, void * dst, size_t bytes, hipStream_t st) = 0;         // current device = the receiver's
+    // A hop that can write straight into the receiver's buffer is told where message (j, msg) is consumed; recv() into that address is then
+    // a wait only, and the receiver calls release() once everything that reads (or overwrites and forwards) the buffer is enqueued.
+    virtual bool bind(int, int, void *) { return false; }
+    virtual bool release(int, int, hipStream_t) { return true; }
+    // A bound message whose buffer the SENDER's kernel can write itself (same device, or the peer mapping is enabled): the address, else
+    // nullptr. The sender then brackets the launch that writes it with produce_begin() (the receiver is done with the previous content)
+    // and produce_end() (the message is there) instead of calling send().
+    virtual void * direct_target(int, int) { return nullptr; }
+    virtual bool produce_begin(int, int, hipStream_t) { return false; }
+    virtual bool produce_end(int, int, hipStream_t) { return false; }
 };
 constexpr int k_hop_msgs = 2;
 
 struct LocalHop : Hop {
     int src_dev, dst_dev;
-    struct Slot { void * box = nullptr; hipEvent_t ready = nullptr, taken = nullptr; bool used = false; };
+    struct Slot { void * box = nullptr; void * direct = nullptr; hipEvent_t ready = nullptr, taken = nullptr; bool used = false, released = false; };
     // One mailbox and one event pair PER MESSAGE of a stream's iteration: a stage of an RWKV-7 chain sends x and then v_first. Through
     // one box the second send only waited for the previous ITERATION's `taken` and overwrote x before the receiver had run -- both
     // receives then read v_first (round-3 review; tests/test_gpu_pipeline_cpp.py::test_rwkv7_greedy_loop_through_a_chain).
+    //
+    // Round 6: a BOUND slot has no mailbox in the path. The peer copy lands where the receiving stage reads the message (its residual
+    // stream, its token word) -- one copy per hop instead of two -- and `taken` is recorded by release() at the end of the receiver's
+    // iteration: that buffer is input, running residual stream and source of the receiver's own outgoing copy, so it is free only behind
+    // all three (pipeline.cpp's consumed_ev, same reason). A send waits for the latest release, also the first send of the token
+    // feedback: the first stage's token word holds the seed token until its first iteration has read it.
+    // Round 6, second step: where the sender's kernel can reach the receiver's buffer (one device, or peer access from the sender's
+    // device), the stage's last layer stores the residual stream THERE (mega_v6_set_x_out) and the hop is two event operations: no copy
+    // kernel between the stages (11 us from the end of the launch to the start of the copy, 4.7 us of copy, 17 us to the start of the next
+    // stage's launch in profiles/r06_hop_trace.txt).
     std::vector<Slot> slots;   // [stream][message]
     size_t cap;
+    bool peer_ok = false;      // kernels on src_dev may store to memory of dst_dev
     LocalHop(int sdev, int ddev, int n_streams, size_t bytes, bool & ok) : src_dev(sdev), dst_dev(ddev), slots((size_t) n_streams * k_hop_msgs), cap(bytes) {
+        peer_ok = sdev == ddev;
+        if (!peer_ok && hipSetDevice(sdev) == hipSuccess) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, sdev, ddev) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(ddev, 0);
+                peer_ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+            }
+            (void) hipGetLastError();
+        }
         ok = hipSetDevice(ddev) == hipSuccess;
         for (Slot & s : slots) {
             ok = ok && hipMalloc(&s.box, bytes) == hipSuccess;
@@ -71,21 +101,60 @@ struct LocalHop : Hop {
             if (s.taken) (void) hipEventDestroy(s.taken);
         }
     }
+    Slot * slot(int j, int msg) { return (msg < 0 || msg >= k_hop_msgs || j < 0 || (size_t) j * k_hop_msgs >= slots.size()) ? nullptr : &slots[(size_t) j * k_hop_msgs + (size_t) msg]; }
+    bool bind(int j, int msg, void * dst) override {
+        const char * e = getenv("RWKV_MI_HOP");      // RWKV_MI_HOP=mailbox: round 5's two-copy hop (A/B, tests; read per call)
+        const bool mailbox = e && e[0] == 'm';
+        Slot * s = slot(j, msg);
+        if (!s || mailbox || !dst) return false;
+        s->direct = dst;
+        return true;
+    }
     bool send(int j, int msg, const void * src, size_t bytes, hipStream_t st) override {
-        if (msg < 0 || msg >= k_hop_msgs || bytes > cap) return false;
-        Slot & s = slots[(size_t) j * k_hop_msgs + (size_t) msg];
-        if (s.used && hipStreamWaitEvent(st, s.taken, 0) != hipSuccess) return false;   // the previous message has left the mailbox
-        if (hipMemcpyPeerAsync(s.box, dst_dev, src, src_dev, bytes, st) != hipSuccess) return false;
-        s.used = true;
-        return hipEventRecord(s.ready, st) == hipSuccess;
+        Slot * s = slot(j, msg);
+        if (!s || bytes > cap) return false;
+        if (s->direct) {
+            if (s->released && hipStreamWaitEvent(st, s->taken, 0) != hipSuccess) return false;   // the receiver is done with what the buffer held
+            if (hipMemcpyPeerAsync(s->direct, dst_dev, src, src_dev, bytes, st) != hipSuccess) return false;
+            s->used = true;
+            return hipEventRecord(s->ready, st) == hipSuccess;
+        }
+        if (s->used && hipStreamWaitEvent(st, s->taken, 0) != hipSuccess) return false;   // the previous message has left the mailbox
+        if (hipMemcpyPeerAsync(s->box, dst_dev, src, src_dev, bytes, st) != hipSuccess) return false;
+        s->used = true;
+        return hipEventRecord(s->ready, st) == hipSuccess;
     }
     bool recv(int j, int msg, void * dst, size_t bytes, hipStream_t st) override {
-        if (msg < 0 || msg >= k_hop_msgs || bytes > cap) return false;
-        Slot & s = slots[(size_t) j * k_hop_msgs + (size_t) msg];
-        if (!s.used) return false;
-        if (hipStreamWaitEvent(st, s.ready, 0) != hipSuccess) return false;
-        if (hipMemcpyAsync(dst, s.box, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
-        return hipEventRecord(s.taken, st) == hipSuccess;
+        Slot * s = slot(j, msg);
+        if (!s || bytes > cap || !s->used) return false;
+        if (hipStreamWaitEvent(st, s->ready, 0) != hipSuccess) return false;
+        if (s->direct) return dst == s->direct;                                              // (already there)
+        if (hipMemcpyAsync(dst, s->box, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+        return hipEventRecord(s->taken, st) == hipSuccess;
+    }
+    bool release(int j, int msg, hipStream_t st) override {
+        Slot * s = slot(j, msg);
+        if (!s) return false;
+        if (!s->direct) return true;
+        s->released = true;
+        return hipEventRecord(s->taken, st) == hipSuccess;
+    }
+    void * direct_target(int j, int msg) override {
+        const char * e = getenv("RWKV_MI_HOP");      // RWKV_MI_HOP=copy: one peer copy per hop (A/B, tests; read per call)
+        const bool copy_only = e && e[0] == 'c';
+        Slot * s = slot(j, msg);
+        return (s && s->direct && peer_ok && !copy_only) ? s->direct : nullptr;
+    }
+    bool produce_begin(int j, int msg, hipStream_t st) override {
+        Slot * s = slot(j, msg);
+        if (!s || !s->direct) return false;
+        return !s->released || hipStreamWaitEvent(st, s->taken, 0) == hipSuccess;
+    }
+    bool produce_end(int j, int msg, hipStream_t st) override {
+        Slot * s = slot(j, msg);
+        if (!s || !s->direct) return false;
+        s->used = true;
+        return hipEventRecord(s->ready, st) == hipSuccess;
     }
 };
 
@@ -246,6 +315,8 @@ struct StagePart {
     Hop * tok_out = nullptr;           // ... to the first stage (last stage of such a chain)
     uint32_t * d_hist = nullptr;       // (last stage) [n_streams][n_tokens] chosen tokens, device
     size_t n_tokens = 0;
+    std::vector<char> hist_in_launch;  // (last stage) per decode stream: the persistent launch appends the token it picks to d_hist itself
+    std::vector<char> x_direct;        // per decode stream: the stage's launch stores the residual stream in the next stage's buffer itself
 };
 
 // stage `p`, decode stream j, token index t: receive, run the layers, send. Everything is enqueued on the context's stream.
@@ -261,19 +332,74 @@ bool stage_iteration(StagePart & p, rwkv_context * err, size_t t, int j) {
         if (!p.in || !p.in->recv(j, 0, c->b.x, D * sizeof(float), c->stream)) return fail();
         if (m.arch_major == 7 && !p.in->recv(j, 1, c->b.v_first, D * sizeof(float), c->stream)) return fail();
     }
+    const bool xd = !m.has_head && (size_t) j < p.x_direct.size() && p.x_direct[(size_t) j] && c->mega != nullptr;
+    if (xd && !p.out->produce_begin(j, 0, c->stream)) return fail();
     if (!forward_decode(c, m.has_head)) return fail();
     if (m.has_head) {
         // the chosen token: where this context's embedding reads it (a one-stage "chain"), else in the slot the feedback hop sends from
         uint32_t * dst = m.has_embed ? c->d_tokens : c->d_next_token;
         if (folded_argmax_target(c) != dst) launch_argmax(c->d_logits, m.n_vocab(), dst, c->stream);   // (else the persistent launch left it there)
-        if (hipMemcpyAsync(p.d_hist + (size_t) j * p.n_tokens + t, dst, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail();
+        const bool in_launch = (size_t) j < p.hist_in_launch.size() && p.hist_in_launch[(size_t) j] && folded_argmax_target(c) == dst;
+        if (!in_launch && hipMemcpyAsync(p.d_hist + (size_t) j * p.n_tokens + t, dst, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail();
         if (p.tok_out && t + 1 < p.n_tokens && !p.tok_out->send(j, 0, dst, sizeof(uint32_t), c->stream)) return fail();
     } else {
-        if (!p.out || !p.out->send(j, 0, c->b.x, D * sizeof(float), c->stream)) return fail();
+        if (xd) { if (!p.out->produce_end(j, 0, c->stream)) return fail(); }
+        else if (!p.out || !p.out->send(j, 0, c->b.x, D * sizeof(float), c->stream)) return fail();
         if (m.arch_major == 7 && !p.out->send(j, 1, c->b.v_first, D * sizeof(float), c->stream)) return fail();
+    }
+    // what this iteration received (or, for the token word of the first stage, what it was seeded with) may be overwritten from here on
+    if (m.has_embed) {
+        if (p.tok_in && !p.tok_in->release(j, 0, c->stream)) return fail();
+    } else {
+        if (!p.in->release(j, 0, c->stream)) return fail();
+        if (m.arch_major == 7 && !p.in->release(j, 1, c->stream)) return fail();
     }
     return true;
 }
+
+// (last stage) the persistent launches of every decode stream append the tokens they pick to the history themselves: no copy per token.
+// Only when the launch really folds the argmax into the slot the loop reads; undone by hist_off() on every exit (the history is freed).
+void hist_on(StagePart & p) {
+    p.hist_in_launch.assign(p.h.size(), 0);
+    if (!p.d_hist) return;
+    for (size_t j = 0; j < p.h.size(); j++) {
+        rwkv_context * c = p.h[j];
+        if (!c->mega || !c->model->has_head || folded_argmax_target(c) == nullptr) continue;
+        if (hipSetDevice(c->model->device) != hipSuccess) continue;
+        if (mega_v6_set_history(c->mega, p.d_hist + j * p.n_tokens, p.n_tokens, c->stream)) p.hist_in_launch[j] = 1;
+    }
+}
+void hist_off(StagePart & p) {
+    for (size_t j = 0; j < p.hist_in_launch.size(); j++) {
+        rwkv_context * c = p.h[j];
+        if (!p.hist_in_launch[j] || !c->mega) continue;
+        if (hipSetDevice(c->model->device) == hipSuccess) (void) mega_v6_set_history(c->mega, nullptr, 0, c->stream);
+        p.hist_in_launch[j] = 0;
+    }
+}
+struct HistScope { StagePart & p; explicit HistScope(StagePart & q) : p(q) { hist_on(p); } ~HistScope() { hist_off(p); } };
+
+// The stages whose single-token step is one directly issued persistent launch store their output where the next stage reads it (a graph
+// replay would keep the pointer it was captured with: those stages keep the copy). Undone on every exit: the target belongs to this call.
+void x_direct_on(StagePart & p) {
+    p.x_direct.assign(p.h.size(), 0);
+    if (!p.out) return;
+    for (size_t j = 0; j < p.h.size(); j++) {
+        rwkv_context * c = p.h[j];
+        void * tgt = p.out->direct_target((int) j, 0);
+        if (!tgt || !c->mega || c->model->has_head || !(!c->use_graph || single_launch_step(c, false))) continue;
+        if (mega_v6_set_x_out(c->mega, (float *) tgt)) p.x_direct[j] = 1;
+    }
+}
+void x_direct_off(StagePart & p) {
+    for (size_t j = 0; j < p.x_direct.size(); j++) if (p.x_direct[j] && p.h[j]->mega) (void) mega_v6_set_x_out(p.h[j]->mega, nullptr);
+    p.x_direct.clear();
+}
+struct XDirectScope {
+    std::vector<StagePart> & ps;
+    explicit XDirectScope(std::vector<StagePart> & q) : ps(q) { for (StagePart & p : ps) x_direct_on(p); }
+    ~XDirectScope() { for (StagePart & p : ps) x_direct_off(p); }
+};
 
 bool seed_tokens(StagePart & p, rwkv_context * err, const uint32_t * first_tokens) {
     for (size_t j = 0; j < p.h.size(); j++) {
@@ -348,6 +474,16 @@ bool pipeline_decode_greedy(rwkv_context * const * fronts, size_t n_streams, con
     RW_CTX_CHECK(f0, RWKV_ERROR_ALLOC, false, hipSetDevice(hist.dev) == hipSuccess && hipMalloc(&hist.p, n_streams * n_tokens * sizeof(uint32_t)) == hipSuccess, "cannot allocate the token history");
     parts[S - 1].d_hist = (uint32_t *) hist.p;
     if (!seed_tokens(parts[0], f0, first_tokens)) return false;
+    // the hops deliver straight into the buffers the receiving stages read (fixed for the length of this call: T stays 1)
+    for (size_t s = 0; s < S; s++)
+        for (size_t j = 0; j < n_streams; j++) {
+            rwkv_context * c = parts[s].h[j];
+            if (hipSetDevice(c->model->device) != hipSuccess || !ensure_scratch(c, 1)) { f0->last_error |= c->last_error ? c->last_error : (int) RWKV_ERROR_ALLOC; return false; }
+            if (parts[s].in) { (void) parts[s].in->bind((int) j, 0, c->b.x); if (c->model->arch_major == 7) (void) parts[s].in->bind((int) j, 1, c->b.v_first); }
+            if (parts[s].tok_in) (void) parts[s].tok_in->bind((int) j, 0, c->d_tokens);
+        }
+    HistScope hist_scope(parts[S - 1]);
+    XDirectScope x_scope(parts);
     for (size_t s = 0; s < S; s++) for (rwkv_context * c : parts[s].h) { if (hipSetDevice(c->model->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { f0->last_error |= RWKV_ERROR_GRAPH; return false; } }
     const auto t0 = std::chrono::steady_clock::now();
     bool ok = true;
@@ -512,6 +648,7 @@ RWKV_API bool rwkv_mi_stage_run(struct rwkv_context * const * handles, size_t n_
         part.d_hist = (uint32_t *) hist.p;
     }
     if (m.has_embed && !seed_tokens(part, c0, first_tokens)) return false;
+    HistScope hist_scope(part);
     for (rwkv_context * c : part.h) RUN_OK(c0, hipStreamSynchronize(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t t = 0; t < n_tokens && ok; t++)

@@ -219,3 +219,62 @@ def test_rwkv7_greedy_loop_through_a_chain(tmp_path, devices):
     one.free()
     pm.free()
     om.free()
+
+
+@pytest.mark.parametrize("name,fmt,devices,kind", [("mega-v6-2048-v8k", "Q4_0", "0,0,0", 2), ("slice-v7-2560", "Q5_1", "0,0", 3), ("chain-v6-32x256", "Q4_0", "0,0,0,0", 0)])
+def test_hop_arms_of_the_greedy_loop(tmp_path, name, fmt, devices, kind):
+    """The three forms of a hop of the C++ greedy loop (runner.cpp LocalHop) give the same tokens and state as the CPU oracle: the stage's
+    last layer storing the residual stream in the next stage's buffer (default where the stage is one persistent launch: kinds 2 / 3), one
+    peer copy into that buffer (RWKV_MI_HOP=copy; also what stages on the per-layer launches get), and round 5's mailbox with a copy on
+    each side (RWKV_MI_HOP=mailbox) -- single stream and two interleaved streams, tokens appended to the history inside the launch where
+    the last stage folds its argmax."""
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS[name]
+    synth.write_model(p, spec, fmt, seed=61)
+    om = O.OracleModel(p)
+    n = 16
+    refs = []
+    for first in (7, 300):
+        ost, tok, ref = om.init_state(), first, []
+        for _ in range(n):
+            ol, ost = om.eval(tok, ost)
+            tok = int(np.argmax(ol))
+            ref.append(tok)
+        refs.append((ref, ost))
+    os.environ["RWKV_MI_NO_AUTOTUNE"] = "1"
+    try:
+        pm = _pipeline_model(p, devices)
+    finally:
+        del os.environ["RWKV_MI_NO_AUTOTUNE"]
+    if kind:
+        assert pm.persist_kind() == kind
+    clone = pm.clone()
+    try:
+        for arm in (None, "copy", "mailbox"):
+            if arm:
+                os.environ["RWKV_MI_HOP"] = arm
+            try:
+                for _ in range(2):      # (twice: the second call finds the buffers of the first released)
+                    pm.state_load(None)
+                    got, _ = pm.decode_greedy(7, n)
+                    assert list(got) == refs[0][0], arm
+                    assert np.array_equal(pm.state_store(), refs[0][1]), arm
+                for m in (pm, clone):
+                    m.state_load(None)
+                toks, _ = type(pm).decode_greedy_streams([pm, clone], [7, 300], n)
+                for j, m in enumerate((pm, clone)):
+                    assert list(toks[j]) == refs[j][0], (arm, j)
+                    assert np.array_equal(m.state_store(), refs[j][1]), (arm, j)
+            finally:
+                os.environ.pop("RWKV_MI_HOP", None)
+        # the plain ABI on the same chain afterwards: the stages' own residual buffers are in use again (x_out was reset)
+        ost, st = om.init_state(), None
+        for t in TOKENS:
+            ol, ost = om.eval(t % spec.n_vocab, ost)
+            lg, st = pm.eval(t % spec.n_vocab, st)
+            assert np.array_equal(lg, ol) and np.array_equal(st, ost)
+    finally:
+        clone.free()
+        pm.free()
+        om.free()
