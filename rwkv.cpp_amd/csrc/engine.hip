@@ -465,6 +465,16 @@ struct Runner {
             launch_matvec_f(*W, x, K, T, y, N, epi, st);
         }
     }
+    // group norm (+ gate) of the WKV output and the output projection behind it; sequence mode: the norm writes the projection's quantised
+    // input image itself (k_groupnorm_seq_q), the f32 values never leave the chip
+    void gn_out(const LayerW & L, float eps, const float * gate) {
+        TileAct ta[1]; float * keys[1] = {b.out};
+        if (fused_outs(1, keys, L.att_output->type, ta) && !ctx->prof.on &&
+            launch_groupnorm_seq_q(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), eps, gate, T, H, S, ta[0], L.att_output->type, st)) {}
+        else { drop_pre(); launch_groupnorm(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), eps, gate, nullptr, nullptr, nullptr, nullptr, T, H, S, st); }
+        mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
+        drop_pre();
+    }
     // WKV-5/6: long sequences on the lane-pipelined kernel (one wave per value column), otherwise one wave per head
     void wkv6(const float * r, const float * k, const float * v, const float * u, int u_per_chan, const float * w, int w_mode,
               const float * state_in, float * state_out, float * out) {
@@ -493,14 +503,23 @@ struct Runner {
             launch_mix(a, T, D, st);
             if (m.arch_major != 7) { const float * xs[2] = {b.m[0], b.m[1]}; prequant(2, xs, D, L.ffn_key->type); }
         }
-        mm(L.ffn_key, b.m[0], b.ffk, epi(EPI_RELU_SQ));
-        if (m.arch_major == 7) {
-            mm(L.ffn_value, b.ffk, b.x, epi(EPI_ADD_RES, nullptr, b.x));
-        } else {
-            mm(L.ffn_receptance, b.m[1], b.r);
-            drop_pre();
-            mm(L.ffn_value, b.ffk, b.x, epi(EPI_SIGMUL_ADD_RES, nullptr, b.x, b.r));
+        // Sequence mode, exact arm: the key product's only consumer is the value product, so its epilogue writes relu(k)^2 straight as that
+        // product's quantised input image (prefill.hip MmqQOut) -- b.ffk is never written, its quantiser launch is gone. Needs the key
+        // product's own input quantised ahead (its image then is not b.tile, which receives the output).
+        TileAct fk; bool fkq = false;
+        if (T >= k_mfma_min_tokens && b.tile && !ctx->prof.on && dtype_quantized(L.ffn_key->type) && dtype_quantized(L.ffn_value->type)) {
+            if (const TileAct * in = find_pre(b.m[0], L.ffn_key->cols(), L.ffn_key->type)) {
+                fk = tile_act_at(b.tile, T, L.ffn_key->rows());
+                fkq = launch_mmq_mfma_q(*L.ffn_key, *in, T, epi(EPI_RELU_SQ), fk, L.ffn_value->type, st);
+            }
         }
+        if (!fkq) mm(L.ffn_key, b.m[0], b.ffk, epi(EPI_RELU_SQ));
+        if (m.arch_major != 7) mm(L.ffn_receptance, b.m[1], b.r);
+        drop_pre();
+        if (fkq) { pre[0].x = b.ffk; pre[0].wtype = L.ffn_value->type; pre[0].K = L.ffn_value->cols(); pre[0].ta = fk; }
+        if (m.arch_major == 7) mm(L.ffn_value, b.ffk, b.x, epi(EPI_ADD_RES, nullptr, b.x));
+        else mm(L.ffn_value, b.ffk, b.x, epi(EPI_SIGMUL_ADD_RES, nullptr, b.x, b.r));
+        drop_pre();
     }
 
     // rwkv_att_v4 (:163-197)
@@ -533,8 +552,7 @@ struct Runner {
         if (v52) mm(L.att_gate, b.m[3], b.g, epi(EPI_SILU));
         wkv6(b.r, b.k, b.v, v52 ? f(L.att_time_faaaa) : f(L.att_time_first), v52 ? 1 : 0, f(L.att_time_decay), v52 ? 1 : 0,
              sin + 2 * D, sout + 2 * D, b.out);
-        launch_groupnorm(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), 1e-5f, v52 ? b.g : nullptr, nullptr, nullptr, nullptr, nullptr, T, H, S, st);
-        mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
+        gn_out(L, 1e-5f, v52 ? b.g : nullptr);
     }
 
     // rwkv_att_v6 (:294-385)
@@ -542,9 +560,18 @@ struct Runner {
         launch_layernorm(b.x, T, D, f(L.ln1_w), f(L.ln1_b), b.xn, st);
         MixArgs a; a.xn = b.xn; a.carry_in = sin + D; a.carry_out = sout + D; a.mode = 1; a.n_out = 1;
         a.coef[0] = f(L.att_time_maa_x); a.out[0] = b.m[5]; a.sx = b.sx;
-        launch_mix(a, T, D, st);
+        {
+            // sequence mode: the mix's only consumer is the W1 product -- it writes that product's quantised input image (and sx, which the
+            // five mixes read) instead of f32 values for a quantiser launch
+            TileAct ta[1];
+            if (fused_outs(1, a.out, L.att_time_maa_w1->type, ta) && getenv("RWKV_MI_NO_MIX_QUANT") == nullptr) {
+                MixArgs q = a; q.out[0] = nullptr;
+                if (!launch_mix_seq_q(q, T, D, st, ta, L.att_time_maa_w1->type)) { drop_pre(); launch_mix(a, T, D, st); }
+            } else { drop_pre(); launch_mix(a, T, D, st); }
+        }
         const int64_t R5 = L.att_time_maa_w1->ne[1], R = R5 / 5;
         mm(L.att_time_maa_w1, b.m[5], b.lr1, epi(EPI_TANH));
+        drop_pre();
         V6Mix2Args v; v.w2 = f(L.att_time_maa_w2); v.tl = b.lr1; v.sx = b.sx; v.xn = b.xn;
         v.maa[0] = f(L.att_time_maa_w); v.maa[1] = f(L.att_time_maa_k); v.maa[2] = f(L.att_time_maa_v);
         v.maa[3] = f(L.att_time_maa_r); v.maa[4] = f(L.att_time_maa_g);
@@ -576,8 +603,7 @@ struct Runner {
         // decay_w2 consumes [T][DR] rows of lr2
         mm(L.att_time_decay_w2, b.lr2, b.w, epi(EPI_V6_DECAY, f(L.att_time_decay)));
         wkv6(b.r, b.k, b.v, f(L.att_time_faaaa), 1, b.w, 2, sin + 2 * D, sout + 2 * D, b.out);
-        launch_groupnorm(b.out, f(L.att_ln_x_w), f(L.att_ln_x_b), 64e-5f, b.g, nullptr, nullptr, nullptr, nullptr, T, H, S, st);
-        mm(L.att_output, b.out, b.x, epi(EPI_ADD_RES, nullptr, b.x));
+        gn_out(L, 64e-5f, b.g);
     }
 
     // rwkv_att_v7 (:387-482)

@@ -87,9 +87,12 @@ void launch_quantize_act_tiles_batched(int n, const float * const * xs, int64_t 
 // sequence-mode mixes writing their outputs as tile images (prefill.hip); `outs` = one image per output
 bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, hipStream_t st, const TileAct * outs = nullptr, int wtype = 0);
 bool launch_mix_seq_q(const MixArgs & a, int64_t T, int64_t D, hipStream_t st, const TileAct * outs, int wtype);
+bool launch_groupnorm_seq_q(const float * x, const float * lw, const float * lb, float eps, const float * gate, int64_t T, int64_t H, int64_t S,
+                            const TileAct & out, int wtype, hipStream_t st);
 // workspace of the split walk (GEMMs with too few output tiles for the chip): partial sums + one zeroed counter per tile
 struct MmqWs { float * part = nullptr; size_t part_bytes = 0; int * counters = nullptr; int n_counters = 0; };
 bool launch_mmq_mfma(const DevTensor & W, const TileAct & x, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st, const MmqWs * ws = nullptr);
+bool launch_mmq_mfma_q(const DevTensor & W, const TileAct & x, int64_t T, const Epi & epi, const TileAct & out, int out_wtype, hipStream_t st);   // output only as the next product's quantised image
 // up to 4 products of the same shape and type in one launch (y_i = epi_i(W_i . x_i))
 bool launch_mmq_mfma_batched(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy,
                              const MmqWs * ws, hipStream_t st);

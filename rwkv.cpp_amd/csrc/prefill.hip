@@ -126,6 +126,33 @@ static __device__ __forceinline__ void quantize_tile_unit(const float (&v)[16], 
     }
 }
 
+// The same block in ONE thread (the 32 elements v of token i's block in its registers): no lane exchange, no LDS -- for producers whose
+// thread owns a whole block of a token (k_groupnorm_seq_q, k_mix_seq_q). Same statements as above: amax and the code sum are order-free,
+// everything else is per element.
+static __device__ __forceinline__ void quantize_block_thread(const float (&v)[32], int i, int64_t tb, float dscale, float off,
+                                                             int8_t * __restrict__ q, float * __restrict__ d, float * __restrict__ s, float * __restrict__ o) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; j++) amax = fmaxf(amax, fabsf(v[j]));
+    const float dd = amax / 127.0f;
+    const float id = dd != 0.0f ? 1.0f / dd : 0.0f;
+    int sum = 0;
+    int w8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const int qi = (int) roundf(v[4 * j + e] * id); sum += qi; w |= (qi & 0xFF) << (8 * e); }
+        w8[j] = w;
+    }
+    *reinterpret_cast<int4 *>(q + tb * 1024 + i * 16) = make_int4(w8[0], w8[1], w8[2], w8[3]);            // half 0: lane i of the unit
+    *reinterpret_cast<int4 *>(q + tb * 1024 + (32 + i) * 16) = make_int4(w8[4], w8[5], w8[6], w8[7]);     // half 1: lane 32 + i
+    const float d16 = round_f16(dd);
+    d[tb * 32 + i] = d16 * dscale;   // a power of two: exact
+    if (s) s[tb * 32 + i] = round_f16((float) sum * dd);
+    if (o) o[tb * 32 + i] = off * (float) sum;
+}
+
 // The same from an f32 tile of 32 tokens x 256 channels staged in LDS (row stride QT_LD floats: 16-byte reads of 32 different rows
 // spread over all banks): the 256-thread workgroup that produced the tile quantises its 8 blocks, two (token tile, block) units per
 // wave. Used by the producers whose only consumers are quantised products (the sequence-mode mixes): the f32 activations never
@@ -527,6 +554,24 @@ __global__ __launch_bounds__(MF<FMT>::NT, 2) void k_mmq_mfma(MmqArgs A) {
     }
     // ---- epilogue: row n = column of the tile (lane), tokens along the registers ----
     const int64_t n = (int64_t) (rt0 + rg) * 32 + nn;
+    if (A.yq.q != nullptr) {
+        // quantised output (MmqQOut): the wave's tile goes through its own patch of LDS (token-major, 33 floats per token) into the
+        // quantiser's operand order -- lane = half * 32 + token holds the 16 elements of its half of the block -- and leaves as one
+        // unit of the next product's image. Same statements per element as the f32 epilogue followed by k_quant_act_tiles.
+        __syncthreads();                     // every wave is through its last step: the chunk buffers are free
+        float * const patch = reinterpret_cast<float *>(lds) + wave * (32 * 33);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int tl = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int64_t t = (int64_t) (tt0 + tg) * 32 + tl;
+            patch[tl * 33 + nn] = (t < T && n < N) ? apply_epi(epi, V[r >> 1][r & 1], t, n, ldy) : 0.0f;
+        }
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = patch[nn * 33 + h * 16 + j];
+        if (rt0 + rg < RT) quantize_tile_unit(v, lane, (int64_t) (tt0 + tg) * A.yq.nb + (rt0 + rg), A.yq.dscale, A.yq.off, A.yq.q, A.yq.d, A.yq.s, A.yq.o);
+        return;
+    }
     if (n < N) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -776,42 +821,120 @@ __global__ __launch_bounds__(256) void k_v6_mix2_seq(V6Mix2Args a, TileOut qo, i
     }
 }
 
-// Token-shift mixes of a sequence (k_mix) with quantised outputs: thread = channel d keeps the 32 tokens of its tile (and the one in
-// front) in registers; per output the tile goes through LDS into the quantiser. Same statements as k_mix (rwkv_graph.inc:204-215).
+// Token-shift mixes of a sequence (k_mix) with quantised outputs. One THREAD per (token, block of 32 channels): the block of the token and of
+// the token in front sit in its registers, every output is mixed and quantised in place (quantize_block_thread) -- no LDS, no barrier.
+// Same statements as k_mix (rwkv_graph.inc:204-215). Workgroup = 32 tokens x 8 blocks (the 256 channels of blockIdx.x).
+// (Until round 6: thread = channel with the tile's 32 tokens in registers, each output staged through LDS into the wave-wide quantiser,
+//  two barriers per output: 11.7 us per launch, the latency of one workgroup's chain.)
 __global__ __launch_bounds__(256) void k_mix_seq_q(MixArgs a, TileOut qo, int T, int D) {
-    constexpr int TT = 32;
-    __shared__ __attribute__((aligned(16))) float l_out[TT * QT_LD];
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    const int t0 = blockIdx.y * TT;
-    float xs[TT + 1];
-    xs[0] = t0 == 0 ? a.carry_in[d] : (t0 - 1 < T ? a.xn[(int64_t) (t0 - 1) * D + d] : 0.0f);
+    const int i = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const int b = blockIdx.x * 8 + bl;                    // block of 32 channels
+    const int64_t tt = blockIdx.y, t = tt * 32 + i;
+    const bool live = t < T;
+    const int d0 = b * 32;
+    float x[32], xp[32];
+    {
+        const float4 * xr = reinterpret_cast<const float4 *>(a.xn + (live ? t : 0) * D + d0);
+        const float4 * pr = (live && t > 0) ? reinterpret_cast<const float4 *>(a.xn + (t - 1) * D + d0) : reinterpret_cast<const float4 *>(a.carry_in + d0);
 #pragma unroll
-    for (int tt = 0; tt < TT; tt++) xs[tt + 1] = t0 + tt < T ? a.xn[(int64_t) (t0 + tt) * D + d] : 0.0f;
-    if (a.mode != 0 && a.sx) {
-#pragma unroll
-        for (int tt = 0; tt < TT; tt++) if (t0 + tt < T) a.sx[(int64_t) (t0 + tt) * D + d] = xs[tt] - xs[tt + 1];
+        for (int j = 0; j < 8; j++) {
+            const float4 f = xr[j], g = pr[j];
+            x[4 * j] = f.x; x[4 * j + 1] = f.y; x[4 * j + 2] = f.z; x[4 * j + 3] = f.w;
+            xp[4 * j] = g.x; xp[4 * j + 1] = g.y; xp[4 * j + 2] = g.z; xp[4 * j + 3] = g.w;
+        }
     }
-    if (T - 1 >= t0 && T - 1 < t0 + TT) {
+    if (live && a.mode != 0 && a.sx) {
+        float4 * sr = reinterpret_cast<float4 *>(a.sx + t * D + d0);
 #pragma unroll
-        for (int tt = 0; tt < TT; tt++) if (t0 + tt == T - 1) a.carry_out[d] = xs[tt + 1];
+        for (int j = 0; j < 8; j++) sr[j] = make_float4(xp[4 * j] - x[4 * j], xp[4 * j + 1] - x[4 * j + 1], xp[4 * j + 2] - x[4 * j + 2], xp[4 * j + 3] - x[4 * j + 3]);
+    }
+    if (live && t == T - 1) {
+        float4 * cr = reinterpret_cast<float4 *>(a.carry_out + d0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) cr[j] = make_float4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
     }
     for (int f = 0; f < a.n_out; f++) {
-        const float c = a.coef[f][d];
+        const float4 * cr = reinterpret_cast<const float4 *>(a.coef[f] + d0);
         float * const of = a.out[f];
-        if (f) __syncthreads();                  // the quantiser is done with the previous output's tile
+        float val[32];
 #pragma unroll
-        for (int tt = 0; tt < TT; tt++) {
-            float val = 0.0f;
-            if (t0 + tt < T) {
-                const float x = xs[tt + 1], xp = xs[tt];
-                if (a.mode == 0) { const float xc = x * c, pc = xp * c; val = xc + (xp - pc); }
-                else { const float sx = xp - x; const float sc = sx * c; val = sc + x; }
-                if (of) of[(int64_t) (t0 + tt) * D + d] = val;
+        for (int j = 0; j < 8; j++) {
+            const float4 c4 = cr[j];
+            const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float xv = x[4 * j + e], pv = xp[4 * j + e], c = cv[e];
+                float v;
+                if (a.mode == 0) { const float xc = xv * c, pc = pv * c; v = xc + (pv - pc); }
+                else { const float sx = pv - xv; const float sc = sx * c; v = sc + xv; }
+                val[4 * j + e] = live ? v : 0.0f;        // (tokens beyond T: zeros in the quantised image)
             }
-            l_out[tt * QT_LD + threadIdx.x] = val;
         }
-        __syncthreads();
-        quantize_lds_tile(l_out, threadIdx.x, blockIdx.y, blockIdx.x * 8, qo.nb, qo.dscale, qo.off, qo.q[f], qo.d[f], qo.s[f], qo.o[f]);
+        if (of && live) {
+            float4 * orow = reinterpret_cast<float4 *>(of + t * D + d0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) orow[j] = make_float4(val[4 * j], val[4 * j + 1], val[4 * j + 2], val[4 * j + 3]);
+        }
+        quantize_block_thread(val, i, tt * qo.nb + b, qo.dscale, qo.off, qo.q[f], qo.d[f], qo.s[f], qo.o[f]);
+    }
+}
+
+// Group norm of the WKV output (+ gate) of a sequence with a quantised output (rwkv_graph.inc:279-283, 372-377; head size 64). One THREAD
+// per (token, head): the 64 values sit in its registers, the two double sums walk the halving tree of the numerics spec by themselves
+// (level o adds element l + o onto element l for l < o, o = 32 .. 1: the additions wave_sum_d makes across lanes, so the same bits as
+// k_groupnorm), and the head's two blocks are quantised in place (quantize_block_thread). No lane exchange, no LDS, no barrier; the
+// normalised f32 values never go to HBM. A wave = 32 tokens x 2 heads: its stores are contiguous 512-byte runs of the image.
+// (The first version of this round kept k_groupnorm's wave-per-(token, head) reductions, 32 tokens in a row per wave, and staged the tile
+//  through LDS: 14.7 us per launch against 13.7 + 6.3 for k_groupnorm + the quantiser -- the reductions' latency chain, not bytes.)
+__global__ __launch_bounds__(64) void k_groupnorm_seq_q(const float * __restrict__ x, const float * __restrict__ lw, const float * __restrict__ lb, float eps,
+                                                        const float * __restrict__ gate, TileOut qo, int T, int D) {
+    const int i = threadIdx.x & 31;
+    const int h = blockIdx.x * 2 + (threadIdx.x >> 5);
+    const int64_t tt = blockIdx.y, t = tt * 32 + i;
+    const bool live = t < T;
+    float xv[64];
+    const float4 * xr = reinterpret_cast<const float4 *>(x + (live ? t : 0) * D + h * 64);
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const float4 f = xr[j]; xv[4 * j] = f.x; xv[4 * j + 1] = f.y; xv[4 * j + 2] = f.z; xv[4 * j + 3] = f.w; }
+    double acc[32];
+#pragma unroll
+    for (int l = 0; l < 32; l++) acc[l] = (double) xv[l] + (double) xv[l + 32];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+        for (int l = 0; l < o; l++) acc[l] = acc[l] + acc[l + o];
+    }
+    const float mean = (float) (acc[0] / 64.0);
+#pragma unroll
+    for (int l = 0; l < 32; l++) { const float a = xv[l] - mean, c = xv[l + 32] - mean; acc[l] = (double) (a * a) + (double) (c * c); }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+        for (int l = 0; l < o; l++) acc[l] = acc[l] + acc[l + o];
+    }
+    const float var = (float) (acc[0] / 64.0);
+    const float scale = 1.0f / sqrtf(var + eps);
+    const float4 * wr = reinterpret_cast<const float4 *>(lw + h * 64), * br = reinterpret_cast<const float4 *>(lb + h * 64);
+    const float4 * gr = gate ? reinterpret_cast<const float4 *>(gate + (live ? t : 0) * D + h * 64) : nullptr;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        float y[32];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float4 w4 = wr[half * 8 + j], b4 = br[half * 8 + j];
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+            float gv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (gr) { const float4 g4 = gr[half * 8 + j]; gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w; }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v = (xv[half * 32 + 4 * j + e] - mean) * scale;
+                v = v * wv[e];
+                v = v + bv[e];
+                if (gr) v *= gv[e];
+                y[4 * j + e] = live ? v : 0.0f;                // (tokens beyond T: zeros in the quantised image)
+            }
+        }
+        quantize_block_thread(y, i, tt * qo.nb + 2 * h + half, qo.dscale, qo.off, qo.q[0], qo.d[0], qo.s[0], qo.o[0]);
     }
 }
 
@@ -836,6 +959,17 @@ bool launch_v6_mix2_seq(const V6Mix2Args & a, int64_t T, int64_t D, int64_t R, h
     const dim3 grid((unsigned) (5 * D / 256), (unsigned) ((rows + TT - 1) / TT));
     if (R == 32) hipLaunchKernelGGL((k_v6_mix2_seq<32, TT>), grid, dim3(256), 0, st, a, qo, (int) T, (int) D);
     else hipLaunchKernelGGL((k_v6_mix2_seq<64, TT>), grid, dim3(256), 0, st, a, qo, (int) T, (int) D);
+    return true;
+}
+
+// group norm (+ gate) with the result only as the quantised image `out` (head size 64, D % 256 == 0; no RWKV-7 bonus term)
+bool launch_groupnorm_seq_q(const float * x, const float * lw, const float * lb, float eps, const float * gate, int64_t T, int64_t H, int64_t S,
+                            const TileAct & out, int wtype, hipStream_t st) {
+    const int64_t D = H * S;
+    if (S != 64 || D % 256 != 0 || H % 2 != 0 || getenv("RWKV_MI_NO_GN_QUANT") != nullptr) return false;
+    const TileOut qo = tile_out_of(1, &out, wtype, D);
+    const dim3 grid((unsigned) (H / 2), (unsigned) (out.T_pad / 32));
+    hipLaunchKernelGGL(k_groupnorm_seq_q, grid, dim3(64), 0, st, x, lw, lb, eps, gate, qo, (int) T, (int) D);
     return true;
 }
 
@@ -1190,7 +1324,7 @@ void launch_quantize_act_tiles(const float * x, int64_t T, int64_t K, int wtype,
 
 template <int FMT>
 static bool launch_mmq_mfma_t(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy,
-                              const MmqWs * ws, hipStream_t st) {
+                              const MmqWs * ws, hipStream_t st, const MmqQOut * yq = nullptr) {
     typedef MF<FMT> M;
     const DevTensor & W0 = *Ws[0];
     const int64_t N = W0.rows();
@@ -1217,6 +1351,8 @@ static bool launch_mmq_mfma_t(int n, const DevTensor * const * Ws, const TileAct
     A.N = N; A.T = T; A.ldy = ldy; A.nb = nb; A.RT = RT; A.C = C; A.split = split;
     A.order = wt->order; for (int a = 0; a < 9; a++) A.a_start[a] = wt->a_start[a];
     A.part = ws ? ws->part : nullptr; A.counters = ws ? ws->counters : nullptr;
+    if (yq) { if (split != 1 || n != 1 || N % 32 != 0) return false; A.yq = *yq; }
+    static_assert(8 * 32 * 33 * 4 <= M::LDS_BYTES, "the quantising epilogue's patches");
     const size_t lds = (size_t) M::LDS_BYTES;
     prefill_prepare_current_device();   // (dynamic-LDS limit: per device, set once per device)
     const dim3 grid((unsigned) (RP < 8 ? RP * C : ((RP + 7) / 8) * 8 * C), (unsigned) n, (unsigned) split);
@@ -1263,6 +1399,27 @@ bool launch_mmq_mfma_batched(int n, const DevTensor * const * Ws, const TileAct 
         case T_Q5_0: return launch_mmq_mfma_t<T_Q5_0>(n, Ws, xs, ys, epis, T, ldy, ws, st);
         case T_Q5_1: return launch_mmq_mfma_t<T_Q5_1>(n, Ws, xs, ys, epis, T, ldy, ws, st);
         case T_Q8_0: return launch_mmq_mfma_t<T_Q8_0>(n, Ws, xs, ys, epis, T, ldy, ws, st);
+        default: return false;
+    }
+}
+
+// y = epi(W . x) written ONLY as the quantised tile image `out` of a following product with weights of type out_wtype (exact arm; false:
+// not applicable -- the caller runs the plain product and quantises its output as before). Nothing reads partial sums: split walks excluded.
+bool launch_mmq_mfma_q(const DevTensor & W, const TileAct & x, int64_t T, const Epi & epi, const TileAct & out, int out_wtype, hipStream_t st) {
+    const bool off = getenv("RWKV_MI_NO_EPI_QUANT") != nullptr;      // (A/B, tests: read per call)
+    if (off || seq_q_arm() != 0 || !dtype_quantized(out_wtype) || W.rows() % 32 != 0 || out.T_pad < (T + 63) / 64 * 64) return false;
+    MmqQOut yq;
+    const bool hm = out_wtype == T_Q4_1 || out_wtype == T_Q5_1, xo = out_wtype == T_Q5_0;
+    yq.q = out.q; yq.d = out.d; yq.s = hm ? out.s : nullptr; yq.o = xo ? out.o : nullptr;
+    yq.dscale = out_wtype == T_Q4_0 ? 0.0625f : 1.0f; yq.off = 16.0f; yq.nb = (int) (W.rows() / 32);
+    const DevTensor * Wp = &W;
+    float * y = nullptr;
+    switch (W.type) {
+        case T_Q4_0: return launch_mmq_mfma_t<T_Q4_0>(1, &Wp, &x, &y, &epi, T, W.rows(), nullptr, st, &yq);
+        case T_Q4_1: return launch_mmq_mfma_t<T_Q4_1>(1, &Wp, &x, &y, &epi, T, W.rows(), nullptr, st, &yq);
+        case T_Q5_0: return launch_mmq_mfma_t<T_Q5_0>(1, &Wp, &x, &y, &epi, T, W.rows(), nullptr, st, &yq);
+        case T_Q5_1: return launch_mmq_mfma_t<T_Q5_1>(1, &Wp, &x, &y, &epi, T, W.rows(), nullptr, st, &yq);
+        case T_Q8_0: return launch_mmq_mfma_t<T_Q8_0>(1, &Wp, &x, &y, &epi, T, W.rows(), nullptr, st, &yq);
         default: return false;
     }
 }

@@ -298,7 +298,7 @@ std::atomic<unsigned long long> g_mmq_fast_launches{0};   // launches of k_mmq_f
 // it). Read per call: the test suite runs the arms in one process. The default is the arm that keeps rwkv_eval_sequence bit-identical to
 // repeated rwkv_eval whatever the chunking (ggml's mul_mat runs the same vec_dot per column for every T, so the reference has that property
 // for quantised files too); the plain-order kernel is an opt-in for callers that take its stated tolerance for +15 % prefill throughput.
-static int seq_q_arm() {
+int seq_q_arm() {
     const char * e = getenv("RWKV_MI_SEQ_Q");
     if (e && e[0] == 'f' && e[1] == 'a') return 1;
     if (e && e[0] == 'f' && e[1] == 'o') return 2;

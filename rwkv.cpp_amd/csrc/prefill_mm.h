@@ -81,6 +81,10 @@ struct PfX { const int8_t * q; const float * d; const float * s; const float * o
 // walk are the 8 subtrees below level 3 of the reduction tree, so part z walks a in [8 z / split, 8 (z + 1) / split) and ends with
 // the sum of its subtree; the workgroup that arrives last on the tile's counter adds the parts in tree order -- the same additions.
 constexpr int MMQ_BATCH = 4;
+// Round 6: the output of product 0 as the tile-major quantised image of the NEXT product's input (q != nullptr; split == 1, N % 32 == 0):
+// a wave's 32 rows x 32 tokens are exactly one (token tile, block) unit of that image, so the epilogue quantises them in place of storing
+// f32 -- the 4 F bytes per token of the channel mixing's key vector no longer travel to HBM and back, and its quantiser launch is gone.
+struct MmqQOut { int8_t * q = nullptr; float * d = nullptr; float * s = nullptr; float * o = nullptr; float dscale = 1.0f, off = 16.0f; int nb = 0; };
 struct MmqArgs {
     PfW w[MMQ_BATCH]; PfX x[MMQ_BATCH]; float * y[MMQ_BATCH]; Epi epi[MMQ_BATCH];
     int64_t N, T, ldy;
@@ -89,6 +93,7 @@ struct MmqArgs {
     int a_start[9];          // steps of the walk before outer iteration a = 0 .. 8
     float * part;            // [split][tile][thread][16] partial sums (split > 1)
     int * counters;          // (not read: the parts are added by k_mmq_combine; reserved for a last-arriver variant in one kernel)
+    MmqQOut yq;              // see MmqQOut
 };
 
 
@@ -96,6 +101,7 @@ struct MmqArgs {
 // or format stays on the exact kernel
 bool launch_mmq_fast(int n, const DevTensor * const * Ws, const TileAct * xs, float * const * ys, const Epi * epis, int64_t T, int64_t ldy, hipStream_t st);
 void mmq_fast_prepare_current_device();
+int  seq_q_arm();          // RWKV_MI_SEQ_Q: 0 exact (default), 1 fast, 2 force
 extern std::atomic<unsigned long long> g_mmq_fast_launches;
 
 }  // namespace rwkvmi
