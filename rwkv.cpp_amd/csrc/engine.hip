@@ -495,8 +495,8 @@ struct Runner {
         else { a.mode = 1; a.n_out = 1; a.coef[0] = f(L.ffn_x_k); }
         a.out[0] = b.m[0]; a.out[1] = b.m[1];
         TileAct tas[5];
-        if (m.arch_major != 7 && L.ffn_receptance->type == L.ffn_key->type && L.ffn_key->cols() == D && fused_outs(2, a.out, L.ffn_key->type, tas)) {
-            // sequence mode: the mix writes its two outputs as quantised tile images (their only consumers are the two products below)
+        if ((m.arch_major == 7 || L.ffn_receptance->type == L.ffn_key->type) && L.ffn_key->cols() == D && fused_outs(a.n_out, a.out, L.ffn_key->type, tas)) {
+            // sequence mode: the mix writes its outputs (RWKV-7: its one output) as quantised tile images (their only consumers are the products below)
             a.out[0] = nullptr; a.out[1] = nullptr;
             launch_mix_seq_q(a, T, D, st, tas, L.ffn_key->type);
         } else {
@@ -508,7 +508,9 @@ struct Runner {
         // product's own input quantised ahead (its image then is not b.tile, which receives the output).
         TileAct fk; bool fkq = false;
         if (T >= k_mfma_min_tokens && b.tile && !ctx->prof.on && dtype_quantized(L.ffn_key->type) && dtype_quantized(L.ffn_value->type)) {
-            if (const TileAct * in = find_pre(b.m[0], L.ffn_key->cols(), L.ffn_key->type)) {
+            // (the receptance product runs between the two: its input must be quantised ahead as well, or it would be quantised into b.tile)
+            const bool rec_ok = m.arch_major == 7 || find_pre(b.m[1], L.ffn_receptance->cols(), L.ffn_receptance->type) != nullptr;
+            if (const TileAct * in = rec_ok ? find_pre(b.m[0], L.ffn_key->cols(), L.ffn_key->type) : nullptr) {
                 fk = tile_act_at(b.tile, T, L.ffn_key->rows());
                 fkq = launch_mmq_mfma_q(*L.ffn_key, *in, T, epi(EPI_RELU_SQ), fk, L.ffn_value->type, st);
             }
