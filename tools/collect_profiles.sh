@@ -14,5 +14,5 @@ w.writeheader()
 for r in rows: w.writerow({k: (r[k][:60] if k == "Kernel_Name" else r[k]) for k in w.fieldnames})
 PY
 done
-for f in ring_phase_trace_7b.txt ring_head_trace_7b.txt pytest.txt head.txt; do [ -s $O/$f ] && cp $O/$f $P/${T}_$f; done
+for f in ring_phase_trace_7b.txt ring_head_trace_7b.txt pytest.txt head.txt hop_ab.txt prefill_fuse_ab.txt; do [ -s $O/$f ] && cp $O/$f $P/${T}_$f; done
 ls -la $P | grep "${T}_" | awk '{print $5, $9}'

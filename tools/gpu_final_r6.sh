@@ -34,3 +34,6 @@ timeout 300 python tools/abi_pinned.py > $O/abi_pinned.txt 2>&1
 bash tools/gpu_pmc_mfma.sh $T > $O/pmc_mfma.log 2>&1
 STAMP=$(python -c "import bench; print(bench.prefill_source_stamp())")
 python tools/pmc_mfma_summary.py $O rwkv6-1b6:Q4_0:prefill $STAMP $O/pmc_mfma.json k_mmq_mfma > $O/pmc_mfma_summary.txt 2>&1; cat $O/pmc_mfma_summary.txt
+# the one-process chain's hop on this box: 1 / 2 / 4 / 8 stages of the 1.6B and the 7B on device 0, three forms of the hop (tools/gpu_hop_ab.sh)
+RWKV_HOP_SKIP_TESTS=1 bash tools/gpu_hop_ab.sh $T/hop > $O/hop.log 2>&1; cp $O/hop/hop_ab.txt $O/hop_ab.txt 2>/dev/null; cat $O/hop_ab.txt
+bash tools/gpu_prefill_fuse_ab.sh $T/fuse > $O/fuse.log 2>&1; tail -7 $O/fuse.log > $O/prefill_fuse_ab.txt; cat $O/prefill_fuse_ab.txt

@@ -2,7 +2,7 @@
 # Round 6: sequence mode with the quantiser folded into its producers (key-product epilogue, group norm, first RWKV-6 mix), A/B on one box.
 cd "$(dirname "$0")/.."; T=${1:-r06p}; O=gpurun_out/$T; mkdir -p $O
 export TMPDIR=/tmp RWKV_BENCH_DIR=/tmp
-( timeout 1200 python -m pytest tests/test_gpu_prefill.py tests/test_gpu_real_geometry.py tests/test_gpu_tiny_rwkv.py tests/test_gpu_synthetic.py tests/test_gpu_reference_programs.py tests/test_gpu_prefill_fast.py -x -q -m gpu -p no:cacheprovider 2>&1 | tail -8 ) | tee $O/pytest_seq.txt
+[ -n "${RWKV_HOP_SKIP_TESTS:-}" ] || ( timeout 1200 python -m pytest tests/test_gpu_prefill.py tests/test_gpu_real_geometry.py tests/test_gpu_tiny_rwkv.py tests/test_gpu_synthetic.py tests/test_gpu_reference_programs.py tests/test_gpu_prefill_fast.py -x -q -m gpu -p no:cacheprovider 2>&1 | tail -8 ) | tee $O/pytest_seq.txt
 B="timeout 500 python bench.py --mode prefill --config rwkv6-1b6 --dtype Q4_0 --steps 6 --warmup 2"
 line() { python - "$1" <<'PY'
 import json,sys
