@@ -22,6 +22,8 @@ RWKV_API bool rwkv_mi_test_force_abort(struct rwkv_context * ctx);
 
 /* Test hook (used by tests/ only): how often the F16 matrix-core sequence kernel has been launched by this process. */
 RWKV_API uint64_t rwkv_mi_test_mmf16_launches(void);
+/* Test hook (used by tests/ only): launches of the EXACT F16 / F32 sequence kernel on the matrix cores (k_mmfx_seq, kernels.hip) so far. */
+RWKV_API uint64_t rwkv_mi_test_mmfx_launches(void);
 
 /* Test hook (used by tests/ only): how often the plain-order quantised sequence GEMM has been launched by this process. */
 RWKV_API uint64_t rwkv_mi_test_mmq_fast_launches(void);

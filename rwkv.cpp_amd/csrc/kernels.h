@@ -42,6 +42,7 @@ void launch_matvec_q(const DevTensor & W, const QAct & x, int64_t T, float * y, 
 // Same for F32 / F16 weights with f32 activations x[t*ldx + k] (F16 weights: activations rounded to fp16 on load).
 void launch_matvec_f(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st);
 
+extern std::atomic<unsigned long long> g_mmfx_launches;    // launches of the exact F16 / F32 matrix-core sequence kernel (k_mmfx_seq) so far (test hook reads it)
 extern std::atomic<unsigned long long> g_mmf16_launches;   // launches of the F16 matrix-core sequence kernel so far (test hook reads it)
 void matvec_f_release_stream(hipStream_t st);   // frees the split-K workspace kept for this stream (a context's own stream, at its destruction)
 

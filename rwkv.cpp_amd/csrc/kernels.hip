@@ -405,6 +405,176 @@ __global__ __launch_bounds__(256) void k_mmf16_combine(MfArgs p) {
     if (n < p.N && t < p.T) p.y[t * p.ldy + n] = apply_epi(p.epi, sum, t, n, p.ldy);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sequence mode, F16 / F32 weights, EXACT: y[T][N] = epi(W[N][K] . x[T][K]) on the matrix cores in ggml's own addition order (round 6).
+//
+// ggml's vec_dot (and k_mvf above, and the oracle) keeps 32 partial sums, partial p = the chain fma(w[k], x[k], .) over k = p, p + 32,
+// p + 64, ... and folds them at the end. v_mfma_f32_16x16x4_f32 adds its four k slices onto the accumulator as a chain of single fused
+// multiply-adds in k order (tools/mfma_f32_chain.hip: bit for bit against fmaf on 1 M random outputs) -- so ONE instruction with the k
+// slices p, p + 32, p + 64, p + 96 of a 128-element step is four links of partial p's chain for a 16-token x 16-row tile, and 32 such
+// instructions (32 accumulators of 4 registers) are the whole step. Lane l = (k slice l / 16, token or row l % 16) reads the 32 consecutive
+// elements of its slice of its token (128 bytes, rounded to fp16 for F16 weights as ggml does) and of its weight row (64 / 128 bytes):
+// no LDS, no barrier; the two token groups and two row groups of a workgroup share their lines in the CU's L1. The fold of the 32
+// partials (16, 8, 4, then (p0 + p1) + (p2 + p3)) is k_mvf's, inside the lane. Bit-identical to k_mvf, hence to the serial path and the
+// oracle (tests/test_gpu_seq_f16.py); RWKV_MI_SEQ_F=valu keeps sequence passes on k_mvf's token tiles (A/B, tests).
+// What it is for: FP16 / FP32 files (every matrix) and the low-rank stages of RWKV-7 in a quantised file -- until now 48.8 us per launch on
+// the VALU token tiles, 12 ms of a 52.7 ms pass of the 2.9B.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float mf_f4 __attribute__((ext_vector_type(4)));
+std::atomic<unsigned long long> g_mmfx_launches{0};
+
+// Workgroup = 4 waves = 2 token groups x 2 row groups; a wave owns 16 tokens x 16 RW rows (RW = 1, 2 MFMA tiles sharing the token operand),
+// the workgroup 32 tokens x 32 RW rows. K walks in steps of 128 through two LDS buffers: global loads are row-contiguous (512 bytes of f32
+// per token and step, rounded to fp16 VALUES on the way in for F16 weights; 256 / 512 bytes per weight row), the operands come out of LDS as
+// 16-byte reads on a pitch of 132 floats / 136 halfs (the 16 rows of a lane group start 4 banks apart: conflict-free).
+// (The first version of this kernel read its operands straight from global memory, 128 bytes per lane: 64 different cache lines per load
+//  instruction -- 98.6 ms per pass of an FP16 1.6B file against 67.5 on k_mvf's token tiles.)
+constexpr int FX_KC = 128, FX_PX = 132, FX_PW16 = 136, FX_PW32 = 132;
+template <bool F16, int RW> struct FxLds {
+    static constexpr int X_FLOATS = 32 * FX_PX;
+    static constexpr int W_BYTES = F16 ? 32 * RW * FX_PW16 * 2 : 32 * RW * FX_PW32 * 4;
+    static constexpr int BUF = X_FLOATS * 4 + W_BYTES;
+    static constexpr int BYTES = 2 * BUF;
+};
+
+template <bool F16, int RW>
+__global__ __launch_bounds__(256) void k_mmfx_seq(const void * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x, int64_t ldx,
+                                                  int64_t T, float * __restrict__ y, int64_t ldy, Epi epi) {
+    typedef FxLds<F16, RW> L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fx_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4, tw = wave & 1, nw = wave >> 1;
+    const int64_t n0 = (int64_t) blockIdx.x * 32 * RW, t0 = (int64_t) blockIdx.y * 32;
+    auto lx = [&](int buf) { return reinterpret_cast<float *>(fx_lds + buf * L::BUF); };
+    auto lw = [&](int buf) { return fx_lds + buf * L::BUF + L::X_FLOATS * 4; };
+    // staging roles. Activations: 4 float4 per thread (token tid / 32 + 8 i, floats 4 (tid % 32) ..). Weights, F16: 2 RW int4 (row tid / 16 + 16 i,
+    // halfs 8 (tid % 16) ..); F32: 4 RW float4 (row tid / 32 + 8 i, floats 4 (tid % 32) ..)
+    float4 xv[4]; int4 wv[4 * RW];
+    auto fetch = [&](int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int64_t t = t0 + (tid >> 5) + 8 * i, k = k0 + 4 * (tid & 31);
+            xv[i] = (t < T && k < K) ? *reinterpret_cast<const float4 *>(x + t * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);   // (K % 32 == 0: absent slices are zeros, fma(0, 0, a) = a)
+        }
+        if constexpr (F16) {
+#pragma unroll
+            for (int i = 0; i < 2 * RW; i++) {
+                const int64_t n = n0 + (tid >> 4) + 16 * i, k = k0 + 8 * (tid & 15);
+                wv[i] = (n < N && k < K) ? *reinterpret_cast<const int4 *>(reinterpret_cast<const uint16_t *>(W) + n * K + k) : make_int4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4 * RW; i++) {
+                const int64_t n = n0 + (tid >> 5) + 8 * i, k = k0 + 4 * (tid & 31);
+                wv[i] = (n < N && k < K) ? *reinterpret_cast<const int4 *>(reinterpret_cast<const float *>(W) + n * K + k) : make_int4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+        float * const bx = lx(buf);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float4 v = xv[i];
+            if constexpr (F16) { v.x = round_f16(v.x); v.y = round_f16(v.y); v.z = round_f16(v.z); v.w = round_f16(v.w); }     // what ggml feeds an F16 matrix
+            *reinterpret_cast<float4 *>(bx + ((tid >> 5) + 8 * i) * FX_PX + 4 * (tid & 31)) = v;
+        }
+        if constexpr (F16) {
+            uint16_t * const bw = reinterpret_cast<uint16_t *>(lw(buf));
+#pragma unroll
+            for (int i = 0; i < 2 * RW; i++) *reinterpret_cast<int4 *>(bw + ((tid >> 4) + 16 * i) * FX_PW16 + 8 * (tid & 15)) = wv[i];
+        } else {
+            float * const bw = reinterpret_cast<float *>(lw(buf));
+#pragma unroll
+            for (int i = 0; i < 4 * RW; i++) *reinterpret_cast<int4 *>(bw + ((tid >> 5) + 8 * i) * FX_PW32 + 4 * (tid & 31)) = wv[i];
+        }
+    };
+    mf_f4 acc[RW][32];
+#pragma unroll
+    for (int r = 0; r < RW; r++)
+#pragma unroll
+        for (int p = 0; p < 32; p++) acc[r][p] = (mf_f4){0.0f, 0.0f, 0.0f, 0.0f};
+    fetch(0); stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t k0 = 0; k0 < K; k0 += FX_KC, buf ^= 1) {
+        const bool more = k0 + FX_KC < K;
+        if (more) fetch(k0 + FX_KC);                                  // the next step's lines are in flight under this step's instructions
+        float xa[32];
+        {
+            const float4 * src = reinterpret_cast<const float4 *>(lx(buf) + (16 * tw + j) * FX_PX + 32 * kq);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const float4 v = src[i]; xa[4 * i] = v.x; xa[4 * i + 1] = v.y; xa[4 * i + 2] = v.z; xa[4 * i + 3] = v.w; }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; r++) {
+            float wb[32];
+            const int row = 16 * (RW * nw + r) + j;
+            if constexpr (F16) {
+                const int4 * src = reinterpret_cast<const int4 *>(reinterpret_cast<const uint16_t *>(lw(buf)) + row * FX_PW16 + 32 * kq);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int4 raw = src[i];
+                    const unsigned u[4] = {(unsigned) raw.x, (unsigned) raw.y, (unsigned) raw.z, (unsigned) raw.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { wb[8 * i + 2 * e] = h2f_bits((uint16_t) (u[e] & 0xFFFFu)); wb[8 * i + 2 * e + 1] = h2f_bits((uint16_t) (u[e] >> 16)); }
+                }
+            } else {
+                const float4 * src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(lw(buf)) + row * FX_PW32 + 32 * kq);
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const float4 v = src[i]; wb[4 * i] = v.x; wb[4 * i + 1] = v.y; wb[4 * i + 2] = v.z; wb[4 * i + 3] = v.w; }
+            }
+            // D[token][row] += A[token][k] B[k][row]: A = the activations (lane: token l % 16, slice l / 16), B = the weights (row l % 16, slice l / 16);
+            // instruction p adds the links k = k0 + p, + 32, + 64, + 96 to partial p's chain
+#pragma unroll
+            for (int p = 0; p < 32; p++) acc[r][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[p], wb[p], acc[r][p], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // C / D layout: column (= weight row) lane % 16, row (= token) 4 (lane / 16) + register. The fold of k_mvf: ps[i] += ps[i + 16], += ps[i + 8],
+    // += ps[i + 4], (ps0 + ps1) + (ps2 + ps3).
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+#pragma unroll
+        for (int p = 0; p < 16; p++) acc[r][p] = acc[r][p] + acc[r][p + 16];
+#pragma unroll
+        for (int p = 0; p < 8; p++) acc[r][p] = acc[r][p] + acc[r][p + 8];
+#pragma unroll
+        for (int p = 0; p < 4; p++) acc[r][p] = acc[r][p] + acc[r][p + 4];
+        const mf_f4 res = (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
+        const int64_t n = n0 + 16 * (RW * nw + r) + j;
+        if (n < N) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int64_t t = t0 + 16 * tw + 4 * kq + e;
+                if (t < T) y[t * ldy + n] = apply_epi(epi, res[e], t, n, ldy);
+            }
+        }
+    }
+}
+
+template <bool F16, int RW>
+static void launch_mmfx_t(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
+    typedef FxLds<F16, RW> L;
+    static std::atomic<unsigned long long> prepared{0};              // per device: the dynamic-LDS limit of this instantiation
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !(prepared.load() & (1ull << dev))) {
+        (void) hipFuncSetAttribute((const void *) k_mmfx_seq<F16, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
+        (void) hipGetLastError();
+        prepared.fetch_or(1ull << dev);
+    }
+    const int64_t N = W.rows(), K = W.cols();
+    const dim3 grid((unsigned) ((N + 32 * RW - 1) / (32 * RW)), (unsigned) ((T + 31) / 32));
+    hipLaunchKernelGGL((k_mmfx_seq<F16, RW>), grid, dim3(256), (size_t) L::BYTES, st, W.data, N, K, x, ldx, T, y, ldy, epi);
+}
+
+// RWKV_MI_SEQ_F = valu: sequence passes of F16 / F32 matrices stay on k_mvf's token tiles (round 5's exact arm; A/B, tests). Read per call.
+static bool seq_f_on_valu() {
+    const char * e = getenv("RWKV_MI_SEQ_F");
+    return e && e[0] == 'v';
+}
+
 std::atomic<unsigned long long> g_mmf16_launches{0};   // launches of k_mmf16_seq by this process (tests assert that the arm they mean to test ran)
 
 // RWKV_MI_SEQ_F16 = valu (default since round 6: ggml's addition order, sequence == serial bit for bit) | mfma (opt-in: k_mmf16_seq on the matrix cores)
@@ -457,6 +627,14 @@ void launch_matvec_f(const DevTensor & W, const float * x, int64_t ldx, int64_t 
         const dim3 grid((unsigned) ((N + 63) / 64), (unsigned) ((T + 63) / 64), (unsigned) a.ksplit);
         hipLaunchKernelGGL(k_mmf16_seq, grid, dim3(256), 0, st, a);
         if (a.ksplit > 1) hipLaunchKernelGGL(k_mmf16_combine, dim3(grid.x, grid.y, 16), dim3(256), 0, st, a);
+        return;
+    }
+    if ((W.type == T_F16 || W.type == T_F32) && T >= 32 && W.cols() % 32 == 0 && ldx % 4 == 0 && !seq_f_on_valu()) {
+        // the exact arm on the matrix cores (k_mmfx_seq): the same bits as k_mvf. Two row tiles per wave where the rows fill the chip anyway.
+        g_mmfx_launches.fetch_add(1, std::memory_order_relaxed);
+        const bool wide = W.rows() * ((T + 31) / 32) >= 64 * 512;
+        if (W.type == T_F16) { if (wide) launch_mmfx_t<true, 2>(W, x, ldx, T, y, ldy, epi, st); else launch_mmfx_t<true, 1>(W, x, ldx, T, y, ldy, epi, st); }
+        else { if (wide) launch_mmfx_t<false, 2>(W, x, ldx, T, y, ldy, epi, st); else launch_mmfx_t<false, 1>(W, x, ldx, T, y, ldy, epi, st); }
         return;
     }
     if (W.type == T_F16) launch_mvf_t<true>(W, x, ldx, T, y, ldy, epi, st);

@@ -62,6 +62,7 @@ RWKV_API void rwkv_mi_test_fail_state_init(int n) { g_test_fail_state_init.store
 
 // Test hook: launches of the F16 matrix-core sequence kernel (k_mmf16_seq) by this process so far.
 RWKV_API uint64_t rwkv_mi_test_mmf16_launches(void) { return (uint64_t) g_mmf16_launches.load(); }
+RWKV_API uint64_t rwkv_mi_test_mmfx_launches(void) { return (uint64_t) g_mmfx_launches.load(); }
 
 // Test hook: launches of the plain-order quantised GEMM (k_mmq_fast) by this process so far.
 RWKV_API uint64_t rwkv_mi_test_mmq_fast_launches(void) { return (uint64_t) g_mmq_fast_launches.load(); }

@@ -162,3 +162,35 @@ def test_full_length_rwkv7_pass_matches_the_oracle(tmp_path, seq_arm):
     seq_arm(cl, ol, "chunked logits"); seq_arm(cst, ost, "chunked state")
     m.free()
     om.free()
+
+
+@pytest.mark.parametrize("name,fmt", [("mega-v6-2048", "Q4_0"), ("mega-v6-2048", "Q5_1"), ("mega-v6-2048", "Q5_0"), ("slice-v7-2560", "Q8_0")])
+@pytest.mark.parametrize("T", [64, 130])
+def test_folded_quantiser_gives_the_same_bits_as_the_separate_launches(tmp_path, name, fmt, T):
+    """Round 6 folded the activation quantiser into three producers of sequence mode (prefill.hip: the channel-mixing key product's epilogue,
+    group norm + gate, the first RWKV-6 mix / RWKV-7's channel-mixing mix). Each has a switch that restores round 5's separate launches:
+    logits and state of a sequence pass at real row lengths must be the oracle's bit for bit with every switch setting -- ragged last
+    token tile included (T = 130), and for the formats whose images carry extra arrays (Q5_1: s, Q5_0: o)."""
+    import os
+    library()
+    p = str(tmp_path / "m.bin")
+    spec = synth.CONFIGS[name]
+    synth.write_model(p, spec, fmt, seed=67)
+    om = O.OracleModel(p)
+    seq = [int((1103515245 * i + 12345) % spec.n_vocab) for i in range(T)]
+    ol, ost = om.eval_sequence(seq, om.init_state())
+    m = model(p)
+    switches = ["RWKV_MI_NO_EPI_QUANT", "RWKV_MI_NO_GN_QUANT", "RWKV_MI_NO_MIX_QUANT"]
+    try:
+        for off in ([], [switches[0]], [switches[1]], [switches[2]], switches):
+            for k in off:
+                os.environ[k] = "1"
+            try:
+                lg, st = m.eval_sequence(seq, None)
+                assert np.array_equal(lg, ol) and np.array_equal(st, ost), (name, fmt, T, off)
+            finally:
+                for k in off:
+                    os.environ.pop(k, None)
+    finally:
+        m.free()
+        om.free()
