@@ -430,42 +430,52 @@ std::atomic<unsigned long long> g_mmfx_launches{0};
 // (The first version of this kernel read its operands straight from global memory, 128 bytes per lane: 64 different cache lines per load
 //  instruction -- 98.6 ms per pass of an FP16 1.6B file against 67.5 on k_mvf's token tiles.)
 constexpr int FX_KC = 128, FX_PX = 132, FX_PW16 = 136, FX_PW32 = 132;
-template <bool F16, int RW> struct FxLds {
+// PH = 2: the 32 partials are independent chains until the fold, so a SECOND set of four waves owns partials 16 .. 31 of the same tiles (half the
+// accumulators per wave: 64 RW registers instead of 128 RW, twice the waves per tile -- short products no longer sit on one wave per SIMD);
+// the fold's first level, ps[i] += ps[i + 16], joins the two sets through LDS.
+template <bool F16, int RW, int PH> struct FxLds {
     static constexpr int X_FLOATS = 32 * FX_PX;
     static constexpr int W_BYTES = F16 ? 32 * RW * FX_PW16 * 2 : 32 * RW * FX_PW32 * 4;
     static constexpr int BUF = X_FLOATS * 4 + W_BYTES;
-    static constexpr int BYTES = 2 * BUF;
+    static constexpr int XCH = PH == 2 ? 4 * RW * 16 * 64 * 16 : 0;        // [wave][row tile][partial][lane] float4
+    static constexpr int BYTES = 2 * BUF > XCH ? 2 * BUF : XCH;
 };
 
-template <bool F16, int RW>
-__global__ __launch_bounds__(256) void k_mmfx_seq(const void * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x, int64_t ldx,
-                                                  int64_t T, float * __restrict__ y, int64_t ldy, Epi epi) {
-    typedef FxLds<F16, RW> L;
+template <bool F16, int RW, int PH>
+__global__ __launch_bounds__(256 * PH) void k_mmfx_seq(const void * __restrict__ W, int64_t N, int64_t K, const float * __restrict__ x, int64_t ldx,
+                                                       int64_t T, float * __restrict__ y, int64_t ldy, Epi epi) {
+    typedef FxLds<F16, RW, PH> L;
+    constexpr int NT = 256 * PH, NP = 32 / PH;
     extern __shared__ __attribute__((aligned(16))) unsigned char fx_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, kq = lane >> 4, tw = wave & 1, nw = wave >> 1;
+    const int w4 = wave & 3, ph = wave >> 2;
+    const int j = lane & 15, kq = lane >> 4, tw = w4 & 1, nw = w4 >> 1;
     const int64_t n0 = (int64_t) blockIdx.x * 32 * RW, t0 = (int64_t) blockIdx.y * 32;
     auto lx = [&](int buf) { return reinterpret_cast<float *>(fx_lds + buf * L::BUF); };
     auto lw = [&](int buf) { return fx_lds + buf * L::BUF + L::X_FLOATS * 4; };
-    // staging roles. Activations: 4 float4 per thread (token tid / 32 + 8 i, floats 4 (tid % 32) ..). Weights, F16: 2 RW int4 (row tid / 16 + 16 i,
-    // halfs 8 (tid % 16) ..); F32: 4 RW float4 (row tid / 32 + 8 i, floats 4 (tid % 32) ..)
-    float4 xv[4]; int4 wv[4 * RW];
+    // staging roles (idx = tid + NT i). Activations: 1024 float4 per step (token idx / 32, floats 4 (idx % 32) ..). Weights, F16: 512 RW int4 (row
+    // idx / 16, halfs 8 (idx % 16) ..); F32: 1024 RW float4 (row idx / 32, floats 4 (idx % 32) ..)
+    constexpr int NX = 1024 / NT, NW16 = 512 * RW / NT, NW32 = 1024 * RW / NT;
+    float4 xv[NX]; int4 wv[F16 ? NW16 : NW32];
     auto fetch = [&](int64_t k0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int64_t t = t0 + (tid >> 5) + 8 * i, k = k0 + 4 * (tid & 31);
+        for (int i = 0; i < NX; i++) {
+            const int idx = tid + NT * i;
+            const int64_t t = t0 + (idx >> 5), k = k0 + 4 * (idx & 31);
             xv[i] = (t < T && k < K) ? *reinterpret_cast<const float4 *>(x + t * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);   // (K % 32 == 0: absent slices are zeros, fma(0, 0, a) = a)
         }
         if constexpr (F16) {
 #pragma unroll
-            for (int i = 0; i < 2 * RW; i++) {
-                const int64_t n = n0 + (tid >> 4) + 16 * i, k = k0 + 8 * (tid & 15);
+            for (int i = 0; i < NW16; i++) {
+                const int idx = tid + NT * i;
+                const int64_t n = n0 + (idx >> 4), k = k0 + 8 * (idx & 15);
                 wv[i] = (n < N && k < K) ? *reinterpret_cast<const int4 *>(reinterpret_cast<const uint16_t *>(W) + n * K + k) : make_int4(0, 0, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4 * RW; i++) {
-                const int64_t n = n0 + (tid >> 5) + 8 * i, k = k0 + 4 * (tid & 31);
+            for (int i = 0; i < NW32; i++) {
+                const int idx = tid + NT * i;
+                const int64_t n = n0 + (idx >> 5), k = k0 + 4 * (idx & 31);
                 wv[i] = (n < N && k < K) ? *reinterpret_cast<const int4 *>(reinterpret_cast<const float *>(W) + n * K + k) : make_int4(0, 0, 0, 0);
             }
         }
@@ -473,70 +483,90 @@ __global__ __launch_bounds__(256) void k_mmfx_seq(const void * __restrict__ W, i
     auto stash = [&](int buf) {
         float * const bx = lx(buf);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NX; i++) {
+            const int idx = tid + NT * i;
             float4 v = xv[i];
             if constexpr (F16) { v.x = round_f16(v.x); v.y = round_f16(v.y); v.z = round_f16(v.z); v.w = round_f16(v.w); }     // what ggml feeds an F16 matrix
-            *reinterpret_cast<float4 *>(bx + ((tid >> 5) + 8 * i) * FX_PX + 4 * (tid & 31)) = v;
+            *reinterpret_cast<float4 *>(bx + (idx >> 5) * FX_PX + 4 * (idx & 31)) = v;
         }
         if constexpr (F16) {
             uint16_t * const bw = reinterpret_cast<uint16_t *>(lw(buf));
 #pragma unroll
-            for (int i = 0; i < 2 * RW; i++) *reinterpret_cast<int4 *>(bw + ((tid >> 4) + 16 * i) * FX_PW16 + 8 * (tid & 15)) = wv[i];
+            for (int i = 0; i < NW16; i++) { const int idx = tid + NT * i; *reinterpret_cast<int4 *>(bw + (idx >> 4) * FX_PW16 + 8 * (idx & 15)) = wv[i]; }
         } else {
             float * const bw = reinterpret_cast<float *>(lw(buf));
 #pragma unroll
-            for (int i = 0; i < 4 * RW; i++) *reinterpret_cast<int4 *>(bw + ((tid >> 5) + 8 * i) * FX_PW32 + 4 * (tid & 31)) = wv[i];
+            for (int i = 0; i < NW32; i++) { const int idx = tid + NT * i; *reinterpret_cast<int4 *>(bw + (idx >> 5) * FX_PW32 + 4 * (idx & 31)) = wv[i]; }
         }
     };
-    mf_f4 acc[RW][32];
+    mf_f4 acc[RW][NP];
 #pragma unroll
     for (int r = 0; r < RW; r++)
 #pragma unroll
-        for (int p = 0; p < 32; p++) acc[r][p] = (mf_f4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int p = 0; p < NP; p++) acc[r][p] = (mf_f4){0.0f, 0.0f, 0.0f, 0.0f};
     fetch(0); stash(0);
     __syncthreads();
     int buf = 0;
     for (int64_t k0 = 0; k0 < K; k0 += FX_KC, buf ^= 1) {
         const bool more = k0 + FX_KC < K;
         if (more) fetch(k0 + FX_KC);                                  // the next step's lines are in flight under this step's instructions
-        float xa[32];
+        float xa[NP];
         {
-            const float4 * src = reinterpret_cast<const float4 *>(lx(buf) + (16 * tw + j) * FX_PX + 32 * kq);
+            const float4 * src = reinterpret_cast<const float4 *>(lx(buf) + (16 * tw + j) * FX_PX + 32 * kq + NP * ph);
 #pragma unroll
-            for (int i = 0; i < 8; i++) { const float4 v = src[i]; xa[4 * i] = v.x; xa[4 * i + 1] = v.y; xa[4 * i + 2] = v.z; xa[4 * i + 3] = v.w; }
+            for (int i = 0; i < NP / 4; i++) { const float4 v = src[i]; xa[4 * i] = v.x; xa[4 * i + 1] = v.y; xa[4 * i + 2] = v.z; xa[4 * i + 3] = v.w; }
         }
 #pragma unroll
         for (int r = 0; r < RW; r++) {
-            float wb[32];
+            float wb[NP];
             const int row = 16 * (RW * nw + r) + j;
             if constexpr (F16) {
-                const int4 * src = reinterpret_cast<const int4 *>(reinterpret_cast<const uint16_t *>(lw(buf)) + row * FX_PW16 + 32 * kq);
+                const int4 * src = reinterpret_cast<const int4 *>(reinterpret_cast<const uint16_t *>(lw(buf)) + row * FX_PW16 + 32 * kq + NP * ph);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < NP / 8; i++) {
                     const int4 raw = src[i];
                     const unsigned u[4] = {(unsigned) raw.x, (unsigned) raw.y, (unsigned) raw.z, (unsigned) raw.w};
 #pragma unroll
                     for (int e = 0; e < 4; e++) { wb[8 * i + 2 * e] = h2f_bits((uint16_t) (u[e] & 0xFFFFu)); wb[8 * i + 2 * e + 1] = h2f_bits((uint16_t) (u[e] >> 16)); }
                 }
             } else {
-                const float4 * src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(lw(buf)) + row * FX_PW32 + 32 * kq);
+                const float4 * src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(lw(buf)) + row * FX_PW32 + 32 * kq + NP * ph);
 #pragma unroll
-                for (int i = 0; i < 8; i++) { const float4 v = src[i]; wb[4 * i] = v.x; wb[4 * i + 1] = v.y; wb[4 * i + 2] = v.z; wb[4 * i + 3] = v.w; }
+                for (int i = 0; i < NP / 4; i++) { const float4 v = src[i]; wb[4 * i] = v.x; wb[4 * i + 1] = v.y; wb[4 * i + 2] = v.z; wb[4 * i + 3] = v.w; }
             }
             // D[token][row] += A[token][k] B[k][row]: A = the activations (lane: token l % 16, slice l / 16), B = the weights (row l % 16, slice l / 16);
-            // instruction p adds the links k = k0 + p, + 32, + 64, + 96 to partial p's chain
+            // the instruction of partial q = NP ph + p adds the links k = k0 + q, + 32, + 64, + 96 to q's chain
 #pragma unroll
-            for (int p = 0; p < 32; p++) acc[r][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[p], wb[p], acc[r][p], 0, 0, 0);
+            for (int p = 0; p < NP; p++) acc[r][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[p], wb[p], acc[r][p], 0, 0, 0);
         }
         if (more) stash(buf ^ 1);
         __syncthreads();
     }
-    // C / D layout: column (= weight row) lane % 16, row (= token) 4 (lane / 16) + register. The fold of k_mvf: ps[i] += ps[i + 16], += ps[i + 8],
-    // += ps[i + 4], (ps0 + ps1) + (ps2 + ps3).
+    // The fold of k_mvf: ps[i] += ps[i + 16], += ps[i + 8], += ps[i + 4], (ps0 + ps1) + (ps2 + ps3). PH = 2: the upper partials come from the
+    // second wave set through LDS (the staging buffers are free: every wave is behind the loop's last barrier).
+    if constexpr (PH == 2) {
+        mf_f4 * const xch = reinterpret_cast<mf_f4 *>(fx_lds) + (size_t) w4 * RW * 16 * 64;
+        if (ph == 1) {
+#pragma unroll
+            for (int r = 0; r < RW; r++)
+#pragma unroll
+                for (int p = 0; p < 16; p++) xch[(r * 16 + p) * 64 + lane] = acc[r][p];
+        }
+        __syncthreads();
+        if (ph == 1) return;
+#pragma unroll
+        for (int r = 0; r < RW; r++)
+#pragma unroll
+            for (int p = 0; p < 16; p++) acc[r][p] = acc[r][p] + xch[(r * 16 + p) * 64 + lane];
+    } else {
+#pragma unroll
+        for (int r = 0; r < RW; r++)
+#pragma unroll
+            for (int p = 0; p < 16; p++) acc[r][p] = acc[r][p] + acc[r][p + 16 < NP ? p + 16 : p];
+    }
+    // C / D layout: column (= weight row) lane % 16, row (= token) 4 (lane / 16) + register
 #pragma unroll
     for (int r = 0; r < RW; r++) {
-#pragma unroll
-        for (int p = 0; p < 16; p++) acc[r][p] = acc[r][p] + acc[r][p + 16];
 #pragma unroll
         for (int p = 0; p < 8; p++) acc[r][p] = acc[r][p] + acc[r][p + 8];
 #pragma unroll
@@ -553,20 +583,20 @@ __global__ __launch_bounds__(256) void k_mmfx_seq(const void * __restrict__ W, i
     }
 }
 
-template <bool F16, int RW>
+template <bool F16, int RW, int PH>
 static void launch_mmfx_t(const DevTensor & W, const float * x, int64_t ldx, int64_t T, float * y, int64_t ldy, const Epi & epi, hipStream_t st) {
-    typedef FxLds<F16, RW> L;
+    typedef FxLds<F16, RW, PH> L;
     static std::atomic<unsigned long long> prepared{0};              // per device: the dynamic-LDS limit of this instantiation
     int dev = 0;
     (void) hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !(prepared.load() & (1ull << dev))) {
-        (void) hipFuncSetAttribute((const void *) k_mmfx_seq<F16, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
+        (void) hipFuncSetAttribute((const void *) k_mmfx_seq<F16, RW, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
         (void) hipGetLastError();
         prepared.fetch_or(1ull << dev);
     }
     const int64_t N = W.rows(), K = W.cols();
     const dim3 grid((unsigned) ((N + 32 * RW - 1) / (32 * RW)), (unsigned) ((T + 31) / 32));
-    hipLaunchKernelGGL((k_mmfx_seq<F16, RW>), grid, dim3(256), (size_t) L::BYTES, st, W.data, N, K, x, ldx, T, y, ldy, epi);
+    hipLaunchKernelGGL((k_mmfx_seq<F16, RW, PH>), grid, dim3(256 * PH), (size_t) L::BYTES, st, W.data, N, K, x, ldx, T, y, ldy, epi);
 }
 
 // RWKV_MI_SEQ_F = valu: sequence passes of F16 / F32 matrices stay on k_mvf's token tiles (round 5's exact arm; A/B, tests). Read per call.
@@ -630,11 +660,13 @@ void launch_matvec_f(const DevTensor & W, const float * x, int64_t ldx, int64_t 
         return;
     }
     if ((W.type == T_F16 || W.type == T_F32) && T >= 32 && W.cols() % 32 == 0 && ldx % 4 == 0 && !seq_f_on_valu()) {
-        // the exact arm on the matrix cores (k_mmfx_seq): the same bits as k_mvf. Two row tiles per wave where the rows fill the chip anyway.
+        // the exact arm on the matrix cores (k_mmfx_seq): the same bits as k_mvf
         g_mmfx_launches.fetch_add(1, std::memory_order_relaxed);
-        const bool wide = W.rows() * ((T + 31) / 32) >= 64 * 512;
-        if (W.type == T_F16) { if (wide) launch_mmfx_t<true, 2>(W, x, ldx, T, y, ldy, epi, st); else launch_mmfx_t<true, 1>(W, x, ldx, T, y, ldy, epi, st); }
-        else { if (wide) launch_mmfx_t<false, 2>(W, x, ldx, T, y, ldy, epi, st); else launch_mmfx_t<false, 1>(W, x, ldx, T, y, ldy, epi, st); }
+        // One row tile per wave, the partials split over two wave sets (121 registers: two workgroups of eight waves per CU). Measured against
+        // two row tiles per wave on four waves (424 - 512 registers, one wave per SIMD) and against both at once, 1024-token passes, same box
+        // (profiles/r06_seq_f_exact.txt): FP16 1.6B file 39.9 / 56.8 / 43.4 ms, FP32 36.9 / 47.6 / 41.2, RWKV-7 2.9B Q5_1 47.7 / 52.9 / 50.7.
+        if (W.type == T_F16) launch_mmfx_t<true, 1, 2>(W, x, ldx, T, y, ldy, epi, st);
+        else launch_mmfx_t<false, 1, 2>(W, x, ldx, T, y, ldy, epi, st);
         return;
     }
     if (W.type == T_F16) launch_mvf_t<true>(W, x, ldx, T, y, ldy, epi, st);
