@@ -1,5 +1,7 @@
 #!/bin/bash
-# k_mmfx_seq: which instantiation for which shapes (RWKV_MI_FX = wide | split | split2 forces one; unset = the shipped choice), same box
+# k_mmfx_seq: which instantiation for which shapes, same box. (Ran at commit 'sequence mode: F16 / F32 matrices on the matrix cores ...' + the
+# partial split, when RWKV_MI_FX = wide | split | split2 forced one of three instantiations; 'split' won everywhere and is the only one built
+# now -- the switch is gone, the record is profiles/r06_seq_f_exact.txt.)
 cd "$(dirname "$0")/.."; T=${1:-r06y}; O=gpurun_out/$T; mkdir -p $O
 export TMPDIR=/tmp RWKV_BENCH_DIR=/tmp
 ( timeout 900 python -m pytest tests/test_gpu_seq_f_exact.py -x -q -m gpu -p no:cacheprovider 2>&1 | tail -3 ) | tee $O/pytest.txt
