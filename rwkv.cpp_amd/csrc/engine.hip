@@ -52,7 +52,8 @@ static int mega_chain_count(rwkv_context * ctx, int delta) {
 static void mega_chain_begin(rwkv_context * ctx) {
     const int dev = ctx->model->device;
     mega_mu(dev).lock();
-    if (dev >= 0 && dev < k_max_devices && g_mega_last[dev] && g_mega_last_owner[dev] != ctx) (void) hipStreamWaitEvent(ctx->stream, g_mega_last[dev], 0);
+    // (chain_covered: a pipeline hop has already made this stream wait on exactly that launch -- one barrier packet in front of the launch, not two)
+    if (dev >= 0 && dev < k_max_devices && g_mega_last[dev] && g_mega_last_owner[dev] != ctx && g_mega_last[dev] != ctx->chain_covered) (void) hipStreamWaitEvent(ctx->stream, g_mega_last[dev], 0);
 }
 static void mega_chain_end(rwkv_context * ctx) {
     const int dev = ctx->model->device;
@@ -61,6 +62,12 @@ static void mega_chain_end(rwkv_context * ctx) {
         g_mega_last[dev] = ctx->mega_done; g_mega_last_owner[dev] = ctx;
     }
     mega_mu(dev).unlock();
+}
+hipEvent_t mega_chain_marker(rwkv_context * ctx) {
+    const int dev = ctx->model->device;
+    if (dev < 0 || dev >= k_max_devices) return nullptr;
+    std::lock_guard<std::mutex> lk(mega_mu(dev));
+    return (g_mega_last_owner[dev] == ctx && g_mega_last[dev] == ctx->mega_done) ? ctx->mega_done : nullptr;
 }
 static void mega_chain_forget(rwkv_context * ctx) {
     const int dev = ctx->model->device;

@@ -170,6 +170,8 @@ struct rwkv_context {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t mega_done = nullptr;   // completion of this context's latest persistent-kernel launch (engine.hip: launches are chained per device)
+    hipEvent_t chain_covered = nullptr;   // (runner.cpp) an event this context's stream already waits on for the coming step: when it is the device's latest
+                                          // persistent launch, the per-device chain does not wait on it a second time
     std::string persist_note;         // why this context runs the single-token path it runs (rwkv_mi_persist_info: chosen kernel, calibration, fall-backs)
 
     // fused single-token path (fused_v6.hip) when the model qualifies
@@ -301,7 +303,8 @@ bool forward_streamed(rwkv_context * ctx, bool want_logits, const float * h_in, 
 void abi_streamer_free(void * p);
 // single-token forward through the captured hipGraph (falls back to forward() when capture is disabled)
 bool forward_decode(rwkv_context * ctx, bool want_logits);
-bool single_launch_step(const rwkv_context * ctx, bool want_logits);   // the step is one directly issued persistent launch (no graph replay)
+bool single_launch_step(const rwkv_context * ctx, bool want_logits);
+hipEvent_t mega_chain_marker(rwkv_context * ctx);   // the event recorded behind ctx's persistent launch if that launch is the latest of its device (else nullptr)   // the step is one directly issued persistent launch (no graph replay)
 // grows the per-context activation scratch to hold T tokens
 bool ensure_scratch(rwkv_context * ctx, int64_t T);
 uint32_t * folded_argmax_target(const rwkv_context * ctx);

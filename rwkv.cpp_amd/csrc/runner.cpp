@@ -54,13 +54,21 @@ struct Hop {
     // and produce_end() (the message is there) instead of calling send().
     virtual void * direct_target(int, int) { return nullptr; }
     virtual bool produce_begin(int, int, hipStream_t) { return false; }
-    virtual bool produce_end(int, int, hipStream_t) { return false; }
+    // done: an event already recorded behind the producing launch on the sender's stream (the per-device chain's marker), or nullptr -- the
+    // hop then records its own
+    virtual bool produce_end(int, int, hipStream_t, hipEvent_t /* done */) { return false; }
+    // the event the last recv() of (j, msg) made the stream wait on (bound messages; else nullptr)
+    virtual hipEvent_t waited_on(int, int) { return nullptr; }
+    // The hop is an edge of a CLOSED loop (greedy decode: the token comes back from the last stage): every buffer's reuse is then ordered by
+    // the loop itself -- stage s can only start token t + 1 behind the last stage's token t, which is behind stage s + 1's token t -- and the
+    // `taken` events of bound messages are neither recorded nor waited for.
+    virtual void set_closed_loop(bool) {}
 };
 constexpr int k_hop_msgs = 2;
 
 struct LocalHop : Hop {
     int src_dev, dst_dev;
-    struct Slot { void * box = nullptr; void * direct = nullptr; hipEvent_t ready = nullptr, taken = nullptr; bool used = false, released = false; };
+    struct Slot { void * box = nullptr; void * direct = nullptr; hipEvent_t ready = nullptr, taken = nullptr, ready_now = nullptr; bool used = false, released = false; };
     // One mailbox and one event pair PER MESSAGE of a stream's iteration: a stage of an RWKV-7 chain sends x and then v_first. Through
     // one box the second send only waited for the previous ITERATION's `taken` and overwrote x before the receiver had run -- both
     // receives then read v_first (round-3 review; tests/test_gpu_pipeline_cpp.py::test_rwkv7_greedy_loop_through_a_chain).
@@ -77,6 +85,8 @@ struct LocalHop : Hop {
     std::vector<Slot> slots;   // [stream][message]
     size_t cap;
     bool peer_ok = false;      // kernels on src_dev may store to memory of dst_dev
+    bool closed = false;       // set_closed_loop
+    void set_closed_loop(bool on) override { static const bool keep = getenv("RWKV_MI_HOP_TAKEN") != nullptr; closed = on && !keep; }   // (RWKV_MI_HOP_TAKEN=1: A/B)
     LocalHop(int sdev, int ddev, int n_streams, size_t bytes, bool & ok) : src_dev(sdev), dst_dev(ddev), slots((size_t) n_streams * k_hop_msgs), cap(bytes) {
         peer_ok = sdev == ddev;
         if (!peer_ok && hipSetDevice(sdev) == hipSuccess) {
@@ -114,9 +124,9 @@ struct LocalHop : Hop {
         Slot * s = slot(j, msg);
         if (!s || bytes > cap) return false;
         if (s->direct) {
-            if (s->released && hipStreamWaitEvent(st, s->taken, 0) != hipSuccess) return false;   // the receiver is done with what the buffer held
+            if (!closed && s->released && hipStreamWaitEvent(st, s->taken, 0) != hipSuccess) return false;   // the receiver is done with what the buffer held
             if (hipMemcpyPeerAsync(s->direct, dst_dev, src, src_dev, bytes, st) != hipSuccess) return false;
-            s->used = true;
+            s->used = true; s->ready_now = s->ready;
             return hipEventRecord(s->ready, st) == hipSuccess;
         }
         if (s->used && hipStreamWaitEvent(st, s->taken, 0) != hipSuccess) return false;   // the previous message has left the mailbox
@@ -127,18 +137,22 @@ struct LocalHop : Hop {
     bool recv(int j, int msg, void * dst, size_t bytes, hipStream_t st) override {
         Slot * s = slot(j, msg);
         if (!s || bytes > cap || !s->used) return false;
+        if (s->direct) {
+            if (!s->ready_now || hipStreamWaitEvent(st, s->ready_now, 0) != hipSuccess) return false;
+            return dst == s->direct;                                                         // (already there)
+        }
         if (hipStreamWaitEvent(st, s->ready, 0) != hipSuccess) return false;
-        if (s->direct) return dst == s->direct;                                              // (already there)
         if (hipMemcpyAsync(dst, s->box, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
         return hipEventRecord(s->taken, st) == hipSuccess;
     }
     bool release(int j, int msg, hipStream_t st) override {
         Slot * s = slot(j, msg);
         if (!s) return false;
-        if (!s->direct) return true;
+        if (!s->direct || closed) return true;
         s->released = true;
         return hipEventRecord(s->taken, st) == hipSuccess;
     }
+    hipEvent_t waited_on(int j, int msg) override { Slot * s = slot(j, msg); return (s && s->direct) ? s->ready_now : nullptr; }
     void * direct_target(int j, int msg) override {
         const char * e = getenv("RWKV_MI_HOP");      // RWKV_MI_HOP=copy: one peer copy per hop (A/B, tests; read per call)
         const bool copy_only = e && e[0] == 'c';
@@ -148,12 +162,15 @@ struct LocalHop : Hop {
     bool produce_begin(int j, int msg, hipStream_t st) override {
         Slot * s = slot(j, msg);
         if (!s || !s->direct) return false;
-        return !s->released || hipStreamWaitEvent(st, s->taken, 0) == hipSuccess;
+        return closed || !s->released || hipStreamWaitEvent(st, s->taken, 0) == hipSuccess;
     }
-    bool produce_end(int j, int msg, hipStream_t st) override {
+    bool produce_end(int j, int msg, hipStream_t st, hipEvent_t done) override {
         Slot * s = slot(j, msg);
         if (!s || !s->direct) return false;
         s->used = true;
+        static const bool own = getenv("RWKV_MI_HOP_OWN_EVENT") != nullptr;       // (A/B: always the hop's own event)
+        if (done && src_dev == dst_dev && !own) { s->ready_now = done; return true; }   // the chain's marker behind the launch IS "the message is there"
+        s->ready_now = s->ready;
         return hipEventRecord(s->ready, st) == hipSuccess;
     }
 };
@@ -334,7 +351,11 @@ bool stage_iteration(StagePart & p, rwkv_context * err, size_t t, int j) {
     }
     const bool xd = !m.has_head && (size_t) j < p.x_direct.size() && p.x_direct[(size_t) j] && c->mega != nullptr;
     if (xd && !p.out->produce_begin(j, 0, c->stream)) return fail();
-    if (!forward_decode(c, m.has_head)) return fail();
+    // (what the stream was just made to wait on -- the previous stage's launch, when the hop used the device chain's marker for it)
+    c->chain_covered = m.has_embed ? (p.tok_in && t > 0 ? p.tok_in->waited_on(j, 0) : nullptr) : p.in->waited_on(j, 0);
+    const bool fwd = forward_decode(c, m.has_head);
+    c->chain_covered = nullptr;
+    if (!fwd) return fail();
     if (m.has_head) {
         // the chosen token: where this context's embedding reads it (a one-stage "chain"), else in the slot the feedback hop sends from
         uint32_t * dst = m.has_embed ? c->d_tokens : c->d_next_token;
@@ -343,7 +364,7 @@ bool stage_iteration(StagePart & p, rwkv_context * err, size_t t, int j) {
         if (!in_launch && hipMemcpyAsync(p.d_hist + (size_t) j * p.n_tokens + t, dst, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail();
         if (p.tok_out && t + 1 < p.n_tokens && !p.tok_out->send(j, 0, dst, sizeof(uint32_t), c->stream)) return fail();
     } else {
-        if (xd) { if (!p.out->produce_end(j, 0, c->stream)) return fail(); }
+        if (xd) { if (!p.out->produce_end(j, 0, c->stream, mega_chain_marker(c))) return fail(); }
         else if (!p.out || !p.out->send(j, 0, c->b.x, D * sizeof(float), c->stream)) return fail();
         if (m.arch_major == 7 && !p.out->send(j, 1, c->b.v_first, D * sizeof(float), c->stream)) return fail();
     }
@@ -482,6 +503,7 @@ bool pipeline_decode_greedy(rwkv_context * const * fronts, size_t n_streams, con
             if (parts[s].in) { (void) parts[s].in->bind((int) j, 0, c->b.x); if (c->model->arch_major == 7) (void) parts[s].in->bind((int) j, 1, c->b.v_first); }
             if (parts[s].tok_in) (void) parts[s].tok_in->bind((int) j, 0, c->d_tokens);
         }
+    for (auto & h : hops) h->set_closed_loop(S > 1);       // (S > 1: the token feedback closes the loop for every decode stream)
     HistScope hist_scope(parts[S - 1]);
     XDirectScope x_scope(parts);
     for (size_t s = 0; s < S; s++) for (rwkv_context * c : parts[s].h) { if (hipSetDevice(c->model->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { f0->last_error |= RWKV_ERROR_GRAPH; return false; } }
