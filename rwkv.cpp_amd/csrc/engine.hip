@@ -661,7 +661,7 @@ struct Runner {
             float * o0 = sout + (int64_t) m.layer_begin * per_layer;
             // (persist_v47.hip: the launch starts from the token id and ends with the argmax where the stage has embedding / head)
             const uint32_t * tok = (lb == m.layer_begin && m.has_embed && mega_v6_folds_embed(ctx->mega)) ? ctx->d_tokens : nullptr;
-            uint32_t * ntok = tok ? ctx->d_tokens : ctx->d_next_token;    // the greedy loops read the next token where the embedding reads it
+            uint32_t * ntok = ctx->ntok_out ? ctx->ntok_out : (tok ? ctx->d_tokens : ctx->d_next_token);    // the greedy loops read the next token where the embedding reads it
             if (whole) mega_v6_forward(ctx->mega, b.x, s0, o0, st, &ctx->prof, head_done ? ctx->d_logits : nullptr, b.v_first, tok, ntok);
             else {
                 // (a range's state pointers are those of ITS first layer for persist_v47.hip, of the stage's first layer for the ring kernel)

@@ -170,6 +170,8 @@ struct rwkv_context {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t mega_done = nullptr;   // completion of this context's latest persistent-kernel launch (engine.hip: launches are chained per device)
+    uint32_t * ntok_out = nullptr;        // (runner.cpp) where a launch that folds the argmax leaves the chosen token instead of d_tokens / d_next_token:
+                                          // the first stage's token word, through the peer mapping (the token feedback without a copy)
     hipEvent_t chain_covered = nullptr;   // (runner.cpp) an event this context's stream already waits on for the coming step: when it is the device's latest
                                           // persistent launch, the per-device chain does not wait on it a second time
     std::string persist_note;         // why this context runs the single-token path it runs (rwkv_mi_persist_info: chosen kernel, calibration, fall-backs)

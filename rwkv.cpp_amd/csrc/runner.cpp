@@ -334,6 +334,7 @@ struct StagePart {
     size_t n_tokens = 0;
     std::vector<char> hist_in_launch;  // (last stage) per decode stream: the persistent launch appends the token it picks to d_hist itself
     std::vector<char> x_direct;        // per decode stream: the stage's launch stores the residual stream in the next stage's buffer itself
+    std::vector<char> tok_direct;      // (last stage) per decode stream: the launch stores the chosen token in the first stage's token word itself
 };
 
 // stage `p`, decode stream j, token index t: receive, run the layers, send. Everything is enqueued on the context's stream.
@@ -351,12 +352,18 @@ bool stage_iteration(StagePart & p, rwkv_context * err, size_t t, int j) {
     }
     const bool xd = !m.has_head && (size_t) j < p.x_direct.size() && p.x_direct[(size_t) j] && c->mega != nullptr;
     if (xd && !p.out->produce_begin(j, 0, c->stream)) return fail();
+    // (last stage of a chain) the launch leaves the chosen token in the first stage's token word itself
+    const bool td = m.has_head && !m.has_embed && p.tok_out && (size_t) j < p.tok_direct.size() && p.tok_direct[(size_t) j] && c->mega != nullptr &&
+                    (size_t) j < p.hist_in_launch.size() && p.hist_in_launch[(size_t) j];
+    if (td) { if (!p.tok_out->produce_begin(j, 0, c->stream)) return fail(); c->ntok_out = (uint32_t *) p.tok_out->direct_target(j, 0); }
     // (what the stream was just made to wait on -- the previous stage's launch, when the hop used the device chain's marker for it)
     c->chain_covered = m.has_embed ? (p.tok_in && t > 0 ? p.tok_in->waited_on(j, 0) : nullptr) : p.in->waited_on(j, 0);
     const bool fwd = forward_decode(c, m.has_head);
-    c->chain_covered = nullptr;
+    c->chain_covered = nullptr; c->ntok_out = nullptr;
     if (!fwd) return fail();
-    if (m.has_head) {
+    if (td) {
+        if (!p.tok_out->produce_end(j, 0, c->stream, mega_chain_marker(c))) return fail();
+    } else if (m.has_head) {
         // the chosen token: where this context's embedding reads it (a one-stage "chain"), else in the slot the feedback hop sends from
         uint32_t * dst = m.has_embed ? c->d_tokens : c->d_next_token;
         if (folded_argmax_target(c) != dst) launch_argmax(c->d_logits, m.n_vocab(), dst, c->stream);   // (else the persistent launch left it there)
@@ -414,11 +421,23 @@ void x_direct_on(StagePart & p) {
 }
 void x_direct_off(StagePart & p) {
     for (size_t j = 0; j < p.x_direct.size(); j++) if (p.x_direct[j] && p.h[j]->mega) (void) mega_v6_set_x_out(p.h[j]->mega, nullptr);
-    p.x_direct.clear();
+    p.x_direct.clear(); p.tok_direct.clear();
+}
+// (last stage) the token feedback the same way: a launch that folds the argmax AND appends to the history itself (hist_on) can leave the token
+// in the first stage's token word -- nothing on this side reads it then
+void tok_direct_on(StagePart & p) {
+    p.tok_direct.assign(p.h.size(), 0);
+    if (!p.tok_out) return;
+    for (size_t j = 0; j < p.h.size(); j++) {
+        rwkv_context * c = p.h[j];
+        if (!p.tok_out->direct_target((int) j, 0) || !c->mega || !c->model->has_head || c->model->has_embed || folded_argmax_target(c) == nullptr) continue;
+        if (!(j < p.hist_in_launch.size() && p.hist_in_launch[j]) || !(!c->use_graph || single_launch_step(c, true))) continue;
+        p.tok_direct[j] = 1;
+    }
 }
 struct XDirectScope {
     std::vector<StagePart> & ps;
-    explicit XDirectScope(std::vector<StagePart> & q) : ps(q) { for (StagePart & p : ps) x_direct_on(p); }
+    explicit XDirectScope(std::vector<StagePart> & q) : ps(q) { for (StagePart & p : ps) { x_direct_on(p); tok_direct_on(p); } }
     ~XDirectScope() { for (StagePart & p : ps) x_direct_off(p); }
 };
 
