@@ -86,7 +86,7 @@ struct LocalHop : Hop {
     size_t cap;
     bool peer_ok = false;      // kernels on src_dev may store to memory of dst_dev
     bool closed = false;       // set_closed_loop
-    void set_closed_loop(bool on) override { static const bool keep = getenv("RWKV_MI_HOP_TAKEN") != nullptr; closed = on && !keep; }   // (RWKV_MI_HOP_TAKEN=1: A/B)
+    void set_closed_loop(bool on) override { closed = on && getenv("RWKV_MI_HOP_TAKEN") == nullptr; }   // (RWKV_MI_HOP_TAKEN=1: A/B, tests; read per call)
     LocalHop(int sdev, int ddev, int n_streams, size_t bytes, bool & ok) : src_dev(sdev), dst_dev(ddev), slots((size_t) n_streams * k_hop_msgs), cap(bytes) {
         peer_ok = sdev == ddev;
         if (!peer_ok && hipSetDevice(sdev) == hipSuccess) {
@@ -168,7 +168,7 @@ struct LocalHop : Hop {
         Slot * s = slot(j, msg);
         if (!s || !s->direct) return false;
         s->used = true;
-        static const bool own = getenv("RWKV_MI_HOP_OWN_EVENT") != nullptr;       // (A/B: always the hop's own event)
+        const bool own = getenv("RWKV_MI_HOP_OWN_EVENT") != nullptr;       // (A/B, tests: always the hop's own event; read per call)
         if (done && src_dev == dst_dev && !own) { s->ready_now = done; return true; }   // the chain's marker behind the launch IS "the message is there"
         s->ready_now = s->ready;
         return hipEventRecord(s->ready, st) == hipSuccess;

@@ -223,11 +223,12 @@ def test_rwkv7_greedy_loop_through_a_chain(tmp_path, devices):
 
 @pytest.mark.parametrize("name,fmt,devices,kind", [("mega-v6-2048-v8k", "Q4_0", "0,0,0", 2), ("slice-v7-2560", "Q5_1", "0,0", 3), ("chain-v6-32x256", "Q4_0", "0,0,0,0", 0)])
 def test_hop_arms_of_the_greedy_loop(tmp_path, name, fmt, devices, kind):
-    """The three forms of a hop of the C++ greedy loop (runner.cpp LocalHop) give the same tokens and state as the CPU oracle: the stage's
-    last layer storing the residual stream in the next stage's buffer (default where the stage is one persistent launch: kinds 2 / 3), one
-    peer copy into that buffer (RWKV_MI_HOP=copy; also what stages on the per-layer launches get), and round 5's mailbox with a copy on
-    each side (RWKV_MI_HOP=mailbox) -- single stream and two interleaved streams, tokens appended to the history inside the launch where
-    the last stage folds its argmax."""
+    """The forms of a hop of the C++ greedy loop (runner.cpp LocalHop) give the same tokens and state as the CPU oracle: the stage's last
+    layer storing the residual stream in the next stage's buffer and the last stage's launch the token in the first stage's token word, one
+    event record and one wait per hop (default where the stage is one persistent launch: kinds 2 / 3), one peer copy into that buffer
+    (RWKV_MI_HOP=copy; also what stages on the per-layer launches get), round 5's mailbox with a copy on each side (RWKV_MI_HOP=mailbox), and
+    the default with its `taken` / own events back ("events") -- single stream and two interleaved streams, tokens appended to the history
+    inside the launch where the last stage folds its argmax."""
     library()
     p = str(tmp_path / "m.bin")
     spec = synth.CONFIGS[name]
@@ -251,8 +252,11 @@ def test_hop_arms_of_the_greedy_loop(tmp_path, name, fmt, devices, kind):
         assert pm.persist_kind() == kind
     clone = pm.clone()
     try:
-        for arm in (None, "copy", "mailbox"):
-            if arm:
+        for arm in (None, "copy", "mailbox", "events"):
+            if arm == "events":       # the default hop with its `taken` events and its own "there" event back (RWKV_MI_HOP_TAKEN / _OWN_EVENT)
+                os.environ["RWKV_MI_HOP_TAKEN"] = "1"
+                os.environ["RWKV_MI_HOP_OWN_EVENT"] = "1"
+            elif arm:
                 os.environ["RWKV_MI_HOP"] = arm
             try:
                 for _ in range(2):      # (twice: the second call finds the buffers of the first released)
@@ -267,7 +271,8 @@ def test_hop_arms_of_the_greedy_loop(tmp_path, name, fmt, devices, kind):
                     assert list(toks[j]) == refs[j][0], (arm, j)
                     assert np.array_equal(m.state_store(), refs[j][1]), (arm, j)
             finally:
-                os.environ.pop("RWKV_MI_HOP", None)
+                for k in ("RWKV_MI_HOP", "RWKV_MI_HOP_TAKEN", "RWKV_MI_HOP_OWN_EVENT"):
+                    os.environ.pop(k, None)
         # the plain ABI on the same chain afterwards: the stages' own residual buffers are in use again (x_out was reset)
         ost, st = om.init_state(), None
         for t in TOKENS:
