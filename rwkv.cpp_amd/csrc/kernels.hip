@@ -435,7 +435,7 @@ constexpr int FX_KC = 128, FX_PX = 132, FX_PW16 = 136, FX_PW32 = 132;
 // the fold's first level, ps[i] += ps[i + 16], joins the two sets through LDS.
 template <bool F16, int RW, int PH> struct FxLds {
     static constexpr int X_FLOATS = 32 * FX_PX;
-    static constexpr int W_BYTES = F16 ? 32 * RW * FX_PW16 * 2 : 32 * RW * FX_PW32 * 4;
+    static constexpr int W_BYTES = 32 * RW * FX_PW32 * 4;               // weights sit in LDS as f32 for both types (F16: converted once, on the way in)
     static constexpr int BUF = X_FLOATS * 4 + W_BYTES;
     static constexpr int XCH = PH == 2 ? 4 * RW * 16 * 64 * 16 : 0;        // [wave][row tile][partial][lane] float4
     static constexpr int BYTES = 2 * BUF > XCH ? 2 * BUF : XCH;
@@ -490,9 +490,20 @@ __global__ __launch_bounds__(256 * PH) void k_mmfx_seq(const void * __restrict__
             *reinterpret_cast<float4 *>(bx + (idx >> 5) * FX_PX + 4 * (idx & 31)) = v;
         }
         if constexpr (F16) {
-            uint16_t * const bw = reinterpret_cast<uint16_t *>(lw(buf));
+            // converted here, once per element (the first version kept halfs in LDS and converted in every wave that read them -- two waves per
+            // element, unpacking shifts included: 6.6 VALU instructions per MFMA and 182 us per launch against 4.1 and 128 for F32 weights)
+            float * const bw = reinterpret_cast<float *>(lw(buf));
 #pragma unroll
-            for (int i = 0; i < NW16; i++) { const int idx = tid + NT * i; *reinterpret_cast<int4 *>(bw + (idx >> 4) * FX_PW16 + 8 * (idx & 15)) = wv[i]; }
+            for (int i = 0; i < NW16; i++) {
+                const int idx = tid + NT * i;
+                const unsigned u[4] = {(unsigned) wv[i].x, (unsigned) wv[i].y, (unsigned) wv[i].z, (unsigned) wv[i].w};
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { f[2 * e] = h2f_bits((uint16_t) (u[e] & 0xFFFFu)); f[2 * e + 1] = h2f_bits((uint16_t) (u[e] >> 16)); }
+                float * dst = bw + (idx >> 4) * FX_PW32 + 8 * (idx & 15);
+                *reinterpret_cast<float4 *>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+                *reinterpret_cast<float4 *>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            }
         } else {
             float * const bw = reinterpret_cast<float *>(lw(buf));
 #pragma unroll
@@ -520,16 +531,7 @@ __global__ __launch_bounds__(256 * PH) void k_mmfx_seq(const void * __restrict__
         for (int r = 0; r < RW; r++) {
             float wb[NP];
             const int row = 16 * (RW * nw + r) + j;
-            if constexpr (F16) {
-                const int4 * src = reinterpret_cast<const int4 *>(reinterpret_cast<const uint16_t *>(lw(buf)) + row * FX_PW16 + 32 * kq + NP * ph);
-#pragma unroll
-                for (int i = 0; i < NP / 8; i++) {
-                    const int4 raw = src[i];
-                    const unsigned u[4] = {(unsigned) raw.x, (unsigned) raw.y, (unsigned) raw.z, (unsigned) raw.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { wb[8 * i + 2 * e] = h2f_bits((uint16_t) (u[e] & 0xFFFFu)); wb[8 * i + 2 * e + 1] = h2f_bits((uint16_t) (u[e] >> 16)); }
-                }
-            } else {
+            {
                 const float4 * src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(lw(buf)) + row * FX_PW32 + 32 * kq + NP * ph);
 #pragma unroll
                 for (int i = 0; i < NP / 4; i++) { const float4 v = src[i]; wb[4 * i] = v.x; wb[4 * i + 1] = v.y; wb[4 * i + 2] = v.z; wb[4 * i + 3] = v.w; }
